@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the UPSTREAM reference (imported from /root/reference, unmodified) in the
+build container.  Run:  python tools/make_golden.py          (needs /root/reference; never runs on the GPU box)
+
+The reference has no tests, golden vectors or fixtures of its own, so these vectors ARE the pin:
+every array below is an output of the reference's own functions
+  dataset/salsa_feature_extraction.py   extract_normalized_eigenvector (:17-129), MagStftExtractor (:132-201),
+                                         compute_scaler (:204-262), extract_features (:265-391)
+  dataset/salsa_lite_feature_extraction.py  extract_features (:18-137)
+driven through tools/ref_shims.py (librosa 0.8.0 / h5py / fire stand-ins -- third-party arithmetic restated there).
+Inputs are regenerated from seeds by salsa_amd/synth.py; each fixture stores the SHA-256 of every input so a drifted
+generator is detected.  Fixtures hold data only (inputs' hashes, parameters, expected outputs).
+"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+from dataset import salsa_feature_extraction as ref_salsa  # noqa: E402  (the reference)
+from dataset import salsa_lite_feature_extraction as ref_lite  # noqa: E402  (the reference)
+
+from salsa_amd.synth import sha256_of, synth_clip, synth_stft_block  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print('%-34s %8.1f KB  %s' % (name, os.path.getsize(path) / 1024, {k: v.shape for k, v in arrays.items()}))
+
+
+# ----------------------------------------------------------------------------------------------- G5: W + bin limits
+def g5_w_and_bins():
+    arrays, meta = {}, {'what': 'MagStftExtractor.W and bin-limit table', 'bins': []}
+    for n_fft, hop in ((512, 300), (256, 150)):
+        for comp in (True, False):
+            ex = ref_salsa.MagStftExtractor(n_fft=n_fft, hop_length=hop, win_length=n_fft, is_compress_high_freq=comp)
+            arrays['W_%d_%s' % (n_fft, 'c' if comp else 'n')] = ex.W
+    for fs, n_fft, fmin, fmax in ((24000, 512, 50, 9000), (24000, 512, 50, 4000), (24000, 512, 50, 2000),
+                                  (24000, 256, 50, 9000), (24000, 256, 50, 4000), (24000, 512, 0, 20000),
+                                  (48000, 512, 50, 9000), (16000, 512, 100, 7999), (32000, 256, 125, 5000)):
+        # exact statements of salsa_feature_extraction.py:298-304 (same in lite :50-54, cutoff :57-58)
+        fmax_c = np.min((fmax, fs // 2))
+        lower = int(np.floor(fmin * n_fft / float(fs)))
+        upper = int(np.floor(fmax_c * n_fft / float(fs)))
+        lower = int(np.max((1, lower)))
+        cutoff = int(np.floor(9000 * n_fft / float(fs)))
+        meta['bins'].append([fs, n_fft, fmin, fmax, lower, upper, cutoff])
+    save('g5_w_bins', meta, **arrays)
+
+
+# ----------------------------------------------------------------------------------------------- G1/G2/G7: eigvec
+def run_eig(X, fmt, track, cond=5.0, lower_bin=1, fs=24000, n_fft=512):
+    with np.errstate(all='ignore'):
+        return ref_salsa.extract_normalized_eigenvector(
+            X.astype(complex), condition_number=cond, n_hopframes=3, is_tracking=track, audio_format=fmt,
+            fs=fs, n_fft=n_fft, lower_bin=lower_bin)
+
+
+def g1_eigvec():
+    for seed, kind, nb, nt in ((0, 'mixed', 24, 96), (1, 'mixed', 16, 64), (2, 'noise', 12, 48)):
+        X = synth_stft_block(seed, nb, nt, kind=kind)
+        arrays, meta = {}, {'seed': seed, 'kind': kind, 'n_bins': nb, 'n_frames': nt, 'sha': sha256_of(X),
+                            'lower_bin': 1, 'fs': 24000, 'n_fft': 512, 'cond': 5.0}
+        for fmt in ('foa', 'mic'):
+            for track in (True, False):
+                arrays['%s_%s' % (fmt, 'track' if track else 'notrack')] = run_eig(X, fmt, track)
+        # G7: cond=0 makes the coherence gate vacuous (s0 > 0), so the non-zero pattern IS the tracker's indicator_sig
+        arrays['sig_mask'] = (np.abs(run_eig(X, 'foa', True, cond=0.0)).sum(axis=0) > 0)
+        arrays['foa_track_cond2'] = run_eig(X, 'foa', True, cond=2.0)
+        arrays['mic_track_lb7'] = run_eig(X, 'mic', True, lower_bin=7)
+        save('g1_eigvec_s%d' % seed, meta, **arrays)
+
+
+def g2_adversarial():
+    rng = np.random.RandomState(77)
+    nb, nt = 10, 40
+    cases = {}
+    # (a) exact rank-1: every frame a scalar multiple of one steering vector
+    steer = np.array([1.0, 0.5 - 0.25j, -0.75 + 0.1j, 0.2 + 0.6j])
+    s = rng.randn(nb, nt) + 1j * rng.randn(nb, nt)
+    cases['rank1'] = (s[:, :, None] * steer[None, None, :])
+    # (b) two orthogonal sources with amplitude ratio around sqrt(cond) -> lambda1/lambda2 around 5
+    a = np.array([1, 1, 1, 1]) / 2.0
+    b = np.array([1, -1, 1, -1]) / 2.0
+    Xb = np.zeros((nb, nt, 4), complex)
+    for ib in range(nb):
+        ratio = np.sqrt(5.0) * (0.98 + 0.004 * ib)      # straddles the gate
+        ph = np.exp(1j * rng.uniform(-np.pi, np.pi, nt))
+        ph2 = np.exp(1j * rng.uniform(-np.pi, np.pi, nt))
+        Xb[ib] = ratio * ph[:, None] * a[None, :] + ph2[:, None] * b[None, :]
+    cases['margin'] = Xb
+    # (c) silent block then signal: floor clamps at 1e-6, all-zero covariance
+    Xc = np.zeros((nb, nt, 4), complex)
+    Xc[:, 25:, :] = (rng.randn(nb, 15, 4) + 1j * rng.randn(nb, 15, 4)) * 1e-3
+    cases['silent'] = Xc
+    # (d) FOA W-channel component tiny: division by u[0,0] blows up (reference has no guard, :118)
+    Xd = (rng.randn(nb, nt, 1) + 1j * rng.randn(nb, nt, 1)) * np.array([1e-7, 1.0, 0.5, -0.3])[None, None, :]
+    Xd = Xd + 1e-9 * (rng.randn(nb, nt, 4) + 1j * rng.randn(nb, nt, 4))
+    cases['w_tiny'] = Xd
+    # (e) constant magnitude: tracker slow-rise path (countdown < 0) then falls behind
+    ph = np.exp(1j * rng.uniform(-np.pi, np.pi, (nb, nt, 1)))
+    cases['const_mag'] = ph * np.array([1.0, 0.3, 0.2, 0.1])[None, None, :] * \
+        (1.0 + 0.3 * np.sin(np.arange(nt) / 3.0))[None, :, None]
+    # (f) level steps: above/below-floor transitions reset the countdown
+    env = np.where((np.arange(nt) // 5) % 2 == 0, 1.0, 0.05)
+    cases['steps'] = (rng.randn(nb, nt, 4) + 1j * rng.randn(nb, nt, 4)) * env[None, :, None]
+    arrays, meta = {}, {'lower_bin': 1, 'fs': 24000, 'n_fft': 512, 'cond': 5.0, 'cases': sorted(cases)}
+    for name, X in cases.items():
+        X = X.astype(np.complex64)
+        arrays['X_' + name] = X          # adversarial inputs are stored (tiny), not regenerated
+        for fmt in ('foa', 'mic'):
+            for track in (True, False):
+                arrays['%s_%s_%s' % (name, fmt, 'track' if track else 'notrack')] = run_eig(X, fmt, track)
+        arrays['%s_sig_mask' % name] = (np.abs(run_eig(X, 'mic', True, cond=0.0)).sum(axis=0) != 0) | \
+                                       (np.abs(run_eig(X, 'foa', True, cond=0.0)).sum(axis=0) > 0)
+    save('g2_adversarial', meta, **arrays)
+
+
+# ----------------------------------------------------------------------------------------------- harness runs
+def make_tree(tmp, fmt, dev_clips, eval_clips, fs=24000, n_fft=512, hop=300, fmin=50, fmax=9000):
+    data_dir = os.path.join(tmp, 'data')
+    feat_dir = os.path.join(tmp, 'feat')
+    for split, clips in ((fmt + '_dev', dev_clips), (fmt + '_eval', eval_clips)):
+        d = os.path.join(data_dir, split)
+        os.makedirs(d, exist_ok=True)
+        for name, audio in clips.items():
+            p = os.path.join(d, name + '.wav')
+            open(p, 'wb').close()
+            ref_shims.register_audio(p, audio)
+    cfg = {'data_dir': data_dir, 'feature_dir': feat_dir,
+           'data': {'format': fmt, 'fs': fs, 'n_fft': n_fft, 'win_len': n_fft, 'hop_len': hop,
+                    'fmin_doa': fmin, 'fmax_doa': fmax}}
+    cfg_path = os.path.join(tmp, 'cfg.yml')
+    with open(cfg_path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    return cfg_path, feat_dir
+
+
+def collect(feat_dir):
+    out = {}
+    for path, dsets in ref_shims.H5_STORE.items():
+        if path.startswith(os.path.abspath(feat_dir)):
+            rel = os.path.relpath(path, feat_dir)
+            for k, v in dsets.items():
+                out[rel.replace(os.sep, '|') + '|' + k] = v
+    return out
+
+
+def g3_end_to_end():
+    specs = {
+        'foa': dict(fmax=9000, dev={'fold1_room1_mix001': (101, 36000), 'fold1_room1_mix002': (102, 24000),
+                                    'fold2_room1_mix003': (103, 19200)}, ev={'mix001': (104, 12000)}),
+        'mic': dict(fmax=4000, dev={'fold1_room1_mix001': (111, 24000), 'fold3_room2_mix007': (112, 19200)},
+                    ev={'mix001': (113, 9000)}),
+    }
+    for fmt, sp in specs.items():
+        tmp = tempfile.mkdtemp()
+        ref_shims.H5_STORE.clear()
+        dev = {k: synth_clip(s, n) for k, (s, n) in sp['dev'].items()}
+        ev = {k: synth_clip(s, n) for k, (s, n) in sp['ev'].items()}
+        cfg_path, feat_dir = make_tree(tmp, fmt, dev, ev, fmax=sp['fmax'])
+        with np.errstate(all='ignore'):
+            ref_salsa.extract_features(data_config=cfg_path, cond_num=5, n_hopframes=3, is_tracking=True,
+                                       is_compress_high_freq=True, task='feature_scaler')
+        arrays = collect(feat_dir)
+        meta = {'format': fmt, 'fmax_doa': sp['fmax'], 'fmin_doa': 50, 'fs': 24000, 'n_fft': 512, 'hop': 300,
+                'cond_num': 5, 'clips': {('dev|' + k): [s, n, sha256_of(dev[k])] for k, (s, n) in sp['dev'].items()}}
+        meta['clips'].update({('eval|' + k): [s, n, sha256_of(ev[k])] for k, (s, n) in sp['ev'].items()})
+        save('g3_salsa_%s' % fmt, meta, **arrays)
+        shutil.rmtree(tmp)
+    # variants: no tracking + no compression + n_fft 256 on one short FOA clip (dir-name suffixes are part of the pin)
+    for tag, kw, nfft, hop in (('notrack_nocompress', dict(is_tracking=False, is_compress_high_freq=False), 512, 300),
+                               ('nfft256', dict(is_tracking=True, is_compress_high_freq=True), 256, 150)):
+        tmp = tempfile.mkdtemp()
+        ref_shims.H5_STORE.clear()
+        dev = {'fold1_a': synth_clip(121, 9600)}
+        cfg_path, feat_dir = make_tree(tmp, 'foa', dev, {}, n_fft=nfft, hop=hop)
+        with np.errstate(all='ignore'):
+            ref_salsa.extract_features(data_config=cfg_path, cond_num=5, n_hopframes=3, task='feature', **kw)
+        arrays = collect(feat_dir)
+        meta = {'format': 'foa', 'fmax_doa': 9000, 'fmin_doa': 50, 'fs': 24000, 'n_fft': nfft, 'hop': hop,
+                'cond_num': 5, 'kw': kw, 'clips': {'dev|fold1_a': [121, 9600, sha256_of(dev['fold1_a'])]}}
+        save('g3_salsa_foa_%s' % tag, meta, **arrays)
+        shutil.rmtree(tmp)
+    # one longer clip (6 s) for tracker drift: spatial channels only, to keep the fixture small
+    tmp = tempfile.mkdtemp()
+    ref_shims.H5_STORE.clear()
+    dev = {'long': synth_clip(131, 144000)}
+    cfg_path, feat_dir = make_tree(tmp, 'foa', dev, {})
+    with np.errstate(all='ignore'):
+        ref_salsa.extract_features(data_config=cfg_path, cond_num=5, n_hopframes=3, task='feature')
+    arrays = collect(feat_dir)
+    (k, v), = arrays.items()
+    meta = {'format': 'foa', 'fmax_doa': 9000, 'fmin_doa': 50, 'fs': 24000, 'n_fft': 512, 'hop': 300, 'cond_num': 5,
+            'clips': {'dev|long': [131, 144000, sha256_of(dev['long'])]}, 'key': k,
+            'logspec_sum': float(v[:4].astype(np.float64).sum())}
+    save('g3_salsa_foa_long', meta, spatial=v[4:], logspec_stride8=v[:4, ::8])
+    shutil.rmtree(tmp)
+
+
+def g4_lite():
+    for ftype, clips in (('salsa_lite', {'fold1_room1_mix001': (141, 24000), 'fold2_room1_mix009': (142, 19200)}),
+                         ('salsa_ipd', {'fold1_room1_mix001': (143, 14400)})):
+        tmp = tempfile.mkdtemp()
+        ref_shims.H5_STORE.clear()
+        dev = {k: synth_clip(s, n) for k, (s, n) in clips.items()}
+        ev = {'mix001': synth_clip(149, 9000)}
+        cfg_path, feat_dir = make_tree(tmp, 'mic', dev, ev, fmax=2000)
+        with np.errstate(all='ignore'):
+            ref_lite.extract_features(data_config=cfg_path, feature_type=ftype, task='feature_scaler')
+        arrays = collect(feat_dir)
+        meta = {'format': 'mic', 'fmax_doa': 2000, 'fmin_doa': 50, 'fs': 24000, 'n_fft': 512, 'hop': 300,
+                'feature_type': ftype,
+                'clips': {('dev|' + k): [s, n, sha256_of(dev[k])] for k, (s, n) in clips.items()}}
+        meta['clips']['eval|mix001'] = [149, 9000, sha256_of(ev['mix001'])]
+        save('g4_%s' % ftype, meta, **arrays)
+        shutil.rmtree(tmp)
+
+
+def g8_stft():
+    """STFT boundary itself (third-party arithmetic, restated in ref_shims._stft): cross-checked against torch.stft
+    and an explicit per-frame rfft so the restatement is pinned by two independent implementations."""
+    import torch
+    y = synth_clip(151, 6000)[0]
+    S = ref_shims._stft(y, n_fft=512, hop_length=300, win_length=512)
+    St = torch.stft(torch.from_numpy(y).double(), 512, 300, 512, torch.hann_window(512, periodic=True,
+                    dtype=torch.float64), center=True, pad_mode='reflect', return_complex=True).numpy()
+    err = np.abs(S - St).max() / np.abs(St).max()
+    assert err < 1e-6, err
+    save('g8_stft', {'seed': 151, 'n': 6000, 'sha': sha256_of(y), 'torch_rel_err': float(err)}, stft=S)
+
+
+if __name__ == '__main__':
+    g5_w_and_bins()
+    g1_eigvec()
+    g2_adversarial()
+    g3_end_to_end()
+    g4_lite()
+    g8_stft()
