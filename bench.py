@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- SALSA feature-extraction throughput on N MI355X (BASELINE.json config 2).
+
+A step = one pass of the hot path (STFT -> log-spectrogram + noise gate + 4x4 covariance -> principal eigenvector)
+over one batch of 32 synthetic 60-s 4-channel 24-kHz clips already resident in HBM, FOA parameters (fmax_doa 9000,
+cond 5, tracking on, high-frequency compression on), output [32][7][4801][200] float32 in HBM.  Clips shard across
+ranks with no collective on the data path (weak scaling: 32 clips per GPU).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def _clip(args):
+    from salsa_amd.synth import synth_clip
+    return synth_clip(*args)
+
+
+def make_batch(seed0, batch, n_samples):
+    import multiprocessing as mp
+    jobs = [(seed0 + i, n_samples) for i in range(batch)]
+    try:
+        with mp.get_context('fork').Pool(min(batch, os.cpu_count() or 1, 16)) as pool:
+            clips = pool.map(_clip, jobs)
+    except Exception:
+        clips = [_clip(j) for j in jobs]
+    return np.stack(clips)
+
+
+def algorithmic_bytes(batch, n_samples, T, F):
+    """audio read once + feature array written once, per kernel (DESIGN.md 'Roofline')."""
+    return {
+        'stft_logspec': batch * (4 * n_samples * 4 + 4 * T * F * 4),
+        'noise_floor_tracker': 0,
+        'cov_eig': batch * (3 * T * F * 4),
+    }
+
+
+def cpu_baseline(feature, fmt, fmax, n_samples, budget_s=12.0, max_clips=16):
+    """The oracle (CPU restatement of the reference) timed on this host, all cores, on a bounded sample of the same
+    workload.  Clip synthesis is not billed."""
+    from oracle import oracle as orc
+    from salsa_amd.synth import synth_clip
+    orc.build()
+    cores = orc.max_threads()
+    orc.set_threads(cores)
+    clips, acc = 0, 0.0
+    while clips < max_clips and acc < budget_s:
+        y = synth_clip(2021 + clips, n_samples)
+        t1 = time.perf_counter()
+        if feature == 'salsa':
+            orc.extract_salsa(y, fmax_doa=fmax, audio_format=fmt)
+        else:
+            orc.extract_lite(y, fmax_doa=fmax, feature_type=feature)
+        acc += time.perf_counter() - t1
+        clips += 1
+    secs = n_samples / 24000.0
+    return {'value': round(clips * secs / acc, 2), 'unit': 'audio-seconds/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d x %.0f-s clips (seeds 2021..), oracle/salsa_oracle.c = float64 C restatement of the '
+                      'reference, OpenMP over bins/frames, %.1f s wall' % (clips, secs, acc)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU per step')
+    ap.add_argument('--seconds', type=float, default=60.0)
+    ap.add_argument('--feature', default='salsa', choices=['salsa', 'salsa_lite', 'salsa_ipd'])
+    ap.add_argument('--format', default=None, choices=['foa', 'mic'])
+    ap.add_argument('--fmax-doa', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    fmt = args.format or ('foa' if args.feature == 'salsa' else 'mic')
+    fmax = args.fmax_doa or (9000 if args.feature == 'salsa' and fmt == 'foa' else 4000 if args.feature == 'salsa' else 2000)
+    n_samples = int(round(args.seconds * 24000))
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+
+    # synthesise this rank's clips before touching the GPU (fork-safe); seeds 2021.. as SURVEY 8(d) config 2
+    host = make_batch(2021 + rank * args.batch, args.batch, n_samples)
+
+    import torch
+    import torch.distributed as dist
+    from salsa_amd.extractor import SalsaExtractor
+
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    ex = SalsaExtractor(audio_format=fmt, feature_type=args.feature, fmax_doa=fmax, device=dev)
+    audio = torch.from_numpy(host).to(dev)
+    Cn, T, F = ex.output_shape(n_samples)
+    out = torch.empty((args.batch, Cn, T, F), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ex.extract(audio, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex.extract(audio, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel durations: HIP events recorded by the library on the launch stream, separate pass (not in `value`)
+    kernels = []
+    roofline = None
+    cpu = None
+    if rank == 0:
+        ex.set_timing(True)
+        sums, n_t = {}, max(3, min(args.steps, 10))
+        for _ in range(n_t):
+            ex.extract(audio, out=out)
+            for name, ms in ex.read_timing():
+                sums[name] = sums.get(name, 0.0) + ms
+        ex.set_timing(False)
+        ab = algorithmic_bytes(args.batch, n_samples, T, F)
+        if args.feature != 'salsa':
+            ab = {'stft_logspec': args.batch * (4 * n_samples * 4 + 7 * T * F * 4)}
+        for name, tot in sums.items():
+            ms = tot / n_t
+            b = ab.get(name, 0)
+            kernels.append({'name': name, 'ms': round(ms, 4), 'algorithmic_bytes': b,
+                            'GBps': round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        dom = max(kernels, key=lambda k: k['ms'])
+        pipe_ms = sum(k['ms'] for k in kernels)
+        pipe_bytes = sum(ab.values())
+        roofline = {'bound': 'hbm', 'kernel': dom['name'], 'kernel_ms': dom['ms'],
+                    'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(dom['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'pipeline': {'ms': round(pipe_ms, 4), 'algorithmic_bytes': pipe_bytes,
+                                 'achieved': round(pipe_bytes / (pipe_ms * 1e-3) / 1e9, 1),
+                                 'frac': round(pipe_bytes / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    'kernels': kernels}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    audio_s = world * args.batch * args.seconds * args.steps
+    line = {
+        'metric': 'SALSA feat-extract audio-s/s',
+        'value': round(audio_s / elapsed, 1),
+        'unit': 'audio-seconds/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': 'Full SALSA %s (eigenvector path): batch %dx%.0f-s 4-ch 24 kHz clips per GPU, '
+                               'feature-extract only, n_fft 512 hop 300 fmax_doa %d cond 5 tracking on'
+                               % (fmt.upper(), args.batch, args.seconds, fmax) if args.feature == 'salsa' else
+                               '%s MIC: batch %dx%.0f-s clips per GPU' % (args.feature, args.batch, args.seconds),
+                   'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'feature': args.feature,
+                   'format': fmt, 'sharding': 'clips/%d (no collective)' % world},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,111 @@
+/*
+ * salsa_hip.h -- C ABI of libsalsa_hip.so, the MI355X (gfx950) SALSA / SALSA-Lite feature extractor.
+ *
+ * The upstream reference (thomeou/SALSA) is pure Python and has no FFI layer: its boundary is a set of Python
+ * function signatures plus the (7, T, F) float32 feature array they produce.  Each entry point below replaces one of
+ * those, batched over clips and operating on caller-owned DEVICE memory (plain pointers and sizes, no torch types);
+ * salsa_amd/features.py re-exposes the reference's own signatures on top of them.
+ *
+ *   reference interface (file:line, relative to the upstream repo)               replaced by
+ *   ---------------------------------------------------------------------------  ---------------------------------
+ *   extract_features() per-file body, dataset/salsa_feature_extraction.py:353-377 salsa_extract_batch (SALSA)
+ *   extract_features() per-file body, dataset/salsa_lite_feature_extraction.py:94-123  salsa_extract_batch (LITE/IPD)
+ *   MagStftExtractor.extract, dataset/salsa_feature_extraction.py:177-201         salsa_logspec_batch
+ *   extract_normalized_eigenvector, dataset/salsa_feature_extraction.py:17-129    salsa_eigvec_batch
+ *   bin limits / freq_dim, dataset/salsa_feature_extraction.py:298-313 (+ lite :50-59)  salsa_bin_limits, salsa_output_shape
+ *   MagStftExtractor.W, dataset/salsa_feature_extraction.py:152-175               salsa_compress_matrix (host)
+ *
+ * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
+ * message of the calling thread's last failure.  Device pointers are caller-owned; work is enqueued asynchronously
+ * on the HIP stream passed in (NULL = the default stream) and nothing is allocated or synchronised inside the
+ * extract calls, so they are hipGraph-capturable.  A plan is bound to the device current at salsa_plan_create.
+ */
+#ifndef SALSA_HIP_H
+#define SALSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SALSA_ABI_VERSION 1
+
+enum { SALSA_FORMAT_FOA = 0, SALSA_FORMAT_MIC = 1 };                      /* cfg['data']['format'] */
+enum { SALSA_FEATURE_SALSA = 0, SALSA_FEATURE_LITE = 1, SALSA_FEATURE_IPD = 2 }; /* 'salsa' | 'salsa_lite' | 'salsa_ipd' */
+enum { SALSA_LAYOUT_PLANAR = 0, SALSA_LAYOUT_INTERLEAVED = 1 };           /* [B][4][N] (librosa.load) | [B][N][4] (WAV) */
+
+enum {
+    SALSA_OK = 0,
+    SALSA_EINVAL = -1,     /* bad argument (NULL pointer, negative size, ...) */
+    SALSA_ENFFT = -2,      /* n_fft not in {256, 512}: the reference's assert, salsa_feature_extraction.py:152,306 */
+    SALSA_EFORMAT = -3,    /* unknown audio format: the reference's ValueError, :125,:332 ; lite requires MIC, lite :72 */
+    SALSA_EBINS = -4,      /* upper_bin > cutoff_bin (lite :59) or an empty / oversized DOA band */
+    SALSA_EWORKSPACE = -5, /* workspace smaller than salsa_workspace_bytes() */
+    SALSA_EHIP = -6        /* a HIP runtime call failed (message in salsa_last_error) */
+};
+
+/* Mirrors the keyword arguments of the reference's extract_features() + the cfg['data'] block of its YAML. */
+typedef struct salsa_params {
+    int fs;                    /* 24000 */
+    int n_fft;                 /* 512 | 256 */
+    int hop_len;               /* 300 */
+    int win_len;               /* <= n_fft */
+    int fmin_doa;              /* Hz */
+    int fmax_doa;              /* Hz (clamped to fs/2 like the reference) */
+    double cond_num;           /* coherence threshold, default 5 */
+    int n_hopframes;           /* default 3 ("do not change") */
+    int is_tracking;           /* noise-floor tracking */
+    int is_compress_high_freq; /* 200/100-bin compressed log-spectrogram */
+    int audio_format;          /* SALSA_FORMAT_* */
+    int feature_type;          /* SALSA_FEATURE_* */
+    int audio_layout;          /* SALSA_LAYOUT_* */
+    int reserved;
+} salsa_params;
+
+typedef struct salsa_plan salsa_plan;
+
+int salsa_abi_version(void);
+const char *salsa_last_error(void);
+
+/* lower_bin, upper_bin (exclusive) and the lite spectrogram cutoff bin, bit-exact integer arithmetic of the reference */
+int salsa_bin_limits(int fs, int n_fft, int fmin_doa, int fmax_doa, int *lower_bin, int *upper_bin, int *cutoff_bin);
+/* host: the (freq_dim x n_fft/2+1) float32 row-major compression matrix W (what the kernels apply implicitly) */
+int salsa_compress_matrix(int n_fft, int is_compress_high_freq, float *W_host);
+
+int salsa_plan_create(const salsa_params *params, salsa_plan **out_plan);
+int salsa_plan_destroy(salsa_plan *plan);
+/* feature array shape for clips of n_samples: C = 7, T = 1 + n_samples / hop_len, F = 200 | 100 | n_fft/2 | cutoff-lower */
+int salsa_output_shape(const salsa_plan *plan, int64_t n_samples, int *C, int64_t *T, int *F);
+/* scratch bytes salsa_extract_batch needs for (batch, n_samples) */
+size_t salsa_workspace_bytes(const salsa_plan *plan, int batch, int64_t n_samples);
+
+/* d_audio: float32 [B][4][N] (planar) or [B][N][4] (interleaved) ; d_out: float32 [B][7][T][F], fully written. */
+int salsa_extract_batch(salsa_plan *plan, const float *d_audio, int batch, int64_t n_samples, float *d_out,
+                        void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
+/* MagStftExtractor.extract: d_audio float32 [B][C][N] planar (any C that is a multiple of 2) -> d_out [B][C][T][F] */
+int salsa_logspec_batch(salsa_plan *plan, const float *d_audio, int batch, int n_channels, int64_t n_samples,
+                        float *d_out, void *hip_stream);
+
+/* extract_normalized_eigenvector: d_X complex64 [B][n_bins][n_frames][4] (the reference's (n_bins,n_frames,n_chans)),
+ * d_out float64 [B][3][n_bins][n_frames].  Uses plan's cond_num / n_hopframes / is_tracking / audio_format / fs /
+ * n_fft; lower_bin as given (it only enters the MIC normalisation).  d_gate (optional, may be NULL): uint8
+ * [B][n_bins][n_frames], 0 = rejected by the noise gate, 1 = failed the coherence test, 2 = emitted. */
+size_t salsa_eigvec_workspace_bytes(const salsa_plan *plan, int batch, int n_bins, int64_t n_frames);
+int salsa_eigvec_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
+                       double *d_out, unsigned char *d_gate, void *d_workspace, size_t workspace_bytes,
+                       void *hip_stream);
+
+/* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
+ * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the
+ * milliseconds of the last call's kernels in launch order (n_out <= SALSA_MAX_KERNELS) and their names. */
+#define SALSA_MAX_KERNELS 8
+int salsa_plan_set_timing(salsa_plan *plan, int enable);
+int salsa_plan_read_timing(salsa_plan *plan, float *ms, const char **names, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALSA_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libsalsa_hip.so (C ABI in include/salsa_hip.h).  There is no CPU fallback: if the HIP library
+is missing this module raises, loudly, with the build command."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsalsa_hip.so')
+SRC_PATH = os.path.join(_HERE, 'csrc', 'salsa_kernels.hip')
+
+FORMAT = {'foa': 0, 'mic': 1}
+FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
+LAYOUT = {'planar': 0, 'interleaved': 1}
+MAX_KERNELS = 8
+
+E_INVAL, E_NFFT, E_FORMAT, E_BINS, E_WORKSPACE, E_HIP = -1, -2, -3, -4, -5, -6
+
+
+class SalsaParams(C.Structure):
+    _fields_ = [('fs', C.c_int), ('n_fft', C.c_int), ('hop_len', C.c_int), ('win_len', C.c_int),
+                ('fmin_doa', C.c_int), ('fmax_doa', C.c_int), ('cond_num', C.c_double), ('n_hopframes', C.c_int),
+                ('is_tracking', C.c_int), ('is_compress_high_freq', C.c_int), ('audio_format', C.c_int),
+                ('feature_type', C.c_int), ('audio_layout', C.c_int), ('reserved', C.c_int)]
+
+
+_lib = None
+
+
+def build_command():
+    return ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB_PATH, SRC_PATH]
+
+
+def load():
+    """Load libsalsa_hip.so; raise if it has not been built (the product never falls back to CPU code)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libsalsa_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; '
+                           'g.build()"` or: %s' % (LIB_PATH, ' '.join(build_command())))
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.salsa_abi_version.restype = C.c_int
+    L.salsa_last_error.restype = C.c_char_p
+    L.salsa_bin_limits.argtypes = [C.c_int] * 4 + [ip, ip, ip]
+    L.salsa_compress_matrix.argtypes = [C.c_int, C.c_int, fp]
+    L.salsa_plan_create.argtypes = [C.POINTER(SalsaParams), C.POINTER(vp)]
+    L.salsa_plan_destroy.argtypes = [vp]
+    L.salsa_output_shape.argtypes = [vp, C.c_int64, ip, C.POINTER(C.c_int64), ip]
+    L.salsa_workspace_bytes.restype = C.c_size_t
+    L.salsa_workspace_bytes.argtypes = [vp, C.c_int, C.c_int64]
+    L.salsa_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int64, vp, vp, C.c_size_t, vp]
+    L.salsa_logspec_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp]
+    L.salsa_eigvec_workspace_bytes.restype = C.c_size_t
+    L.salsa_eigvec_workspace_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
+    L.salsa_eigvec_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.c_size_t, vp]
+    L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
+    L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().salsa_last_error().decode()
+
+
+EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
+           'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
+           'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
+           'salsa_plan_read_timing']

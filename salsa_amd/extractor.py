@@ -1,0 +1,170 @@
+"""Device-side front end: a plan over libsalsa_hip.so operating on torch CUDA(HIP) tensors.
+
+torch is plumbing only (device memory, streams): every FLOP of the feature path runs in the hand-written HIP kernels
+of salsa_amd/csrc/salsa_kernels.hip behind the C ABI of include/salsa_hip.h."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _raise(rc):
+    msg = _lib.last_error()
+    if rc == _lib.E_NFFT:
+        raise AssertionError(msg)            # the reference asserts n_fft in (256, 512)
+    if rc == _lib.E_FORMAT:
+        if 'only for MIC' in msg:
+            raise AssertionError(msg)        # salsa_lite_feature_extraction.py:72
+        raise ValueError(msg)                # salsa_feature_extraction.py:125, :332
+    if rc == _lib.E_BINS:
+        raise AssertionError(msg)            # lite :59
+    if rc == _lib.E_INVAL:
+        raise ValueError(msg)
+    raise RuntimeError('libsalsa_hip: %s (code %d)' % (msg, rc))
+
+
+def bin_limits(fs, n_fft, fmin_doa, fmax_doa):
+    """(lower_bin, upper_bin, cutoff_bin) -- salsa_feature_extraction.py:298-304, lite :57-58 (host integer math)."""
+    lo, up, cut = C.c_int(), C.c_int(), C.c_int()
+    rc = _lib.load().salsa_bin_limits(int(fs), int(n_fft), int(fmin_doa), int(fmax_doa), C.byref(lo), C.byref(up),
+                                      C.byref(cut))
+    if rc:
+        _raise(rc)
+    return lo.value, up.value, cut.value
+
+
+def compress_matrix(n_fft, is_compress_high_freq=True):
+    """MagStftExtractor.W (salsa_feature_extraction.py:152-175) as the kernels apply it."""
+    if n_fft not in (256, 512):
+        raise AssertionError('nfft is not 512 or 256')
+    F = (200 if n_fft == 512 else 100) if is_compress_high_freq else n_fft // 2
+    W = np.zeros((F, n_fft // 2 + 1), np.float32)
+    rc = _lib.load().salsa_compress_matrix(n_fft, int(is_compress_high_freq), W.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        _raise(rc)
+    return W
+
+
+class SalsaExtractor:
+    """Batched SALSA / SALSA-Lite / SALSA-IPD feature extraction on one MI355X.
+
+    Keyword names follow the reference's extract_features() and its YAML ``data`` block."""
+
+    def __init__(self, fs=24000, n_fft=512, hop_len=300, win_len=None, fmin_doa=50, fmax_doa=9000, cond_num=5.0,
+                 n_hopframes=3, is_tracking=True, is_compress_high_freq=True, audio_format='foa',
+                 feature_type='salsa', audio_layout='planar', device=None):
+        if audio_format not in _lib.FORMAT:
+            raise ValueError('Unknown audio format {}'.format(audio_format))
+        assert feature_type in _lib.FEATURE, 'Invalid feature type {}'.format(feature_type)
+        self.L = _lib.load()
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.params = _lib.SalsaParams(
+            fs=int(fs), n_fft=int(n_fft), hop_len=int(hop_len), win_len=int(win_len or n_fft), fmin_doa=int(fmin_doa),
+            fmax_doa=int(fmax_doa), cond_num=float(cond_num), n_hopframes=int(n_hopframes),
+            is_tracking=int(bool(is_tracking)), is_compress_high_freq=int(bool(is_compress_high_freq)),
+            audio_format=_lib.FORMAT[audio_format], feature_type=_lib.FEATURE[feature_type],
+            audio_layout=_lib.LAYOUT[audio_layout], reserved=0)
+        self.audio_layout = audio_layout
+        self.feature_type = feature_type
+        self._plan = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_plan_create(C.byref(self.params), C.byref(self._plan))
+        if rc:
+            self._plan = None
+            _raise(rc)
+        self._ws = None
+
+    def __del__(self):
+        if getattr(self, '_plan', None):
+            self.L.salsa_plan_destroy(self._plan)
+            self._plan = None
+
+    # ------------------------------------------------------------------------------------------------ shapes
+    def output_shape(self, n_samples):
+        c, t, f = C.c_int(), C.c_int64(), C.c_int()
+        rc = self.L.salsa_output_shape(self._plan, int(n_samples), C.byref(c), C.byref(t), C.byref(f))
+        if rc:
+            _raise(rc)
+        return c.value, t.value, f.value
+
+    def workspace_bytes(self, batch, n_samples):
+        return int(self.L.salsa_workspace_bytes(self._plan, int(batch), int(n_samples)))
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------------------------------------ hot path
+    def extract(self, audio: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """audio float32 CUDA [B,4,N] (planar) or [B,N,4] (interleaved) -> features float32 [B,7,T,F]."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.is_contiguous()
+        if self.audio_layout == 'planar':
+            B, ch, N = audio.shape
+        else:
+            B, N, ch = audio.shape
+        assert ch == 4, 'SALSA features are defined for 4-channel clips'
+        Cn, T, F = self.output_shape(N)
+        if out is None:
+            out = torch.empty((B, Cn, T, F), dtype=torch.float32, device=audio.device)
+        else:
+            assert out.shape == (B, Cn, T, F) and out.dtype == torch.float32 and out.is_contiguous() and out.is_cuda
+        nws = self.workspace_bytes(B, N)
+        ws = self._workspace(nws)
+        rc = self.L.salsa_extract_batch(self._plan, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        if rc:
+            _raise(rc)
+        return out
+
+    __call__ = extract
+
+    def logspec(self, audio: torch.Tensor) -> torch.Tensor:
+        """MagStftExtractor.extract on device: audio [B,4,N] planar -> [B,4,T,F]."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.is_contiguous()
+        B, ch, N = audio.shape
+        assert ch == 4
+        n_fft = self.params.n_fft
+        F = ((200 if n_fft == 512 else 100) if self.params.is_compress_high_freq else n_fft // 2)
+        T = 1 + N // self.params.hop_len
+        out = torch.empty((B, 4, T, F), dtype=torch.float32, device=audio.device)
+        rc = self.L.salsa_logspec_batch(self._plan, C.c_void_p(audio.data_ptr()), B, 4, N,
+                                        C.c_void_p(out.data_ptr()), self._stream())
+        if rc:
+            _raise(rc)
+        return out
+
+    def eigvec(self, X: torch.Tensor, lower_bin: int, return_gate: bool = False):
+        """extract_normalized_eigenvector on device: X complex64 [B,n_bins,n_frames,4] -> float64 [B,3,n_bins,n_frames]."""
+        assert X.is_cuda and X.dtype == torch.complex64 and X.dim() == 4 and X.shape[3] == 4 and X.is_contiguous()
+        B, nb, nt, _ = X.shape
+        out = torch.empty((B, 3, nb, nt), dtype=torch.float64, device=X.device)
+        gate = torch.empty((B, nb, nt), dtype=torch.uint8, device=X.device)
+        nws = int(self.L.salsa_eigvec_workspace_bytes(self._plan, B, nb, nt))
+        ws = self._workspace(nws)
+        rc = self.L.salsa_eigvec_batch(self._plan, C.c_void_p(X.data_ptr()), B, nb, nt, int(lower_bin),
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(gate.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        if rc:
+            _raise(rc)
+        return (out, gate) if return_gate else out
+
+    # ------------------------------------------------------------------------------------------------ timing
+    def set_timing(self, enable: bool):
+        self.L.salsa_plan_set_timing(self._plan, int(bool(enable)))
+
+    def read_timing(self):
+        """[(kernel name, milliseconds)] of the last extract() call (HIP events on its stream)."""
+        ms = (C.c_float * _lib.MAX_KERNELS)()
+        names = (C.c_char_p * _lib.MAX_KERNELS)()
+        n = C.c_int()
+        rc = self.L.salsa_plan_read_timing(self._plan, ms, names, C.byref(n))
+        if rc:
+            _raise(rc)
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

@@ -1,0 +1,111 @@
+// tests/hostemu/hostemu.cpp -- CPU unit-test harness for salsa_amd/csrc/salsa_math.h (the per-thread arithmetic of the
+// HIP kernels).  TEST INFRASTRUCTURE ONLY: it lets `pytest -m "not gpu"` exercise the kernels' butterflies, Stockham
+// addressing and eigen-gate on CPU (no GPU in the build container).  The product never loads it and has no CPU path.
+#include "../../salsa_amd/csrc/salsa_math.h"
+#include <vector>
+using namespace salsa;
+
+extern "C" {
+
+// One N-point complex FFT through the kernel's Stockham addressing + dftR butterflies (float64 or float32).
+int hostemu_fft(const double *in_re, const double *in_im, int N, int use_f32, double *out_re, double *out_im)
+{
+    const int R = (N == 512) ? 8 : (N == 256 ? 4 : 0);
+    if (!R) return -1;
+    std::vector<cplx<double>> tw(N);
+    for (int m = 0; m < N; m++) tw[m] = {cos(-2.0 * M_PI * m / N), sin(-2.0 * M_PI * m / N)};
+    if (use_f32) {
+        std::vector<cplx<float>> x(N), y(N);
+        for (int n = 0; n < N; n++) x[n] = {(float)in_re[n], (float)in_im[n]};
+        for (int p = 1; p < N; p *= R) {
+            for (int i = 0; i < N / R; i++) {
+                cplx<float> v[8];
+                for (int r = 0; r < R; r++) {
+                    v[r] = x[stockham_in(i, r, N, R)];
+                    int e = stockham_tw(i, r, p, N, R);
+                    v[r] = cmul(v[r], cplx<float>{(float)tw[e].re, (float)tw[e].im});
+                }
+                if (R == 8) dftR<8>(v); else dftR<4>(v);
+                for (int r = 0; r < R; r++) y[stockham_out(i, r, p, R)] = v[r];
+            }
+            x.swap(y);
+        }
+        for (int n = 0; n < N; n++) { out_re[n] = x[n].re; out_im[n] = x[n].im; }
+        return 0;
+    }
+    std::vector<cplx<double>> x(N), y(N);
+    for (int n = 0; n < N; n++) x[n] = {in_re[n], in_im[n]};
+    for (int p = 1; p < N; p *= R) {
+        for (int i = 0; i < N / R; i++) {
+            cplx<double> v[8];
+            for (int r = 0; r < R; r++) {
+                v[r] = x[stockham_in(i, r, N, R)];
+                v[r] = cmul(v[r], tw[stockham_tw(i, r, p, N, R)]);
+            }
+            if (R == 8) dftR<8>(v); else dftR<4>(v);
+            for (int r = 0; r < R; r++) y[stockham_out(i, r, p, R)] = v[r];
+        }
+        x.swap(y);
+    }
+    for (int n = 0; n < N; n++) { out_re[n] = x[n].re; out_im[n] = x[n].im; }
+    return 0;
+}
+
+// two real sequences through one packed complex FFT + unpack_pair
+int hostemu_rfft_pair(const double *x0, const double *x1, int N, double *X0 /*[N/2+1][2]*/, double *X1)
+{
+    std::vector<double> re(N), im(N);
+    if (hostemu_fft(x0, x1, N, 0, re.data(), im.data())) return -1;
+    for (int k = 0; k <= N / 2; k++) {
+        cplx<double> a = {re[k], im[k]}, b = {re[(N - k) % N], im[(N - k) % N]}, u, v;
+        unpack_pair(a, b, u, v);
+        X0[2 * k] = u.re; X0[2 * k + 1] = u.im;
+        X1[2 * k] = v.re; X1[2 * k + 1] = v.im;
+    }
+    return 0;
+}
+
+// The eigenvector stage exactly as the cov/eig kernel evaluates it per TF bin.
+// X [nb][nt][4] c64 ; out [3][nb][nt] f64 ; rank [nb][nt] u8 (0 not evaluated, 1 fail, 2 pass)
+int hostemu_eigvec(const float *X, int nb, long nt, double cond, int n_hop, int tracking, int format, double delta,
+                   int lower_bin, double *out, unsigned char *rank)
+{
+    for (size_t i = 0; i < (size_t)3 * nb * nt; i++) out[i] = 0.0;
+    for (int b = 0; b < nb; b++) {
+        const float *Xb = X + (size_t)b * nt * 8;
+        auto pw = [&](long t) {
+            t = ((t % nt) + nt) % nt;
+            double re = Xb[t * 8], im = Xb[t * 8 + 1];
+            return re * re + im * im;
+        };
+        auto mag = [&](long t) { return sqrt(((0.0 + pw(t)) + pw(t - 1) + pw(t - 2)) / 3); };
+        long n0 = nt < 5 ? nt : 5;
+        double acc = 0;
+        for (long t = 0; t < n0; t++) acc += mag(t);
+        tracker_state st = {0.5 * (acc / (double)n0), 3};
+        for (long t = 0; t < nt; t++) {
+            bool sig = tracker_step(st, mag(t));
+            rank[(size_t)b * nt + t] = 0;
+            if (tracking && !sig) continue;
+            herm4<double> R = {};
+            for (int k = -n_hop; k <= n_hop; k++) {
+                long tt = (((t + k) % nt) + nt) % nt;
+                cplx<double> x[4];
+                for (int c = 0; c < 4; c++) x[c] = {(double)Xb[tt * 8 + 2 * c], (double)Xb[tt * 8 + 2 * c + 1]};
+                herm4_rank1_add(R, x);
+            }
+            eig_result<double> er = herm4_gate_eigvec(R, cond, !tracking);
+            rank[(size_t)b * nt + t] = er.rank1 ? 2 : 1;
+            if (tracking && !er.rank1) continue;
+            double e[3];
+            if (format == 0) normalise_foa(er.u, e);
+            else normalise_mic(er.u, delta * (double)(b + lower_bin), e);
+            for (int i = 0; i < 3; i++) out[((size_t)i * nb + b) * nt + t] = e[i];
+        }
+    }
+    return 0;
+}
+
+long hostemu_reflect(long i, long N) { return reflect_index(i, N); }
+
+} // extern "C"

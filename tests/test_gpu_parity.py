@@ -1,0 +1,229 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI (libsalsa_hip.so via
+salsa_amd.extractor), against (i) the golden vectors produced by the reference itself and (ii) the CPU oracle on
+seeded inputs.  Tolerances (BASELINE.json north_star): bit-exact frame/bin indexing and gates, 1e-5 relative on
+floats.  A gate disagreement is admissible only inside float64 round-off of the threshold (|margin| < 1e-9)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_clip, load_golden
+from salsa_amd.synth import sha256_of, synth_clip, synth_stft_block
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_DB, ATOL_SP = 1e-5, 2e-5, 1e-6
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def _extractor(**kw):
+    from salsa_amd.extractor import SalsaExtractor
+    return SalsaExtractor(**kw)
+
+
+def _gpu_features(y, dev, **kw):
+    ex = _extractor(**kw)
+    a = torch.from_numpy(np.ascontiguousarray(y[None])).to(dev)
+    return ex.extract(a)[0].cpu().numpy()
+
+
+def _check(out, ref, margin=None, n_spec=4):
+    """out/ref (7,T,F).  margin: oracle gate margins (nd,T) to justify gate flips, or None (no flips allowed)."""
+    assert out.shape == ref.shape and out.dtype == np.float32
+    np.testing.assert_allclose(out[:n_spec], ref[:n_spec], rtol=RTOL, atol=ATOL_DB)
+    with np.errstate(invalid='ignore'):
+        bad = np.abs(out[n_spec:] - ref[n_spec:]) > ATOL_SP + RTOL * np.abs(ref[n_spec:])
+    bad = bad.any(axis=0)                              # (T, F)
+    if bad.any():
+        assert margin is not None, 'spatial channels differ in %d TF bins' % bad.sum()
+        nd = margin.shape[0]
+        assert not bad[:, nd:].any()
+        m = np.abs(margin.T[bad[:, :nd]])
+        assert np.all(m < 1e-9), 'gate/values differ outside round-off of the threshold: %s' % m[:8]
+        assert bad.sum() <= max(2, int(2e-5 * bad.size))
+
+
+# ----------------------------------------------------------------------------------------------- eigenvector stage
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_eigvec_matches_reference_golden(dev, seed):
+    meta, a = load_golden('g1_eigvec_s%d' % seed)
+    X = synth_stft_block(seed, meta['n_bins'], meta['n_frames'], kind=meta['kind'])
+    assert sha256_of(X) == meta['sha']
+    Xd = torch.from_numpy(X[None]).to(dev)
+    for fmt in ('foa', 'mic'):
+        for track in (True, False):
+            ex = _extractor(audio_format=fmt, is_tracking=track, fmax_doa=9000 if fmt == 'foa' else 4000)
+            out, gate = ex.eigvec(Xd, lower_bin=1, return_gate=True)
+            ref = a['%s_%s' % (fmt, 'track' if track else 'notrack')]
+            np.testing.assert_allclose(out[0].cpu().numpy(), ref, rtol=1e-8, atol=1e-9)
+            if track:
+                g = gate[0].cpu().numpy()
+                assert np.array_equal(g > 0, a['sig_mask'])         # tracker indicator bit-exact
+    ex = _extractor(audio_format='foa', cond_num=2.0)
+    np.testing.assert_allclose(ex.eigvec(Xd, 1)[0].cpu().numpy(), a['foa_track_cond2'], rtol=1e-8, atol=1e-9)
+    ex = _extractor(audio_format='mic', fmax_doa=4000)
+    np.testing.assert_allclose(ex.eigvec(Xd, 7)[0].cpu().numpy(), a['mic_track_lb7'], rtol=1e-8, atol=1e-9)
+
+
+def test_eigvec_adversarial_golden(dev, oracle):
+    meta, a = load_golden('g2_adversarial')
+    for case in meta['cases']:
+        X = a['X_' + case]
+        Xd = torch.from_numpy(np.ascontiguousarray(X[None])).to(dev)
+        for fmt in ('foa', 'mic'):
+            for track in (True, False):
+                ref = a['%s_%s_%s' % (case, fmt, 'track' if track else 'notrack')]
+                ex = _extractor(audio_format=fmt, is_tracking=track, fmax_doa=9000 if fmt == 'foa' else 4000)
+                out = ex.eigvec(Xd, 1)[0].cpu().numpy()
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(out), fin), (case, fmt, track)
+                tol = 1e-5 if case == 'w_tiny' else 1e-8
+                with np.errstate(invalid='ignore'):
+                    bad = ((np.abs(out - ref) > tol * (0.1 + np.abs(ref))) & fin).any(axis=0)
+                if case == 'margin' and track:
+                    _, aux = oracle.extract_normalized_eigenvector(X, 5.0, 3, True, fmt, fs=24000, n_fft=512,
+                                                                   lower_bin=1, return_aux=True)
+                    assert np.all(np.abs(aux['margin'][bad]) < 1e-9)
+                else:
+                    assert not bad.any(), (case, fmt, track, int(bad.sum()))
+        ex = _extractor(audio_format='foa', cond_num=0.0)
+        _, gate = ex.eigvec(Xd, 1, return_gate=True)
+        assert np.array_equal(gate[0].cpu().numpy() > 0, a[case + '_sig_mask']), case
+
+
+# ----------------------------------------------------------------------------------------------- end-to-end goldens
+def _golden_items(meta, a):
+    clips = {k: golden_clip(*v) for k, v in meta['clips'].items()}
+    for key, ref in a.items():
+        parts = key.split('|')
+        if parts[-1] != 'feature':
+            continue
+        split, name = parts[3], parts[4][:-3]
+        yield key, clips[('dev|' if split.endswith('_dev') else 'eval|') + name], ref
+
+
+@pytest.mark.parametrize('fmt', ['foa', 'mic'])
+def test_full_salsa_matches_reference_golden(dev, oracle, fmt):
+    meta, a = load_golden('g3_salsa_%s' % fmt)
+    for key, y, ref in _golden_items(meta, a):
+        out = _gpu_features(y, dev, audio_format=fmt, fmax_doa=meta['fmax_doa'])
+        _, aux = oracle.extract_salsa(y, fmax_doa=meta['fmax_doa'], audio_format=fmt, return_aux=True)
+        _check(out, ref, aux['margin'])
+
+
+def test_full_salsa_variants_match_reference_golden(dev):
+    meta, a = load_golden('g3_salsa_foa_notrack_nocompress')
+    for key, y, ref in _golden_items(meta, a):
+        _check(_gpu_features(y, dev, is_tracking=False, is_compress_high_freq=False), ref)
+    meta, a = load_golden('g3_salsa_foa_nfft256')
+    for key, y, ref in _golden_items(meta, a):
+        _check(_gpu_features(y, dev, n_fft=256, hop_len=150), ref)
+    meta, a = load_golden('g3_salsa_foa_long')
+    y = golden_clip(*meta['clips']['dev|long'])
+    out = _gpu_features(y, dev)
+    np.testing.assert_allclose(out[4:], a['spatial'], rtol=RTOL, atol=ATOL_SP)
+    np.testing.assert_allclose(out[:4, ::8], a['logspec_stride8'], rtol=RTOL, atol=ATOL_DB)
+
+
+@pytest.mark.parametrize('ftype', ['salsa_lite', 'salsa_ipd'])
+def test_salsa_lite_matches_reference_golden(dev, ftype):
+    meta, a = load_golden('g4_%s' % ftype)
+    k = np.arange(1, 192, dtype=np.float64)
+    period = 2.0 * np.ones(191) if ftype == 'salsa_ipd' else 2 * np.pi / (2 * np.pi * 24000 / (512 * 343.0) * k)
+    for key, y, ref in _golden_items(meta, a):
+        out = _gpu_features(y, dev, audio_format='mic', feature_type=ftype, fmax_doa=2000)
+        assert out.shape == ref.shape
+        np.testing.assert_allclose(out[:4], ref[:4], rtol=RTOL, atol=ATOL_DB)
+        np.testing.assert_allclose(out[4:, 1:], ref[4:, 1:], rtol=RTOL, atol=ATOL_SP)
+        d0 = out[4:, 0].astype(np.float64) - ref[4:, 0]          # frame 0: real spectrum, phase sign is round-off
+        d0 = d0 - period * np.round(d0 / period)
+        assert np.abs(d0).max() < 1e-5
+        assert not out[4:, :, 42:].any()
+
+
+# ----------------------------------------------------------------------------------------------- vs oracle, seeded
+@pytest.mark.parametrize('fmt,fmax,layout', [('foa', 9000, 'planar'), ('mic', 4000, 'interleaved')])
+def test_batched_clips_against_oracle(dev, oracle, fmt, fmax, layout):
+    n = 10 * 24000
+    ys = np.stack([synth_clip(500 + i, n) for i in range(3)])
+    ex = _extractor(audio_format=fmt, fmax_doa=fmax, audio_layout=layout)
+    a = torch.from_numpy(ys).to(dev)
+    if layout == 'interleaved':
+        a = a.permute(0, 2, 1).contiguous()
+    out = ex.extract(a).cpu().numpy()
+    assert out.shape == (3, 7, 801, 200)
+    for i in range(3):
+        ref, aux = oracle.extract_salsa(ys[i], fmax_doa=fmax, audio_format=fmt, return_aux=True)
+        _check(out[i], ref, aux['margin'])
+    # batch invariance: a clip's features do not depend on its batch neighbours (bit-identical)
+    solo = ex.extract(a[1:2].contiguous()).cpu().numpy()
+    assert np.array_equal(solo[0], out[1])
+
+
+def test_ragged_and_tiny_clips_against_oracle(dev, oracle):
+    for n in (300, 511, 512, 813, 2999, 3000, 3001):       # around hop / n_fft boundaries; heavy reflect padding
+        y = synth_clip(900 + n, n)
+        ref, aux = oracle.extract_salsa(y, return_aux=True)
+        _check(_gpu_features(y, dev), ref, aux['margin'])
+        ref = oracle.extract_lite(y, fmax_doa=2000)
+        out = _gpu_features(y, dev, audio_format='mic', feature_type='salsa_lite', fmax_doa=2000)
+        np.testing.assert_allclose(out[:4], ref[:4], rtol=RTOL, atol=ATOL_DB)
+        np.testing.assert_allclose(out[4:, 1:], ref[4:, 1:], rtol=RTOL, atol=ATOL_SP)
+
+
+def test_silent_and_constant_clips(dev, oracle):
+    z = np.zeros((4, 6000), np.float32)
+    out = _gpu_features(z, dev)
+    assert np.all(out[:4] == -100.0) and not out[4:].any()             # 10*log10(1e-10), nothing passes the gates
+    c = np.ones((4, 6000), np.float32) * 0.25
+    ref, aux = oracle.extract_salsa(c, return_aux=True)
+    _check(_gpu_features(c, dev), ref, aux['margin'])
+
+
+def test_logspec_entry_point(dev, oracle):
+    y = synth_clip(77, 24000)
+    ex = _extractor()
+    out = ex.logspec(torch.from_numpy(y[None]).to(dev))[0].cpu().numpy()
+    np.testing.assert_allclose(out, oracle.logspec(y), rtol=RTOL, atol=ATOL_DB)
+    ex = _extractor(is_compress_high_freq=False)
+    out = ex.logspec(torch.from_numpy(y[None]).to(dev))[0].cpu().numpy()
+    np.testing.assert_allclose(out, oracle.logspec(y, compress=False), rtol=RTOL, atol=ATOL_DB)
+
+
+# ----------------------------------------------------------------------------------------------- full size
+def test_full_size_60s_batch_properties(dev, oracle):
+    """BASELINE config 2 shape (60-s clips), reduced batch: one clip checked against the oracle in full, the rest by
+    size-independent properties (determinism, batch invariance, zero band, finite, spatial unit norm)."""
+    B, n = 4, 60 * 24000
+    ys = np.stack([synth_clip(2021 + i, n) for i in range(B)])
+    ex = _extractor()
+    a = torch.from_numpy(ys).to(dev)
+    out1 = ex.extract(a)
+    out2 = ex.extract(a)
+    assert torch.equal(out1, out2)                                        # deterministic
+    o = out1.cpu().numpy()
+    assert o.shape == (B, 7, 4801, 200) and np.isfinite(o).all()
+    assert not o[:, 4:, :, 191:].any()                                    # zero above upper_bin (:373-374)
+    nrm = np.sqrt((o[:, 4:].astype(np.float64) ** 2).sum(axis=1))
+    emitted = nrm > 0
+    assert 0.02 < emitted[:, :, :191].mean() < 0.9
+    assert np.abs(nrm[emitted] - 1.0).max() < 1e-6                        # FOA eigenvector features are unit vectors
+    ref, aux = oracle.extract_salsa(ys[0], return_aux=True)
+    _check(o[0], ref, aux['margin'])
+    perm = torch.flip(a, dims=[0]).contiguous()
+    assert torch.equal(torch.flip(ex.extract(perm), dims=[0]), out1)      # batch-order invariance
+
+
+def test_errors_mirror_reference(dev):
+    with pytest.raises(AssertionError):
+        _extractor(n_fft=1024)
+    with pytest.raises(ValueError):
+        _extractor(audio_format='xyz')
+    with pytest.raises(AssertionError):
+        _extractor(feature_type='salsa_lite', audio_format='foa')          # lite :72
+    with pytest.raises(AssertionError):
+        _extractor(feature_type='salsa_lite', audio_format='mic', fmax_doa=9500)   # lite :59
