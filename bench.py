@@ -48,28 +48,11 @@ def algorithmic_bytes(batch, n_samples, T, F):
     }
 
 
-def cpu_baseline(feature, fmt, fmax, n_samples, budget_s=12.0, max_clips=16):
-    """The oracle (CPU restatement of the reference) timed on this host, all cores, on a bounded sample of the same
-    workload.  Clip synthesis is not billed."""
-    from oracle import oracle as orc
-    from salsa_amd.synth import synth_clip
-    orc.build()
-    cores = orc.max_threads()
-    orc.set_threads(cores)
-    clips, acc = 0, 0.0
-    while clips < max_clips and acc < budget_s:
-        y = synth_clip(2021 + clips, n_samples)
-        t1 = time.perf_counter()
-        if feature == 'salsa':
-            orc.extract_salsa(y, fmax_doa=fmax, audio_format=fmt)
-        else:
-            orc.extract_lite(y, fmax_doa=fmax, feature_type=feature)
-        acc += time.perf_counter() - t1
-        clips += 1
-    secs = n_samples / 24000.0
-    return {'value': round(clips * secs / acc, 2), 'unit': 'audio-seconds/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d x %.0f-s clips (seeds 2021..), oracle/salsa_oracle.c = float64 C restatement of the '
-                      'reference, OpenMP over bins/frames, %.1f s wall' % (clips, secs, acc)}
+def cpu_baseline(feature, fmt, fmax, n_samples):
+    """The oracle (CPU restatement of the reference) timed on this host's cores on a bounded sample of the same
+    workload (one 60-s clip per worker process, <= 32 workers).  Reported beside the GPU number, never the target."""
+    from oracle import cpu_bench
+    return cpu_bench.run(feature, fmt, fmax, n_samples)
 
 
 def main():

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 
 // ------------------------------------------------------------------------------------------------------------ K2
 // One lane per (clip, bin); sequential over time (the tracker state depends on every earlier frame).
+constexpr int TR_CHUNK = 32;
+
 __global__ __launch_bounds__(64) void tracker_kernel(const KParams kp, const float2 *__restrict__ Xs,
                                                      unsigned char *__restrict__ valid)
 {
@@ -246,15 +248,32 @@ __global__ __launch_bounds__(64) void tracker_kernel(const KParams kp, const flo
     salsa::tracker_state st = {0.5 * (acc / (double)n0), 3};
     double p1 = P(-1), p2 = P(-2);
     unsigned char *vout = valid + (long)b * Tn * kp.nd + bin;
-#pragma unroll 4
-    for (long t = 0; t < Tn; t++) {
-        const float2 x = x0[t * stride];
-        const double re = x.x, im = x.y;
-        const double p0 = re * re + im * im;
-        const double mag = sqrt((((0.0 + p0) + p1) + p2) / 3);
-        vout[t * kp.nd] = salsa::tracker_step(st, mag) ? 1 : 0;
-        p2 = p1;
-        p1 = p0;
+    // The recurrence is sequential but its inputs are not: keep TR_CHUNK frames of channel 0 in registers and fetch
+    // the next chunk while stepping through the current one, so the ~2 us strided-load latency is paid once per
+    // chunk instead of once per frame.
+    float2 cur[TR_CHUNK], nxt[TR_CHUNK];
+#pragma unroll
+    for (int i = 0; i < TR_CHUNK; i++) cur[i] = x0[(i < Tn ? i : Tn - 1) * stride];
+    for (long c0 = 0; c0 < Tn; c0 += TR_CHUNK) {
+#pragma unroll
+        for (int i = 0; i < TR_CHUNK; i++) {
+            const long tn = c0 + TR_CHUNK + i;
+            nxt[i] = x0[(tn < Tn ? tn : Tn - 1) * stride];
+        }
+#pragma unroll
+        for (int i = 0; i < TR_CHUNK; i++) {
+            const long t = c0 + i;
+            if (t < Tn) {
+                const double re = cur[i].x, im = cur[i].y;
+                const double p0 = re * re + im * im;
+                const double mag = sqrt((((0.0 + p0) + p1) + p2) / 3);
+                vout[t * kp.nd] = salsa::tracker_step(st, mag) ? 1 : 0;
+                p2 = p1;
+                p1 = p0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TR_CHUNK; i++) cur[i] = nxt[i];
     }
 }
 
