@@ -5,7 +5,7 @@
 //   K1 stft_kernel      one wave per packed 512-point complex FFT (two real channels), Stockham radix-8 through LDS;
 //                       unpacks to the 4 channel spectra, writes the log-spectrogram channels 0-3 straight to the
 //                       output and spills the DOA band of the spectra (float32-rounded, like the reference's
-//                       complex64 STFT) to the workspace as Xs[b][t][c][bin].
+//                       complex64 STFT) to the workspace as Xs[b][t][channel pair][bin] (float4).
 //   K2 tracker_kernel   one lane per (clip, bin): 3-frame RMS of channel 0 and the sequential noise-floor tracker
 //                       in float64 -> valid[b][t][bin].
 //   K3 cov_eig_kernel   one lane per TF bin (64 consecutive bins of one frame per wave, coalesced): 7-frame Hermitian
@@ -66,283 +66,422 @@ struct KParams {
 constexpr int FEATURE_LOGSPEC_ONLY = 3;
 
 // ------------------------------------------------------------------------------------------------------------ K1
+// STFT + log-spectrogram (+ spill of the DOA band, or the SALSA-Lite phase features).
+//
+// Work item of ONE WAVE = one packed N-point complex FFT z = w*(y_c0 + i*y_c1) of a channel pair of one frame:
+// 64 lanes x R points, Stockham radix-R passes exchanged through a wave-private LDS buffer (no workgroup barrier:
+// the LDS serves a wave's DS instructions in order, so a wave-level scheduling fence is all the passes need), then
+// the unpack of the pair's two spectra X_c0, X_c1 (they depend on this transform only), rounded to float32 like the
+// reference's complex64 STFT, and straight from registers: 10*log10 of the power into output channels c0, c1 and
+// the DOA band of both channels as ONE float4 per bin into the spill.  A wave walks K1_NF consecutive frames x 2
+// pairs and prefetches the next item's samples while the current transform runs.  Twiddles and the window live in
+// registers for the whole walk.
 template <int N> struct fft_cfg {
-    static constexpr int R = (N == 512) ? 8 : 4; // points per lane; 64 lanes per transform either way
-    static constexpr int PADN = N + N / 8;       // one pad element every 8: stride-R scatter of 16-B elements is conflict-free
+    static constexpr int R = (N == 512) ? 8 : 4;                 // points per lane; 64 lanes per transform either way
+    static constexpr int PADN = N + N / 8;                       // one pad slot every 8: the stride-R scatter of 16-B elements is conflict-free
+    static constexpr int NP = (N == 512) ? 2 : 3;                // twiddled passes (p = R, R^2, ...)
 };
 
 __device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
 
-constexpr int K1_FRAMES_PER_ITER = 2;
-constexpr int K1_ITERS = 4;
-constexpr int K1_FRAMES_PER_BLOCK = K1_FRAMES_PER_ITER * K1_ITERS;
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
+
+constexpr int K1_NF = 8;                                          // frames per wave
+constexpr int K1_FRAMES_PER_BLOCK = 4 * K1_NF;
 
 template <int N, typename T>
 __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
-                                                   float2 *__restrict__ Xs)
+                                                   float4 *__restrict__ Xs)
 {
     constexpr int R = fft_cfg<N>::R;
     constexpr int PADN = fft_cfg<N>::PADN;
+    constexpr int NP = fft_cfg<N>::NP;
     constexpr int NB = N / 2 + 1;
     __shared__ cplx<T> buf[4][PADN];
-    __shared__ float pw[K1_FRAMES_PER_ITER][4][NB];
+    __shared__ float pw[4][2][64];     // powers of the compressed band (<= 63 bins) of the wave's two channels
+    __shared__ float2 x0s[4][NB];      // SALSA-Lite: channel-0 spectrum of the frame, kept for pair 1
 
-    const int tid = threadIdx.x;
-    const int w = tid >> 6, lane = tid & 63;
-    const int fr = w >> 1, pair = w & 1;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
-    const long t0 = (long)blockIdx.x * K1_FRAMES_PER_BLOCK;
     const long Ns = kp.N, Tn = kp.T;
-    cplx<T> *mybuf = buf[w];
+    const long t_begin = ((long)blockIdx.x * 4 + w) * K1_NF;
+    if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
+    cplx<T> *z = buf[w];
+    const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
 
-    // window and twiddles of this lane's elements (same for every frame)
     T win[R];
+    cplx<T> twr[NP][R - 1];
 #pragma unroll
-    for (int r = 0; r < R; r++) win[r] = (T)window[salsa::stockham_in(lane, r, N, R)];
-
-    for (int it = 0; it < K1_ITERS; it++) {
-        const long t = t0 + it * K1_FRAMES_PER_ITER + fr;
-        const bool live = t < Tn;
-        cplx<T> v[R];
-        // ---- load + window: z[n] = w[n] * (y_c0[n] + i y_c1[n]) for this wave's channel pair
-        {
-            const long base = t * kp.hop - N / 2;
-            const bool interior = live && base >= 0 && base + N <= Ns;
-            const int c0 = 2 * pair;
+    for (int r = 0; r < R; r++) win[r] = (T)(0.5 * window[salsa::stockham_in(lane, r, N, R)]); // 0.5: the unpack's /2, exact
+    {
+        int p = R;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int n = salsa::stockham_in(lane, r, N, R);
-                float y0 = 0.f, y1 = 0.f;
-                if (live) {
-                    const long s = interior ? base + n : salsa::reflect_index(base + n, Ns);
-                    if (kp.layout == SALSA_LAYOUT_PLANAR) {
-                        y0 = audio[((long)b * 4 + c0) * Ns + s];
-                        y1 = audio[((long)b * 4 + c0 + 1) * Ns + s];
-                    } else {
-                        const float2 yy = *reinterpret_cast<const float2 *>(audio + ((long)b * Ns + s) * 4 + c0);
-                        y0 = yy.x;
-                        y1 = yy.y;
-                    }
-                }
-                v[r] = {win[r] * (T)y0, win[r] * (T)y1};
-            }
-        }
-        // ---- Stockham passes, in place in this wave's LDS buffer
-        salsa::dftR<R>(v); // pass p = 1 (no twiddles)
-#pragma unroll
-        for (int r = 0; r < R; r++) mybuf[padi(salsa::stockham_out(lane, r, 1, R))] = v[r];
-#pragma unroll
-        for (int p = R; p < N; p *= R) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; r++) v[r] = mybuf[padi(salsa::stockham_in(lane, r, N, R))];
-            __syncthreads();
+        for (int q = 0; q < NP; q++, p *= R)
 #pragma unroll
             for (int r = 1; r < R; r++) {
                 const cplx<double> wd = tw[salsa::stockham_tw(lane, r, p, N, R)];
-                v[r] = salsa::cmul(v[r], cplx<T>{(T)wd.re, (T)wd.im});
+                twr[q][r - 1] = {(T)wd.re, (T)wd.im};
             }
-            salsa::dftR<R>(v);
-#pragma unroll
-            for (int r = 0; r < R; r++) mybuf[padi(salsa::stockham_out(lane, r, p, R))] = v[r];
-        }
-        __syncthreads();
+    }
 
-        // ---- unpack the two packed transforms of this frame into 4 channel spectra; 128 lanes per frame
-        const cplx<T> *za = buf[fr * 2 + 0], *zb = buf[fr * 2 + 1];
-        const int j = pair * 64 + lane;
-        float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip
-        for (int k = j; k <= N / 2; k += 128) {
-            const int km = (N - k) & (N - 1);
-            cplx<T> X[4];
-            salsa::unpack_pair(za[padi(k)], za[padi(km)], X[0], X[1]);
-            salsa::unpack_pair(zb[padi(k)], zb[padi(km)], X[2], X[3]);
-            float2 xf[4];
-            float pc[4];
+    auto load_item = [&](int item, float *y0, float *y1) {
+        const long t = t_begin + (item >> 1);
+        const int c0 = 2 * (item & 1);
+        const long base = t * kp.hop - N / 2;
+        const bool interior = base >= 0 && base + N <= Ns;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                xf[c] = make_float2((float)X[c].re, (float)X[c].im); // the reference stores its STFT as complex64
-                pc[c] = xf[c].x * xf[c].x + xf[c].y * xf[c].y;
+        for (int r = 0; r < R; r++) {
+            const int n = salsa::stockham_in(lane, r, N, R);
+            const long s = interior ? base + n : salsa::reflect_index(base + n, Ns);
+            if (kp.layout == SALSA_LAYOUT_PLANAR) {
+                y0[r] = audio[((long)b * 4 + c0) * Ns + s];
+                y1[r] = audio[((long)b * 4 + c0 + 1) * Ns + s];
+            } else {
+                const float2 yy = *reinterpret_cast<const float2 *>(audio + ((long)b * Ns + s) * 4 + c0);
+                y0[r] = yy.x;
+                y1[r] = yy.y;
             }
-            if (!live) continue;
-            if (kp.feature == SALSA_FEATURE_SALSA || kp.feature == FEATURE_LOGSPEC_ONLY) {
-                if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper) {
+        }
+    };
+
+    const long nfr = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
+    const int nitems = (int)nfr * 2;
+    float y0[R], y1[R];
+    load_item(0, y0, y1);
+    float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip
+
+    for (int item = 0; item < nitems; item++) {
+        const long t = t_begin + (item >> 1);
+        const int pr = item & 1;
+        cplx<T> v[R];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) Xs[(((long)b * Tn + t) * 4 + c) * kp.nd + (k - kp.lower)] = xf[c];
-                }
+        for (int r = 0; r < R; r++) v[r] = {win[r] * (T)y0[r], win[r] * (T)y1[r]};
+        if (item + 1 < nitems) load_item(item + 1, y0, y1); // prefetch: in flight during the passes below
+        // ---- Stockham passes, in place in the wave-private buffer
+        salsa::dftR<R>(v); // pass p = 1 (no twiddles)
+        wave_lds_fence();  // previous item's unpack reads are done before we overwrite z
+#pragma unroll
+        for (int r = 0; r < R; r++) z[padi(salsa::stockham_out(lane, r, 1, R))] = v[r];
+        {
+            int p = R;
+#pragma unroll
+            for (int q = 0; q < NP; q++, p *= R) {
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < R; r++) v[r] = z[padi(salsa::stockham_in(lane, r, N, R))];
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 1; r < R; r++) v[r] = salsa::cmul(v[r], twr[q][r - 1]);
+                salsa::dftR<R>(v);
+#pragma unroll
+                for (int r = 0; r < R; r++) z[padi(salsa::stockham_out(lane, r, p, R))] = v[r];
+            }
+        }
+        wave_lds_fence();
+
+        // ---- unpack this pair's two spectra; lane handles bins k = lane + 64 m (and lane 0 the Nyquist bin)
+        const int c0 = 2 * pr;
+        auto unpack_bin = [&](const int k) {
+            const int km = (N - k) & (N - 1);
+            cplx<T> Xa, Xb;
+            salsa::unpack_pair_prescaled(z[padi(k)], z[padi(km)], Xa, Xb);
+            const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
+            const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
+            const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+            if (!lite) {
+                if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
+                    Xs[(((long)b * Tn + t) * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
                 if (k >= 1 && k <= kp.ident) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        o[((long)c * Tn + t) * kp.F + (k - 1)] = 10.0f * log10f(fmaxf(1e-10f, pc[c]));
-                } else if (k > kp.ident) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pw[fr][c][k] = pc[c];
+                    o[((long)c0 * Tn + t) * kp.F + (k - 1)] = db10(pa);
+                    o[((long)(c0 + 1) * Tn + t) * kp.F + (k - 1)] = db10(pb);
+                } else if (k > kp.ident && k < N / 2) {
+                    pw[w][0][k - kp.ident - 1] = pa;
+                    pw[w][1][k - kp.ident - 1] = pb;
                 }
             } else { // SALSA-Lite / SALSA-IPD (salsa_lite_feature_extraction.py:103-120)
+                if (pr == 0) x0s[w][k] = xa;
                 if (k >= kp.lower && k < kp.cutoff) {
                     const int f = k - kp.lower;
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        o[((long)c * Tn + t) * kp.F + f] = 10.0f * log10f(fmaxf(1e-10f, pc[c]));
-                    const double x0r = xf[0].x, x0i = xf[0].y;
+                    o[((long)c0 * Tn + t) * kp.F + f] = db10(pa);
+                    o[((long)(c0 + 1) * Tn + t) * kp.F + f] = db10(pb);
+                    const float2 x0 = pr == 0 ? xa : x0s[w][k];
                     const double scale = kp.feature == SALSA_FEATURE_IPD ? 3.14159265358979323846
                                                                          : kp.delta * (double)(k == 0 ? 1 : k);
+                    // pair 0 contributes channel 1 (phase vs channel 0); pair 1 contributes channels 2 and 3
 #pragma unroll
-                    for (int c = 1; c < 4; c++) {
+                    for (int h = (pr == 0 ? 1 : 0); h < 2; h++) {
+                        const float2 xc = h == 0 ? xa : xb;
                         float ph = 0.f;
                         if (f < kp.upper) { // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
-                            double wr = (double)xf[c].x * x0r + (double)xf[c].y * x0i;
-                            double wi = (double)xf[c].y * x0r - (double)xf[c].x * x0i;
+                            double wr = (double)xc.x * x0.x + (double)xc.y * x0.y;
+                            double wi = (double)xc.y * x0.x - (double)xc.x * x0.y;
                             const double m = fmax(fabs(wr), fabs(wi));
                             if (m < 1e-30 && m > 0.0) { wr *= 0x1p200; wi *= 0x1p200; } // keep the float cast normal
                             ph = (float)((double)atan2f((float)wi, (float)wr) / scale);
                         }
-                        o[((long)(3 + c) * Tn + t) * kp.F + f] = ph;
+                        o[((long)(3 + c0 + h) * Tn + t) * kp.F + f] = ph;
                     }
                 }
             }
-        }
-        __syncthreads();
-        // ---- compressed high-frequency rows of W: mean-like sum of 8 (last row 7) bins times 1/8
-        if (kp.feature != SALSA_FEATURE_LITE && kp.feature != SALSA_FEATURE_IPD && kp.compress && live) {
-            const int c = j & 3, gi = j >> 2;
+        };
+#pragma unroll
+        for (int mi = 0; mi < N / 128; mi++) unpack_bin(lane + 64 * mi);
+        if (lane == 0) unpack_bin(N / 2);
+        // ---- compressed high-frequency rows of W: sum of 8 (last row 7) bins times 1/8
+        if (!lite && kp.compress) {
+            wave_lds_fence();
             const int ng = kp.F - kp.ident;
+            const int h = lane & 1, gi = lane >> 1;
             if (gi < ng) {
-                const int start = kp.ident + 1 + 8 * gi;
                 const int cnt = gi < ng - 1 ? 8 : 7;
                 float acc = 0.f;
-                for (int q = 0; q < cnt; q++) acc += 0.125f * pw[fr][c][start + q];
-                o[((long)c * Tn + t) * kp.F + kp.ident + gi] = 10.0f * log10f(fmaxf(1e-10f, acc));
+                for (int q = 0; q < cnt; q++) acc += 0.125f * pw[w][h][8 * gi + q];
+                o[((long)(c0 + h) * Tn + t) * kp.F + kp.ident + gi] = db10(acc);
             }
         }
-        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------ K2
-// One lane per (clip, bin); sequential over time (the tracker state depends on every earlier frame).
-constexpr int TR_CHUNK = 32;
+// Noise-floor tracker.  The recurrence over time is strictly sequential per (clip, bin), but everything that feeds it
+// (|X0|^2, the 3-frame mean, the float64 divide and square root) is not.  One 512-lane workgroup serves 64 adjacent
+// bins of one clip: wave 0 runs the recurrence (a ~5-instruction dependent chain per frame) at raised priority, waves
+// 1-7 stay one chunk of TR_CH frames ahead computing mag[t][bin] into an LDS ring, with the loads of the chunk after
+// that already in flight.  Spill layout: Xs[b][t][pair][bin] as float4 (c0.re, c0.im, c1.re, c1.im); channel 0 is the
+// .xy of pair 0.  Output: one 64-bit mask per (clip, chunk, bin), bit i = indicator_sig of frame 64*chunk + i.
+constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
+constexpr int TR_WAVES = 8;     // 1 consumer + 7 producers
 
-__global__ __launch_bounds__(64) void tracker_kernel(const KParams kp, const float2 *__restrict__ Xs,
-                                                     unsigned char *__restrict__ valid)
+template <int COUNT>
+__device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, long stride, long c0,
+                                             int first, bool active, float2 *x)
 {
-    const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-    if (idx >= (long)kp.B * kp.nd) return;
-    const int b = (int)(idx / kp.nd), bin = (int)(idx % kp.nd);
+    // |X0| samples of frames c0+first-2 .. c0+first+COUNT-1 (wrap on the time axis; beyond the clip: unused)
     const long Tn = kp.T;
-    const float2 *x0 = Xs + ((long)b * Tn * 4) * kp.nd + bin; // channel 0 of frame t at x0[t*4*nd]
-    const long stride = 4L * kp.nd;
-    auto P = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < COUNT + 2; i++) {
+        long t = c0 + first + i - 2;
+        if (t >= Tn) t = Tn - 1;
         t %= Tn;
         if (t < 0) t += Tn;
-        const float2 x = x0[t * stride];
-        const double re = x.x, im = x.y;
-        return re * re + im * im;
-    };
-    // noise_floor = 0.5 * mean(mag[0:5])  (:58)
-    const long n0 = Tn < 5 ? Tn : 5;
-    double acc = 0.0;
-    for (long t = 0; t < n0; t++) acc += sqrt((((0.0 + P(t)) + P(t - 1)) + P(t - 2)) / 3);
-    salsa::tracker_state st = {0.5 * (acc / (double)n0), 3};
-    double p1 = P(-1), p2 = P(-2);
-    unsigned char *vout = valid + (long)b * Tn * kp.nd + bin;
-    // The recurrence is sequential but its inputs are not: keep TR_CHUNK frames of channel 0 in registers and fetch
-    // the next chunk while stepping through the current one, so the ~2 us strided-load latency is paid once per
-    // chunk instead of once per frame.
-    float2 cur[TR_CHUNK], nxt[TR_CHUNK];
+        const float4 v = active ? x0[t * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[i] = make_float2(v.x, v.y);
+    }
+}
+
+template <int COUNT>
+__device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][64]*/, int lane)
+{
+    double p[COUNT + 2];
 #pragma unroll
-    for (int i = 0; i < TR_CHUNK; i++) cur[i] = x0[(i < Tn ? i : Tn - 1) * stride];
-    for (long c0 = 0; c0 < Tn; c0 += TR_CHUNK) {
+    for (int i = 0; i < COUNT + 2; i++) {
+        const double re = x[i].x, im = x[i].y;
+        p[i] = re * re + im * im;
+    }
 #pragma unroll
-        for (int i = 0; i < TR_CHUNK; i++) {
-            const long tn = c0 + TR_CHUNK + i;
-            nxt[i] = x0[(tn < Tn ? tn : Tn - 1) * stride];
-        }
-#pragma unroll
-        for (int i = 0; i < TR_CHUNK; i++) {
-            const long t = c0 + i;
-            if (t < Tn) {
-                const double re = cur[i].x, im = cur[i].y;
-                const double p0 = re * re + im * im;
-                const double mag = sqrt((((0.0 + p0) + p1) + p2) / 3);
-                vout[t * kp.nd] = salsa::tracker_step(st, mag) ? 1 : 0;
-                p2 = p1;
-                p1 = p0;
+    for (int i = 0; i < COUNT; i++) {
+        if (first + i < TR_CH)
+            dst[(first + i) * 64 + lane] = sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3); // :53-55, reference's order
+    }
+}
+
+__global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
+                                                                unsigned long long *__restrict__ valid)
+{
+    __shared__ double ring[2][TR_CH * 64];
+    const int ngroups = (kp.nd + 63) / 64;
+    const int b = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bin = g * 64 + lane;
+    const bool active = bin < kp.nd;
+    const long Tn = kp.T;
+    const long stride = 2L * kp.nd; // float4 elements per frame
+    const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
+    const long nchunks = (Tn + TR_CH - 1) / TR_CH;
+    constexpr int PER_ALL = TR_CH / TR_WAVES;               // prologue: all 8 waves produce chunk 0
+    constexpr int PER_PROD = (TR_CH + TR_WAVES - 2) / (TR_WAVES - 1);
+    {
+        float2 x[PER_ALL + 2];
+        tracker_load<PER_ALL>(kp, x0, stride, 0, w * PER_ALL, active, x);
+        tracker_mag<PER_ALL>(x, w * PER_ALL, ring[0], lane);
+    }
+    float2 xr[PER_PROD + 2];
+    const int pfirst = (w - 1) * PER_PROD;
+    if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xr);
+    __syncthreads();
+    salsa::tracker_state st = {0.0, 3};
+    unsigned long long *vout = valid + (long)b * nchunks * kp.nd + (active ? bin : 0);
+    if (w == 0) __builtin_amdgcn_s_setprio(3);
+    for (long c = 0; c < nchunks; c++) {
+        const double *cur = ring[c & 1];
+        if (w == 0) {
+            if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
+                const long n0 = Tn < 5 ? Tn : 5;
+                double acc = 0.0;
+                for (long t = 0; t < n0; t++) acc += cur[t * 64 + lane];
+                st.floor = 0.5 * (acc / (double)n0);
             }
-        }
+            unsigned long long m = 0;
+            const int nfr = (int)(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH);
+            if (nfr == TR_CH) {
+#pragma unroll 16
+                for (int i = 0; i < TR_CH; i++) m |= (unsigned long long)salsa::tracker_step(st, cur[i * 64 + lane]) << i;
+            } else {
+                for (int i = 0; i < nfr; i++) m |= (unsigned long long)salsa::tracker_step(st, cur[i * 64 + lane]) << i;
+            }
+            if (active) vout[c * kp.nd] = m;
+        } else if (c + 1 < nchunks) {
+            float2 xn[PER_PROD + 2];
+            if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, xn);
+            tracker_mag<PER_PROD>(xr, pfirst, ring[(c + 1) & 1], lane);
 #pragma unroll
-        for (int i = 0; i < TR_CHUNK; i++) cur[i] = nxt[i];
+            for (int i = 0; i < PER_PROD + 2; i++) xr[i] = xn[i];
+        }
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------ K3
-// One block per (clip, frame); lane = bin.  FEAT: write float32 channels 4-6 of the feature array (zeros above the
-// DOA band up to F); otherwise write the float64 (3, n_bins, n_frames) array of extract_normalized_eigenvector.
-template <bool FEAT>
-__global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float2 *__restrict__ Xs,
-                                                      const unsigned char *__restrict__ valid,
+// Covariance + eigen-gate + eigenvector.  Only TF bins that pass the noise gate need the (float64, ~700 instruction)
+// solve, and they are scattered: a wave that owns 64 fixed bins runs the solve if ANY lane is valid.  So each workgroup
+// takes a tile of K3_FT frames x (<=256) bins of one clip, compacts the valid (frame, bin) pairs into an LDS work list
+// (lane order preserved, so neighbouring lanes still read neighbouring bins), writes zeros for the rest, and then the
+// 256 lanes walk the dense list.  FEAT: write float32 channels 4-6 of the feature array (zeros above the DOA band up
+// to F); otherwise write the float64 (3, n_bins, n_frames) array of extract_normalized_eigenvector (+ gate codes).
+constexpr int K3_FT = 16; // frames per tile; divides TR_CH so a tile's gate bits sit in one mask word per bin
+
+template <bool FEAT, int NHOP>
+__global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+                                                      const unsigned long long *__restrict__ valid,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
 {
-    const long bt = blockIdx.x;
-    const int bin = blockIdx.y * 256 + threadIdx.x;
+    __shared__ unsigned short list[K3_FT * 256];
+    __shared__ int count;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
     const long Tn = kp.T;
-    const int b = (int)(bt / Tn);
-    const long t = bt % Tn;
-    const int limit = FEAT ? kp.F : kp.nd;
-    if (bin >= limit) return;
-    double e[3] = {0.0, 0.0, 0.0};
-    unsigned char g = 0;
-    if (bin < kp.nd) {
-        const bool sig = kp.tracking ? (valid[bt * kp.nd + bin] != 0) : true;
-        if (sig) {
-            salsa::herm4<double> R = {};
-            for (int k = -kp.n_hop; k <= kp.n_hop; k++) {
-                long tt = (t + k) % Tn; // np.pad(..., 'wrap') on the time axis (:43)
-                if (tt < 0) tt += Tn;
-                const float2 *xp = Xs + (((long)b * Tn + tt) * 4) * kp.nd + bin;
-                cplx<double> x[4];
+    const long t0 = (long)blockIdx.x * K3_FT;
+    const int nft = (int)(Tn - t0 < K3_FT ? Tn - t0 : K3_FT);
+    const int bin0 = blockIdx.z * 256;
+    const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
+    if (tid == 0) count = 0;
+    __syncthreads();
+    auto emit = [&](long t, int bin, const double *e, unsigned char g) {
+        if (FEAT) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float2 xv = xp[(long)c * kp.nd];
-                    x[c] = {(double)xv.x, (double)xv.y};
-                }
-                salsa::herm4_rank1_add(R, x);
-            }
-            const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, !kp.tracking);
-            g = er.rank1 ? 2 : 1;
-            if (er.rank1 || !kp.tracking) { // :111-112 the coherence test only gates when tracking
-                if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e);
-                else salsa::normalise_mic(er.u, kp.delta * (double)(bin + kp.lower), e);
-                if (!kp.tracking) g = 2;
+            for (int i = 0; i < 3; i++) out_feat[(((long)b * kp.OC + 4 + i) * Tn + t) * kp.F + bin] = (float)e[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) out_eig[(((long)b * 3 + i) * kp.nd + bin) * Tn + t] = e[i];
+            if (gate) gate[((long)b * kp.nd + bin) * Tn + t] = g;
+        }
+    };
+    const double zero3[3] = {0.0, 0.0, 0.0};
+    {
+        // lane = bin (consecutive lanes, consecutive bins); frames outer, so the list is frame-major / bin-minor
+        const int bl = tid;
+        const bool in = bl < nbc;
+        unsigned long long word = ~0ull;
+        if (in && kp.tracking) {
+            const long nchunks = (Tn + TR_CH - 1) / TR_CH;
+            word = valid[((long)b * nchunks + t0 / TR_CH) * kp.nd + bin0 + bl] >> (t0 % TR_CH);
+        }
+        for (int ft = 0; ft < nft; ft++) {
+            if (in) {
+                if ((word >> ft) & 1) list[atomicAdd(&count, 1)] = (unsigned short)(ft * 256 + bl); // wave-aggregated: lane order survives
+                else emit(t0 + ft, bin0 + bl, zero3, 0);
             }
         }
     }
-    if (FEAT) {
+    if (FEAT && blockIdx.z == gridDim.z - 1) { // zero the feature bins above the DOA band (:373-374)
+        const int tail = kp.F - kp.nd;
+        for (int i = tid; i < nft * tail; i += 256) {
+            const int ft = i / tail, f = kp.nd + (i - ft * tail);
 #pragma unroll
-        for (int i = 0; i < 3; i++) out_feat[(((long)b * kp.OC + 4 + i) * Tn + t) * kp.F + bin] = (float)e[i];
-    } else {
+            for (int c = 0; c < 3; c++) out_feat[(((long)b * kp.OC + 4 + c) * Tn + t0 + ft) * kp.F + f] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int n = count;
+    const long stride = 2L * kp.nd;
+    const int nhop = NHOP >= 0 ? NHOP : kp.n_hop;
+    for (int s = tid; s < n; s += 256) {
+        const int i = list[s];
+        const long t = t0 + (i >> 8);
+        const int bin = bin0 + (i & 255);
+        salsa::herm4<double> R = {};
+        const float4 *xb = Xs + (long)b * Tn * stride + bin;
+        if (NHOP >= 0) {
+            constexpr int NW = NHOP >= 0 ? 2 * NHOP + 1 : 1;
+            float4 xa[NW], xc[NW];
 #pragma unroll
-        for (int i = 0; i < 3; i++) out_eig[(((long)b * 3 + i) * kp.nd + bin) * Tn + t] = e[i];
-        if (gate) gate[((long)b * kp.nd + bin) * Tn + t] = g;
+            for (int k = 0; k <= 2 * NHOP; k++) {
+                long tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
+                if (tt < 0) tt = (tt % Tn + Tn) % Tn;
+                else if (tt >= Tn) tt %= Tn;
+                xa[k] = xb[tt * stride];
+                xc[k] = xb[tt * stride + kp.nd];
+            }
+#pragma unroll
+            for (int k = 0; k <= 2 * NHOP; k++) {
+                const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
+                                           {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
+                salsa::herm4_rank1_add(R, x);
+            }
+        } else {
+            for (int k = -nhop; k <= nhop; k++) {
+                long tt = ((t + k) % Tn + Tn) % Tn;
+                const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
+                const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
+                                           {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
+                salsa::herm4_rank1_add(R, x);
+            }
+        }
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, !kp.tracking);
+        double e[3] = {0.0, 0.0, 0.0};
+        unsigned char g = er.rank1 ? 2 : 1;
+        if (er.rank1 || !kp.tracking) { // :111-112 the coherence test only gates when tracking
+            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e);
+            else salsa::normalise_mic(er.u, kp.delta * (double)(bin + kp.lower), e);
+            g = 2;
+        }
+        emit(t, bin, e, g);
     }
 }
 
-// reference layout (n_bins, n_frames, 4) complex64 -> internal Xs[b][t][c][bin]
-__global__ void relayout_kernel(const float2 *__restrict__ X, float2 *__restrict__ Xs, int B, int nb, long Tn)
+template <bool FEAT>
+static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned long long *valid,
+                           float *out_feat, double *out_eig, unsigned char *gate)
+{
+    if (kp.n_hop == 3)
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+    else
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+}
+
+// reference layout (n_bins, n_frames, 4) complex64 -> internal Xs[b][t][pair][bin] float4
+__global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xs, int B, int nb, long Tn)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)B * nb * Tn * 4;
+    const long total = (long)B * nb * Tn * 2;
     if (idx >= total) return;
     const int bin = (int)(idx % nb);
     long r = idx / nb;
-    const int c = (int)(r % 4);
-    r /= 4;
+    const int pr = (int)(r % 2);
+    r /= 2;
     const long t = r % Tn;
     const int b = (int)(r / Tn);
-    Xs[idx] = X[(((long)b * nb + bin) * Tn + t) * 4 + c];
+    Xs[idx] = X[(((long)b * nb + bin) * Tn + t) * 2 + pr];
 }
 
 } // namespace
@@ -500,13 +639,13 @@ size_t salsa_workspace_bytes(const salsa_plan *pl, int batch, int64_t n_samples)
 {
     if (!pl || batch <= 0 || n_samples <= 0 || pl->p.feature_type != SALSA_FEATURE_SALSA) return 0;
     const size_t T = 1 + n_samples / pl->p.hop_len;
-    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + align256((size_t)batch * T * pl->nd) + 256;
+    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + align256((size_t)batch * ((T + 63) / 64) * pl->nd * 8) + 256;
 }
 
 size_t salsa_eigvec_workspace_bytes(const salsa_plan *pl, int batch, int n_bins, int64_t n_frames)
 {
     if (!pl || batch <= 0 || n_bins <= 0 || n_frames <= 0) return 0;
-    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + align256((size_t)batch * n_frames * n_bins) + 256;
+    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + align256((size_t)batch * ((n_frames + 63) / 64) * n_bins * 8) + 256;
 }
 
 static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
@@ -547,7 +686,7 @@ static void mark(salsa_plan *pl, hipStream_t s, const char *name)
     else pl->n_kernels = 0;
 }
 
-static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float2 *Xs, hipStream_t s)
+static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
     dim3 grid((unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK), (unsigned)kp.B);
     if (pl->p.n_fft == 512)
@@ -568,13 +707,13 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
     hipStream_t s = (hipStream_t)hip_stream;
     KParams kp = make_kparams(pl, batch, n_samples);
     const bool full = pl->p.feature_type == SALSA_FEATURE_SALSA;
-    float2 *Xs = nullptr;
-    unsigned char *valid = nullptr;
+    float4 *Xs = nullptr;
+    unsigned long long *valid = nullptr;
     if (full) {
         const size_t need = salsa_workspace_bytes(pl, batch, n_samples);
         if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
-        Xs = (float2 *)d_workspace;
-        valid = (unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2));
+        Xs = (float4 *)d_workspace;
+        valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
     }
     mark(pl, s, nullptr);
     int rc = launch_stft(pl, kp, d_audio, d_out, Xs, s);
@@ -582,15 +721,13 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
     mark(pl, s, "stft_logspec");
     if (!full) return SALSA_OK;
     if (kp.nd > 0 && kp.tracking) {
-        const long n = (long)kp.B * kp.nd;
-        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, kp, Xs, valid);
+        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
         HIP_TRY(hipGetLastError());
     }
     mark(pl, s, "noise_floor_tracker");
     {
-        dim3 grid((unsigned)((long)kp.B * kp.T), (unsigned)((kp.F + 255) / 256));
-        hipLaunchKernelGGL((cov_eig_kernel<true>), grid, dim3(256), 0, s, kp, Xs, valid, d_out, (double *)nullptr,
-                           (unsigned char *)nullptr);
+        dim3 grid((unsigned)((kp.T + K3_FT - 1) / K3_FT), (unsigned)kp.B, (unsigned)((kp.nd + 255) / 256));
+        launch_cov_eig<true>(kp, grid, s, Xs, valid, d_out, (double *)nullptr, (unsigned char *)nullptr);
         HIP_TRY(hipGetLastError());
     }
     mark(pl, s, "cov_eig");
@@ -628,18 +765,17 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     kp.upper = lower_bin + n_bins;
     kp.F = n_bins;
     kp.feature = SALSA_FEATURE_SALSA;
-    float2 *Xs = (float2 *)d_workspace;
-    unsigned char *valid = (unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2));
-    const long total = (long)batch * n_bins * n_frames * 4;
-    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float2 *)d_X, Xs, batch, n_bins, (long)n_frames);
+    float4 *Xs = (float4 *)d_workspace;
+    unsigned long long *valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
+    const long total = (long)batch * n_bins * n_frames * 2;
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (long)n_frames);
     HIP_TRY(hipGetLastError());
     if (kp.tracking) {
-        const long n = (long)kp.B * kp.nd;
-        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, kp, Xs, valid);
+        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
         HIP_TRY(hipGetLastError());
     }
-    dim3 grid((unsigned)((long)kp.B * kp.T), (unsigned)((n_bins + 255) / 256));
-    hipLaunchKernelGGL((cov_eig_kernel<false>), grid, dim3(256), 0, s, kp, Xs, valid, (float *)nullptr, d_out, d_gate);
+    dim3 grid((unsigned)((kp.T + K3_FT - 1) / K3_FT), (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
+    launch_cov_eig<false>(kp, grid, s, Xs, valid, (float *)nullptr, d_out, d_gate);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }

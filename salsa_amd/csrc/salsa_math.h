@@ -98,6 +98,13 @@ template <typename T> SALSA_HD void unpack_pair(cplx<T> a, cplx<T> b, cplx<T> &x
     x1 = {(a.im + b.im) * (T)0.5, (b.re - a.re) * (T)0.5};
 }
 
+// Same with the /2 already applied to the transform's input (the kernels fold 0.5 into the window: exact).
+template <typename T> SALSA_HD void unpack_pair_prescaled(cplx<T> a, cplx<T> b, cplx<T> &x0, cplx<T> &x1)
+{
+    x0 = {a.re + b.re, a.im - b.im};
+    x1 = {a.im + b.im, b.re - a.re};
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 4x4 Hermitian matrix: 4 real diagonals + 6 complex upper off-diagonals in the order (01,02,03,12,13,23).
 template <typename T> struct herm4 {
@@ -187,22 +194,102 @@ template <typename T> SALSA_HD cplx<T> det3(cplx<T> a, cplx<T> b, cplx<T> c, cpl
     return cadd(csub(cmul(a, m0), cmul(b, m1)), cmul(c, m2));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cheap reciprocal / reciprocal-sqrt (device: v_rcp_f64 / v_rsq_f64, ~24 good bits).  Used only where the
+// consumer is self-correcting (Newton root iteration) or where the seed is refined explicitly.
+SALSA_HD double approx_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+SALSA_HD double approx_rsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(x);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+// 1/sqrt(x) to ~1e-15 relative: hardware seed + two Newton steps.  x = 0 -> NaN after refinement (inf * NaN), the
+// same NaN the reference's 0/0 produces at salsa_feature_extraction.py:119.
+SALSA_HD double refined_rsqrt(double x)
+{
+    double y = approx_rsqrt(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+// 2^(-floor(log2 x)) for normal positive x: scaling by it is exact and puts x in [1, 2).
+SALSA_HD double pow2_unscale(double x)
+{
+    const uint64_t bits = __builtin_bit_cast(uint64_t, x);
+    const uint64_t e = (bits >> 52) & 0x7ff;
+    return __builtin_bit_cast(double, (uint64_t)(2046 - e) << 52);
+}
+
+// The twelve 2x2 minors (rows {0,1}: s0..s5, rows {2,3}: c0..c5) of a Hermitian 4x4 in packed form, from which both
+// the characteristic polynomial and the adjugate follow by Laplace expansion.
+template <typename T> struct minors4 {
+    T s0, c5;                          // real for a Hermitian matrix
+    cplx<T> s1, s2, s3, s4, s5, c0, c1, c2, c3, c4;
+};
+
+template <typename T> SALSA_HD cplx<T> rmul(T r, cplx<T> a) { return {r * a.re, r * a.im}; }
+
+template <typename T> SALSA_HD minors4<T> herm4_minors(const herm4<T> &A)
+{
+    const T a00 = A.d[0], a11 = A.d[1], a22 = A.d[2], a33 = A.d[3];
+    const cplx<T> a01 = A.o[0], a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4], a23 = A.o[5];
+    minors4<T> m;
+    m.s0 = a00 * a11 - (a01.re * a01.re + a01.im * a01.im);
+    m.s1 = csub(rmul(a00, a12), cmul(cconj(a01), a02));          // a00 a12 - a10 a02
+    m.s2 = csub(rmul(a00, a13), cmul(cconj(a01), a03));          // a00 a13 - a10 a03
+    m.s3 = csub(cmul(a01, a12), rmul(a11, a02));                 // a01 a12 - a11 a02
+    m.s4 = csub(cmul(a01, a13), rmul(a11, a03));                 // a01 a13 - a11 a03
+    m.s5 = csub(cmul(a02, a13), cmul(a12, a03));                 // a02 a13 - a12 a03
+    m.c5 = a22 * a33 - (a23.re * a23.re + a23.im * a23.im);
+    m.c4 = csub(rmul(a33, cconj(a12)), cmul(cconj(a13), a23));   // a21 a33 - a31 a23
+    m.c3 = csub(cmul(cconj(a12), cconj(a23)), rmul(a22, cconj(a13))); // a21 a32 - a31 a22
+    m.c2 = csub(rmul(a33, cconj(a02)), cmul(cconj(a03), a23));   // a20 a33 - a30 a23
+    m.c1 = csub(cmul(cconj(a02), cconj(a23)), rmul(a22, cconj(a03))); // a20 a32 - a30 a22
+    m.c0 = csub(cmul(cconj(a02), cconj(a13)), cmul(cconj(a03), cconj(a12))); // a20 a31 - a30 a21
+    return m;
+}
+
+template <typename T> SALSA_HD T re_mul(cplx<T> a, cplx<T> b) { return a.re * b.re - a.im * b.im; } // Re(a b)
+
+// diagonal of adj(A) (real) from the minors
+template <typename T> SALSA_HD void herm4_adj_diag(const herm4<T> &A, const minors4<T> &m, T *dg)
+{
+    const cplx<T> a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4];
+    dg[0] = A.d[1] * m.c5 - re_mul(a12, m.c4) + re_mul(a13, m.c3);                       //  a11 c5 - a12 c4 + a13 c3
+    dg[1] = A.d[0] * m.c5 - re_mul(a02, m.c2) + re_mul(a03, m.c1);                       //  a00 c5 - a02 c2 + a03 c1
+    dg[2] = re_mul(cconj(a03), m.s4) - re_mul(cconj(a13), m.s2) + A.d[3] * m.s0;         //  a30 s4 - a31 s2 + a33 s0
+    dg[3] = re_mul(cconj(a02), m.s3) - re_mul(cconj(a12), m.s1) + A.d[2] * m.s0;         //  a20 s3 - a21 s1 + a22 s0
+}
+
 // Result of the per-TF-bin solve.
 template <typename T> struct eig_result {
     bool rank1;      // coherence test s0 > s1*cond (salsa_feature_extraction.py:106)
-    T margin;        // diagnostic: q(c)-based signed distance proxy (negative = one root above c)
+    T margin;        // diagnostic: q(mu1/cond) (negative = exactly one root above the threshold)
     cplx<T> u[4];    // principal eigenvector (arbitrary scale and phase); valid when computed
 };
 
 // Gate + principal eigenvector of a Hermitian PSD 4x4 R (any positive scale).
 //
-// Eigenvalues: R is normalised to trace 1 (A); the characteristic quartic q comes from the power sums tr(A^k), k<=4,
-// through Newton's identities; mu1 = largest root by Newton's iteration started at sqrt(tr A^2) >= mu1, which
-// descends monotonically onto mu1 for a real-rooted polynomial.  The gate mu1 > cond*mu2 is decided WITHOUT solving
-// for mu2: by Budan-Fourier (exact for real-rooted polynomials) the number of roots above c = mu1/cond equals the sign
-// variations of (q, q', q''/2, q'''/6, 1) at c; the bin is rank-1 iff that count is exactly one.
-// Eigenvector: a column of adj(A - mu1 I) = prod_{i>=2}(mu_i - mu1) u u^H, taking the column with the largest
-// diagonal cofactor.  Exact for any spectral gap (also with tracking off, where no gate protects the solve).
+// Eigenvalues: R is scaled by an exact power of two so its trace lies in [1,2) (A).  The characteristic quartic
+//   q(x) = x^4 - e1 x^3 + e2 x^2 - e3 x + e4,  e1 = tr A, e2 = sum of principal 2x2 minors, e3 = tr adj(A), e4 = det A
+// comes from the 2x2 minors by Laplace expansion.  mu1 = largest root by Newton's iteration started just above
+// sqrt(tr A^2) >= mu1, which descends monotonically onto mu1 for a real-rooted polynomial (the division inside the
+// iteration may be approximate: the iteration is self-correcting).  The gate mu1 > cond*mu2 is decided WITHOUT
+// solving for mu2: by Budan-Fourier (exact for real-rooted polynomials) the number of roots above c = mu1/cond equals
+// the sign variations of the Taylor coefficients (q, q1, q2/2, q3/6, 1) of q at c; the bin is rank-1 iff that count
+// is exactly one.
+// Eigenvector: a column of adj(A - mu1 I) = prod_{i>=2}(mu_i - mu1) u u^H (again from 2x2 minors), taking the column
+// with the largest diagonal cofactor.  Exact for any spectral gap (also with tracking off, where nothing gates it).
 template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, bool need_vector_always)
 {
     eig_result<T> res;
@@ -212,46 +299,49 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
     const T tr = R.d[0] + R.d[1] + R.d[2] + R.d[3];
     if (!(tr > (T)0)) return res; // zero matrix: s0 > s1*cond is 0 > 0 = False; LAPACK's U for it is the identity
-    const T inv = (T)1 / tr;
+    const T sc = (T)pow2_unscale((double)tr);
     herm4<T> A;
 #pragma unroll
-    for (int i = 0; i < 4; i++) A.d[i] = R.d[i] * inv;
+    for (int i = 0; i < 4; i++) A.d[i] = R.d[i] * sc;
 #pragma unroll
-    for (int k = 0; k < 6; k++) A.o[k] = {R.o[k].re * inv, R.o[k].im * inv};
-    const herm4<T> A2 = herm4_square(A);
-    const T p1 = A.d[0] + A.d[1] + A.d[2] + A.d[3]; // == 1 up to rounding
-    const T p2 = A2.d[0] + A2.d[1] + A2.d[2] + A2.d[3];
-    const T p3 = herm4_trace_prod(A, A2);
-    const T p4 = herm4_frob2(A2);
-    const T e1 = p1;
-    const T e2 = (e1 * p1 - p2) * (T)0.5;
-    const T e3 = (e2 * p1 - e1 * p2 + p3) * (T)(1.0 / 3.0);
-    const T e4 = (e3 * p1 - e2 * p2 + e1 * p3 - p4) * (T)0.25;
+    for (int k = 0; k < 6; k++) A.o[k] = {R.o[k].re * sc, R.o[k].im * sc};
+    const minors4<T> m = herm4_minors(A);
+    T nrm = 0; // sum |a_ij|^2, i<j
+#pragma unroll
+    for (int k = 0; k < 6; k++) nrm += A.o[k].re * A.o[k].re + A.o[k].im * A.o[k].im;
+    const T e1 = A.d[0] + A.d[1] + A.d[2] + A.d[3];
+    const T e2 = A.d[0] * A.d[1] + A.d[0] * A.d[2] + A.d[0] * A.d[3] + A.d[1] * A.d[2] + A.d[1] * A.d[3] + A.d[2] * A.d[3] - nrm;
+    T dg[4];
+    herm4_adj_diag(A, m, dg);
+    const T e3 = dg[0] + dg[1] + dg[2] + dg[3];
+    // det = s0 c5 - s1 c4 + s2 c3 + s3 c2 - s4 c1 + s5 c0 (real for Hermitian A)
+    const T e4 = m.s0 * m.c5 - re_mul(m.s1, m.c4) + re_mul(m.s2, m.c3) + re_mul(m.s3, m.c2) - re_mul(m.s4, m.c1) + re_mul(m.s5, m.c0);
     const T a3 = -e1, a2 = e2, a1 = -e3, a0 = e4; // q(x) = x^4 + a3 x^3 + a2 x^2 + a1 x + a0
-    T x = sqrt(p2);
-    if (x > p1) x = p1;
-    for (int it = 0; it < 48; it++) {
-        T q = (((x + a3) * x + a2) * x + a1) * x + a0;
-        T dq = (((T)4 * x + (T)3 * a3) * x + (T)2 * a2) * x + a1;
+    const T p2 = e1 * e1 - (T)2 * e2;             // tr(A^2) >= mu1^2
+    T x = p2 * (T)approx_rsqrt((double)p2) * (T)(1.0 + 1.0 / 1048576.0); // just above sqrt(p2)
+    if (!(x < e1)) x = e1;
+    for (int it = 0; it < 64; it++) {
+        const T q = (((x + a3) * x + a2) * x + a1) * x + a0;
+        const T dq = (((T)4 * x + (T)3 * a3) * x + (T)2 * a2) * x + a1;
         if (!(dq > (T)0)) break;
-        T step = q / dq;
+        const T step = q * (T)approx_rcp((double)dq);
         if (!(step > (T)0)) break; // at (or rounded past) the root
-        T xn = x - step;
+        const T xn = x - step;
         if (!(xn < x)) break;
         x = xn;
-        if (step <= (T)4 * (sizeof(T) == 8 ? (T)2.2e-16 : (T)1.2e-7) * x) break;
+        if (step <= (T)8 * (sizeof(T) == 8 ? (T)2.2e-16 : (T)1.2e-7) * x) break;
     }
     const T mu1 = x;
     if (cond <= (T)1) {
         res.rank1 = mu1 > (T)0; // mu2*cond < mu1 whenever mu1 > 0 (cond == 1: strict s0 > s1, a measure-zero tie)
     } else {
         const T c = mu1 / cond;
-        T t0 = (((c + a3) * c + a2) * c + a1) * c + a0;
-        T t1 = (((T)4 * c + (T)3 * a3) * c + (T)2 * a2) * c + a1;
-        T t2 = ((T)6 * c + (T)3 * a3) * c + a2;
-        T t3 = (T)4 * c + a3;
+        const T t0 = (((c + a3) * c + a2) * c + a1) * c + a0;
+        const T t1 = (((T)4 * c + (T)3 * a3) * c + (T)2 * a2) * c + a1;
+        const T t2 = ((T)6 * c + (T)3 * a3) * c + a2;
+        const T t3 = (T)4 * c + a3;
         int var = 0;
-        T prev = (T)1; // q''''/24 = 1
+        T prev = (T)1; // fourth Taylor coefficient of a monic quartic
         if (t3 != (T)0) { var += ((t3 < 0) != (prev < 0)); prev = t3; }
         if (t2 != (T)0) { var += ((t2 < 0) != (prev < 0)); prev = t2; }
         if (t1 != (T)0) { var += ((t1 < 0) != (prev < 0)); prev = t1; }
@@ -264,34 +354,28 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     herm4<T> B = A;
 #pragma unroll
     for (int i = 0; i < 4; i++) B.d[i] -= mu1;
-    const cplx<T> b00 = {B.d[0], 0}, b11 = {B.d[1], 0}, b22 = {B.d[2], 0}, b33 = {B.d[3], 0};
+    const minors4<T> n = herm4_minors(B);
+    T bd[4];
+    herm4_adj_diag(B, n, bd);
     const cplx<T> b01 = B.o[0], b02 = B.o[1], b03 = B.o[2], b12 = B.o[3], b13 = B.o[4], b23 = B.o[5];
-    const cplx<T> b10 = cconj(b01), b20 = cconj(b02), b30 = cconj(b03), b21 = cconj(b12), b31 = cconj(b13), b32 = cconj(b23);
-    // diagonal cofactors (real)
-    T c00 = det3(b11, b12, b13, b21, b22, b23, b31, b32, b33).re;
-    T c11 = det3(b00, b02, b03, b20, b22, b23, b30, b32, b33).re;
-    T c22 = det3(b00, b01, b03, b10, b11, b13, b30, b31, b33).re;
-    T c33 = det3(b00, b01, b02, b10, b11, b12, b20, b21, b22).re;
-    // adj(B)_{ij} = cofactor_{ji} = (-1)^{i+j} det(B without row j, col i).  For Hermitian B adj is Hermitian.
-    // upper entries adj01, adj02, adj03, adj12, adj13, adj23:
-    cplx<T> m;
-    m = det3(b01, b02, b03, b21, b22, b23, b31, b32, b33); const cplx<T> adj01 = {-m.re, -m.im}; // remove row1,col0
-    m = det3(b01, b02, b03, b11, b12, b13, b31, b32, b33); const cplx<T> adj02 = m;              // remove row2,col0
-    m = det3(b01, b02, b03, b11, b12, b13, b21, b22, b23); const cplx<T> adj03 = {-m.re, -m.im}; // remove row3,col0
-    m = det3(b00, b02, b03, b10, b12, b13, b30, b32, b33); const cplx<T> adj12 = {-m.re, -m.im}; // remove row2,col1
-    m = det3(b00, b02, b03, b10, b12, b13, b20, b22, b23); const cplx<T> adj13 = m;              // remove row3,col1
-    m = det3(b00, b01, b03, b10, b11, b13, b20, b21, b23); const cplx<T> adj23 = {-m.re, -m.im}; // remove row3,col2
-    T m0 = fabs(c00), m1 = fabs(c11), m2 = fabs(c22), m3 = fabs(c33);
+    // upper triangle of adj(B) (Hermitian)
+    const cplx<T> adj01 = csub(csub(cmul(b02, n.c4), rmul(n.c5, b01)), cmul(b03, n.c3));                    // -a01 c5 + a02 c4 - a03 c3
+    const cplx<T> adj02 = cadd(csub(cmul(cconj(b13), n.s5), cmul(cconj(b23), n.s4)), rmul(B.d[3], n.s3));   //  a31 s5 - a32 s4 + a33 s3
+    const cplx<T> adj03 = csub(csub(rmul(B.d[2], n.s4), cmul(cconj(b12), n.s5)), cmul(b23, n.s3));          // -a21 s5 + a22 s4 - a23 s3
+    const cplx<T> adj12 = csub(csub(cmul(cconj(b23), n.s2), cmul(cconj(b03), n.s5)), rmul(B.d[3], n.s1));   // -a30 s5 + a32 s2 - a33 s1
+    const cplx<T> adj13 = cadd(csub(cmul(cconj(b02), n.s5), rmul(B.d[2], n.s2)), cmul(b23, n.s1));          //  a20 s5 - a22 s2 + a23 s1
+    const cplx<T> adj23 = csub(csub(cmul(cconj(b12), n.s2), cmul(cconj(b02), n.s4)), rmul(n.s0, b23));      // -a20 s4 + a21 s2 - a23 s0
+    const T m0 = fabs(bd[0]), m1 = fabs(bd[1]), m2 = fabs(bd[2]), m3 = fabs(bd[3]);
     int j = 0;
     T best = m0;
     if (m1 > best) { best = m1; j = 1; }
     if (m2 > best) { best = m2; j = 2; }
     if (m3 > best) { best = m3; j = 3; }
     // column j of adj: u_i = adj_{ij}
-    if (j == 0) { res.u[0] = {c00, 0}; res.u[1] = cconj(adj01); res.u[2] = cconj(adj02); res.u[3] = cconj(adj03); }
-    else if (j == 1) { res.u[0] = adj01; res.u[1] = {c11, 0}; res.u[2] = cconj(adj12); res.u[3] = cconj(adj13); }
-    else if (j == 2) { res.u[0] = adj02; res.u[1] = adj12; res.u[2] = {c22, 0}; res.u[3] = cconj(adj23); }
-    else { res.u[0] = adj03; res.u[1] = adj13; res.u[2] = adj23; res.u[3] = {c33, 0}; }
+    if (j == 0) { res.u[0] = {bd[0], 0}; res.u[1] = cconj(adj01); res.u[2] = cconj(adj02); res.u[3] = cconj(adj03); }
+    else if (j == 1) { res.u[0] = adj01; res.u[1] = {bd[1], 0}; res.u[2] = cconj(adj12); res.u[3] = cconj(adj13); }
+    else if (j == 2) { res.u[0] = adj02; res.u[1] = adj12; res.u[2] = {bd[2], 0}; res.u[3] = cconj(adj23); }
+    else { res.u[0] = adj03; res.u[1] = adj13; res.u[2] = adj23; res.u[3] = {bd[3], 0}; }
     if (!(best > (T)0)) { // A == mu1 I numerically (fully degenerate): any vector; match LAPACK's identity column
         res.u[0] = {(T)1, (T)0};
         res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
@@ -299,19 +383,26 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     return res;
 }
 
-// FOA: real(u[1:]/u[0]) then L2-normalise (salsa_feature_extraction.py:118-119; no guard, IEEE inf/nan propagate).
+// FOA: real(u[1:]/u[0]) then L2-normalise (salsa_feature_extraction.py:118-119).  Re(u_i/u_0) = Re(u_i conj(u_0))
+// / |u_0|^2 and the positive factor 1/|u_0|^2 cancels in the normalisation, so e = v/||v|| with v_i = Re(u_i
+// conj(u_0)); u_0 = 0 gives 0/0 = NaN exactly where the reference (no guard) does.
 template <typename T> SALSA_HD void normalise_foa(const cplx<T> *u, T *e)
 {
-    const T den = u[0].re * u[0].re + u[0].im * u[0].im;
+    // scale u so |v| is O(1): adjugate columns can be tiny when the spectral gap is (tracking off)
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s = fmax(s, fabs(u[i].re)); s = fmax(s, fabs(u[i].im)); }
+    const T r = s > (T)0 ? (T)pow2_unscale((double)s) : (T)1;
+    const cplx<T> u0 = {u[0].re * r, u[0].im * r};
     T ss = 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        e[i] = (u[i + 1].re * u[0].re + u[i + 1].im * u[0].im) / den;
+        e[i] = (u[i + 1].re * r) * u0.re + (u[i + 1].im * r) * u0.im;
         ss += e[i] * e[i];
     }
-    ss = sqrt(ss);
+    const T inv = (T)refined_rsqrt((double)ss);
 #pragma unroll
-    for (int i = 0; i < 3; i++) e[i] = e[i] / ss;
+    for (int i = 0; i < 3; i++) e[i] = e[i] * inv;
 }
 
 // MIC: angle(u[1:]*conj(u[0])) / (delta*k) (salsa_feature_extraction.py:121-123); dk = delta*(ibin+lower_bin).

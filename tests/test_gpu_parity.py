@@ -184,6 +184,14 @@ def test_ragged_and_tiny_clips_against_oracle(dev, oracle):
         _check_lite(out, ref)
 
 
+def test_other_hop_frames_and_cond(dev, oracle):
+    """n_hopframes != 3 takes the generic (non-unrolled) covariance path; cond_num 0 disables the coherence gate."""
+    y = synth_clip(321, 3 * 24000)
+    for nh, cond in ((2, 5.0), (1, 3.0), (3, 0.0), (4, 8.0)):
+        ref, aux = oracle.extract_salsa(y, n_hopframes=nh, cond_num=cond, return_aux=True)
+        _check(_gpu_features(y, dev, n_hopframes=nh, cond_num=cond), ref, aux['margin'])
+
+
 def test_silent_and_constant_clips(dev, oracle):
     z = np.zeros((4, 6000), np.float32)
     out = _gpu_features(z, dev)
