@@ -100,10 +100,16 @@ int salsa_eigvec_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins
 
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
  * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the
- * milliseconds of the last call's kernels in launch order (n_out <= SALSA_MAX_KERNELS) and their names. */
-#define SALSA_MAX_KERNELS 8
+ * milliseconds of the last call's launches in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */
+#define SALSA_MAX_KERNELS 32
 int salsa_plan_set_timing(salsa_plan *plan, int enable);
 int salsa_plan_read_timing(salsa_plan *plan, float *ms, const char **names, int *n_out);
+
+/* Clip-group pipelining of salsa_extract_batch (default 1 = off; at most 8, capped at the batch size): the batch is cut into
+ * n_groups clip ranges whose kernels run on plan-owned streams forked from / joined to the caller's stream, so the
+ * latency-bound noise-floor tracker of one group overlaps the STFT / eigen kernels of the others.  1 = one group on
+ * the caller's stream only. */
+int salsa_plan_set_groups(salsa_plan *plan, int n_groups);
 
 #ifdef __cplusplus
 }

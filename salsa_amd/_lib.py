@@ -10,7 +10,7 @@ SRC_PATH = os.path.join(_HERE, 'csrc', 'salsa_kernels.hip')
 FORMAT = {'foa': 0, 'mic': 1}
 FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
 LAYOUT = {'planar': 0, 'interleaved': 1}
-MAX_KERNELS = 8
+MAX_KERNELS = 32
 
 E_INVAL, E_NFFT, E_FORMAT, E_BINS, E_WORKSPACE, E_HIP = -1, -2, -3, -4, -5, -6
 
@@ -55,6 +55,7 @@ def load():
     L.salsa_eigvec_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.c_size_t, vp]
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
+    L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -66,4 +67,4 @@ def last_error() -> str:
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
-           'salsa_plan_read_timing']
+           'salsa_plan_read_timing', 'salsa_plan_set_groups']

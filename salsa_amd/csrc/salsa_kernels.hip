@@ -45,8 +45,8 @@ int fail(int code, const char *fmt, const char *a = "", long b = 0)
 
 struct KParams {
     int B;
-    long N;   // samples per channel
-    long T;   // frames
+    int N;    // samples per channel (host checks 4*N < 2^31)
+    int T;    // frames (host checks 7*T*F < 2^31 and the per-clip spill < 2^31 elements)
     int hop;
     int lower, upper, nd; // DOA band [lower, upper), nd = upper - lower
     int cutoff;           // lite: spectrogram band [lower, cutoff)
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
-    const long Ns = kp.N, Tn = kp.T;
-    const long t_begin = ((long)blockIdx.x * 4 + w) * K1_NF;
+    const int Ns = kp.N, Tn = kp.T;
+    const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
     if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
     cplx<T> *z = buf[w];
     const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
@@ -133,34 +133,38 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             }
     }
 
+    const float *clip = audio + (long)b * 4 * Ns;
     auto load_item = [&](int item, float *y0, float *y1) {
-        const long t = t_begin + (item >> 1);
+        const int t = t_begin + (item >> 1);
         const int c0 = 2 * (item & 1);
-        const long base = t * kp.hop - N / 2;
+        const int base = t * kp.hop - N / 2;
         const bool interior = base >= 0 && base + N <= Ns;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const int n = salsa::stockham_in(lane, r, N, R);
-            const long s = interior ? base + n : salsa::reflect_index(base + n, Ns);
+            int s = base + salsa::stockham_in(lane, r, N, R);
+            if (!interior) { // np.pad(mode='reflect'); one fold suffices because Ns > N/2 (checked on the host)
+                if (s < 0) s = -s;
+                else if (s >= Ns) s = 2 * (Ns - 1) - s;
+            }
             if (kp.layout == SALSA_LAYOUT_PLANAR) {
-                y0[r] = audio[((long)b * 4 + c0) * Ns + s];
-                y1[r] = audio[((long)b * 4 + c0 + 1) * Ns + s];
+                y0[r] = clip[c0 * Ns + s];
+                y1[r] = clip[(c0 + 1) * Ns + s];
             } else {
-                const float2 yy = *reinterpret_cast<const float2 *>(audio + ((long)b * Ns + s) * 4 + c0);
+                const float2 yy = *reinterpret_cast<const float2 *>(clip + s * 4 + c0);
                 y0[r] = yy.x;
                 y1[r] = yy.y;
             }
         }
     };
 
-    const long nfr = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
-    const int nitems = (int)nfr * 2;
+    const int nitems = (Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF) * 2;
     float y0[R], y1[R];
     load_item(0, y0, y1);
-    float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip
+    float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
+    float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
 
     for (int item = 0; item < nitems; item++) {
-        const long t = t_begin + (item >> 1);
+        const int t = t_begin + (item >> 1);
         const int pr = item & 1;
         cplx<T> v[R];
 #pragma unroll
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!lite) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    Xs[(((long)b * Tn + t) * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
+                    xs[(t * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
                 if (k >= 1 && k <= kp.ident) {
-                    o[((long)c0 * Tn + t) * kp.F + (k - 1)] = db10(pa);
-                    o[((long)(c0 + 1) * Tn + t) * kp.F + (k - 1)] = db10(pb);
+                    o[(c0 * Tn + t) * kp.F + (k - 1)] = db10(pa);
+                    o[((c0 + 1) * Tn + t) * kp.F + (k - 1)] = db10(pb);
                 } else if (k > kp.ident && k < N / 2) {
                     pw[w][0][k - kp.ident - 1] = pa;
                     pw[w][1][k - kp.ident - 1] = pb;
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 if (pr == 0) x0s[w][k] = xa;
                 if (k >= kp.lower && k < kp.cutoff) {
                     const int f = k - kp.lower;
-                    o[((long)c0 * Tn + t) * kp.F + f] = db10(pa);
-                    o[((long)(c0 + 1) * Tn + t) * kp.F + f] = db10(pb);
+                    o[(c0 * Tn + t) * kp.F + f] = db10(pa);
+                    o[((c0 + 1) * Tn + t) * kp.F + f] = db10(pb);
                     const float2 x0 = pr == 0 ? xa : x0s[w][k];
                     const double scale = kp.feature == SALSA_FEATURE_IPD ? 3.14159265358979323846
                                                                          : kp.delta * (double)(k == 0 ? 1 : k);
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                             if (m < 1e-30 && m > 0.0) { wr *= 0x1p200; wi *= 0x1p200; } // keep the float cast normal
                             ph = (float)((double)atan2f((float)wi, (float)wr) / scale);
                         }
-                        o[((long)(3 + c0 + h) * Tn + t) * kp.F + f] = ph;
+                        o[((3 + c0 + h) * Tn + t) * kp.F + f] = ph;
                     }
                 }
             }
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 const int cnt = gi < ng - 1 ? 8 : 7;
                 float acc = 0.f;
                 for (int q = 0; q < cnt; q++) acc += 0.125f * pw[w][h][8 * gi + q];
-                o[((long)(c0 + h) * Tn + t) * kp.F + kp.ident + gi] = db10(acc);
+                o[((c0 + h) * Tn + t) * kp.F + kp.ident + gi] = db10(acc);
             }
         }
     }
@@ -262,17 +266,16 @@ constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
 constexpr int TR_WAVES = 8;     // 1 consumer + 7 producers
 
 template <int COUNT>
-__device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, long stride, long c0,
+__device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, int stride, int c0,
                                              int first, bool active, float2 *x)
 {
     // |X0| samples of frames c0+first-2 .. c0+first+COUNT-1 (wrap on the time axis; beyond the clip: unused)
-    const long Tn = kp.T;
+    const int Tn = kp.T;
 #pragma unroll
     for (int i = 0; i < COUNT + 2; i++) {
-        long t = c0 + first + i - 2;
+        int t = c0 + first + i - 2;
         if (t >= Tn) t = Tn - 1;
-        t %= Tn;
-        if (t < 0) t += Tn;
+        while (t < 0) t += Tn;
         const float4 v = active ? x0[t * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
         x[i] = make_float2(v.x, v.y);
     }
@@ -303,10 +306,10 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bin = g * 64 + lane;
     const bool active = bin < kp.nd;
-    const long Tn = kp.T;
-    const long stride = 2L * kp.nd; // float4 elements per frame
+    const int Tn = kp.T;
+    const int stride = 2 * kp.nd; // float4 elements per frame
     const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
-    const long nchunks = (Tn + TR_CH - 1) / TR_CH;
+    const int nchunks = (Tn + TR_CH - 1) / TR_CH;
     constexpr int PER_ALL = TR_CH / TR_WAVES;               // prologue: all 8 waves produce chunk 0
     constexpr int PER_PROD = (TR_CH + TR_WAVES - 2) / (TR_WAVES - 1);
     {
@@ -321,17 +324,17 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     salsa::tracker_state st = {0.0, 3};
     unsigned long long *vout = valid + (long)b * nchunks * kp.nd + (active ? bin : 0);
     if (w == 0) __builtin_amdgcn_s_setprio(3);
-    for (long c = 0; c < nchunks; c++) {
+    for (int c = 0; c < nchunks; c++) {
         const double *cur = ring[c & 1];
         if (w == 0) {
             if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
-                const long n0 = Tn < 5 ? Tn : 5;
+                const int n0 = Tn < 5 ? Tn : 5;
                 double acc = 0.0;
-                for (long t = 0; t < n0; t++) acc += cur[t * 64 + lane];
+                for (int t = 0; t < n0; t++) acc += cur[t * 64 + lane];
                 st.floor = 0.5 * (acc / (double)n0);
             }
             unsigned long long m = 0;
-            const int nfr = (int)(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH);
+            const int nfr = Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH;
             if (nfr == TR_CH) {
 #pragma unroll 16
                 for (int i = 0; i < TR_CH; i++) m |= (unsigned long long)salsa::tracker_step(st, cur[i * 64 + lane]) << i;
@@ -369,21 +372,24 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     __shared__ int count;
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const long Tn = kp.T;
-    const long t0 = (long)blockIdx.x * K3_FT;
-    const int nft = (int)(Tn - t0 < K3_FT ? Tn - t0 : K3_FT);
+    const int Tn = kp.T;
+    const int t0 = blockIdx.x * K3_FT;
+    const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
     const int bin0 = blockIdx.z * 256;
     const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
     if (tid == 0) count = 0;
     __syncthreads();
-    auto emit = [&](long t, int bin, const double *e, unsigned char g) {
+    float *of = FEAT ? out_feat + ((long)b * kp.OC + 4) * Tn * kp.F : nullptr; // channels 4-6 of this clip, [3][T][F]
+    double *oe = FEAT ? nullptr : out_eig + (long)b * 3 * kp.nd * Tn;
+    unsigned char *og = (!FEAT && gate) ? gate + (long)b * kp.nd * Tn : nullptr;
+    auto emit = [&](int t, int bin, const double *e, unsigned char g) {
         if (FEAT) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) out_feat[(((long)b * kp.OC + 4 + i) * Tn + t) * kp.F + bin] = (float)e[i];
+            for (int i = 0; i < 3; i++) of[(i * Tn + t) * kp.F + bin] = (float)e[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; i++) out_eig[(((long)b * 3 + i) * kp.nd + bin) * Tn + t] = e[i];
-            if (gate) gate[((long)b * kp.nd + bin) * Tn + t] = g;
+            for (int i = 0; i < 3; i++) oe[((long)i * kp.nd + bin) * Tn + t] = e[i];
+            if (og) og[(long)bin * Tn + t] = g;
         }
     };
     const double zero3[3] = {0.0, 0.0, 0.0};
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         const bool in = bl < nbc;
         unsigned long long word = ~0ull;
         if (in && kp.tracking) {
-            const long nchunks = (Tn + TR_CH - 1) / TR_CH;
+            const int nchunks = (Tn + TR_CH - 1) / TR_CH;
             word = valid[((long)b * nchunks + t0 / TR_CH) * kp.nd + bin0 + bl] >> (t0 % TR_CH);
         }
         for (int ft = 0; ft < nft; ft++) {
@@ -408,27 +414,28 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         for (int i = tid; i < nft * tail; i += 256) {
             const int ft = i / tail, f = kp.nd + (i - ft * tail);
 #pragma unroll
-            for (int c = 0; c < 3; c++) out_feat[(((long)b * kp.OC + 4 + c) * Tn + t0 + ft) * kp.F + f] = 0.f;
+            for (int c = 0; c < 3; c++) of[(c * Tn + t0 + ft) * kp.F + f] = 0.f;
         }
     }
     __syncthreads();
     const int n = count;
-    const long stride = 2L * kp.nd;
+    const int stride = 2 * kp.nd;
     const int nhop = NHOP >= 0 ? NHOP : kp.n_hop;
+    const float4 *xclip = Xs + (long)b * Tn * stride;
     for (int s = tid; s < n; s += 256) {
         const int i = list[s];
-        const long t = t0 + (i >> 8);
+        const int t = t0 + (i >> 8);
         const int bin = bin0 + (i & 255);
         salsa::herm4<double> R = {};
-        const float4 *xb = Xs + (long)b * Tn * stride + bin;
+        const float4 *xb = xclip + bin;
         if (NHOP >= 0) {
             constexpr int NW = NHOP >= 0 ? 2 * NHOP + 1 : 1;
             float4 xa[NW], xc[NW];
 #pragma unroll
             for (int k = 0; k <= 2 * NHOP; k++) {
-                long tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
-                if (tt < 0) tt = (tt % Tn + Tn) % Tn;
-                else if (tt >= Tn) tt %= Tn;
+                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
                 xa[k] = xb[tt * stride];
                 xc[k] = xb[tt * stride + kp.nd];
             }
@@ -440,7 +447,9 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
             }
         } else {
             for (int k = -nhop; k <= nhop; k++) {
-                long tt = ((t + k) % Tn + Tn) % Tn;
+                int tt = t + k;
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
                 const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
                 const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
                                            {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
@@ -470,7 +479,7 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
 }
 
 // reference layout (n_bins, n_frames, 4) complex64 -> internal Xs[b][t][pair][bin] float4
-__global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xs, int B, int nb, long Tn)
+__global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xs, int B, int nb, int Tn)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * nb * Tn * 2;
@@ -479,7 +488,7 @@ __global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict
     long r = idx / nb;
     const int pr = (int)(r % 2);
     r /= 2;
-    const long t = r % Tn;
+    const int t = (int)(r % Tn);
     const int b = (int)(r / Tn);
     Xs[idx] = X[(((long)b * nb + bin) * Tn + t) * 2 + pr];
 }
@@ -487,6 +496,8 @@ __global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict
 } // namespace
 
 // ================================================================================================== plan + C ABI
+constexpr int SALSA_MAX_GROUPS = 8;
+
 struct salsa_plan {
     salsa_params p;
     int device;
@@ -496,8 +507,14 @@ struct salsa_plan {
     cplx<double> *d_tw;
     int timing;
     int n_kernels;
-    hipEvent_t ev[SALSA_MAX_KERNELS + 1];
+    hipEvent_t ev0[SALSA_MAX_KERNELS], ev1[SALSA_MAX_KERNELS]; // start/stop of each launch (timing mode only)
     const char *names[SALSA_MAX_KERNELS];
+    // clip-group pipeline: stream 0 runs the STFT kernels of all groups back to back; group g's tracker and
+    // covariance/eigen kernels run on stream 1+g, so the latency-bound tracker of one group hides under the
+    // STFT / eigen work of its neighbours.
+    int n_groups;
+    hipStream_t streams[SALSA_MAX_GROUPS + 1];
+    hipEvent_t ev_fork, ev_stft[SALSA_MAX_GROUPS], ev_join[SALSA_MAX_GROUPS + 1];
 };
 
 extern "C" {
@@ -608,7 +625,21 @@ int salsa_plan_create(const salsa_params *params, salsa_plan **out_plan)
         salsa_plan_destroy(pl);
         return fail(SALSA_EHIP, "plan table upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
-    for (int i = 0; i <= SALSA_MAX_KERNELS; i++) pl->ev[i] = nullptr;
+    pl->n_groups = 1; // measured on ROCm 7.2: multi-stream issue costs more host time than the overlap returns
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
+        bool ok = true;
+        for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++)
+            ok = hipStreamCreateWithPriority(&pl->streams[i], hipStreamNonBlocking, i == 0 ? lo : hi) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            salsa_plan_destroy(pl);
+            return fail(SALSA_EHIP, "stream / event creation failed%s");
+        }
+    }
     *out_plan = pl;
     return SALSA_OK;
 }
@@ -618,8 +649,16 @@ int salsa_plan_destroy(salsa_plan *pl)
     if (!pl) return SALSA_OK;
     if (pl->d_window) (void)hipFree(pl->d_window);
     if (pl->d_tw) (void)hipFree(pl->d_tw);
-    for (int i = 0; i <= SALSA_MAX_KERNELS; i++)
-        if (pl->ev[i]) (void)hipEventDestroy(pl->ev[i]);
+    for (int i = 0; i < SALSA_MAX_KERNELS; i++) {
+        if (pl->ev0[i]) (void)hipEventDestroy(pl->ev0[i]);
+        if (pl->ev1[i]) (void)hipEventDestroy(pl->ev1[i]);
+    }
+    for (int i = 0; i <= SALSA_MAX_GROUPS; i++) {
+        if (pl->streams[i]) (void)hipStreamDestroy(pl->streams[i]);
+        if (pl->ev_join[i]) (void)hipEventDestroy(pl->ev_join[i]);
+        if (i < SALSA_MAX_GROUPS && pl->ev_stft[i]) (void)hipEventDestroy(pl->ev_stft[i]);
+    }
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     delete pl;
     return SALSA_OK;
 }
@@ -653,8 +692,8 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     KParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.B = batch;
-    kp.N = n_samples;
-    kp.T = 1 + n_samples / pl->p.hop_len;
+    kp.N = (int)n_samples;
+    kp.T = (int)(1 + n_samples / pl->p.hop_len);
     kp.hop = pl->p.hop_len;
     kp.lower = pl->lower;
     kp.upper = pl->upper;
@@ -674,16 +713,20 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     return kp;
 }
 
-static void mark(salsa_plan *pl, hipStream_t s, const char *name)
+// timing mode: bracket one launch with events on ITS stream
+static int mark_begin(salsa_plan *pl, hipStream_t s, const char *name)
 {
-    if (!pl->timing) return;
-    if (name && pl->n_kernels < SALSA_MAX_KERNELS) pl->names[pl->n_kernels] = name;
-    const int slot = name ? pl->n_kernels + 1 : 0;
-    if (slot > SALSA_MAX_KERNELS) return;
-    if (!pl->ev[slot]) (void)hipEventCreate(&pl->ev[slot]);
-    (void)hipEventRecord(pl->ev[slot], s);
-    if (name) pl->n_kernels++;
-    else pl->n_kernels = 0;
+    if (!pl->timing || pl->n_kernels >= SALSA_MAX_KERNELS) return -1;
+    const int i = pl->n_kernels++;
+    pl->names[i] = name;
+    if (!pl->ev0[i]) (void)hipEventCreate(&pl->ev0[i]);
+    if (!pl->ev1[i]) (void)hipEventCreate(&pl->ev1[i]);
+    (void)hipEventRecord(pl->ev0[i], s);
+    return i;
+}
+static void mark_end(salsa_plan *pl, hipStream_t s, int i)
+{
+    if (i >= 0) (void)hipEventRecord(pl->ev1[i], s);
 }
 
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
@@ -704,6 +747,11 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         return fail(SALSA_EINVAL, "salsa_extract_batch: bad argument%s");
     if (n_samples <= pl->p.n_fft / 2)
         return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
+    {   // kernels index inside one clip with 32-bit offsets
+        const int64_t T64 = 1 + n_samples / pl->p.hop_len;
+        if (n_samples * 4 >= INT32_MAX || T64 * 7 * pl->F >= INT32_MAX || T64 * 2 * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX)
+            return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
+    }
     hipStream_t s = (hipStream_t)hip_stream;
     KParams kp = make_kparams(pl, batch, n_samples);
     const bool full = pl->p.feature_type == SALSA_FEATURE_SALSA;
@@ -715,22 +763,52 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         Xs = (float4 *)d_workspace;
         valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
     }
-    mark(pl, s, nullptr);
-    int rc = launch_stft(pl, kp, d_audio, d_out, Xs, s);
-    if (rc) return rc;
-    mark(pl, s, "stft_logspec");
-    if (!full) return SALSA_OK;
-    if (kp.nd > 0 && kp.tracking) {
-        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
+    pl->n_kernels = 0;
+    const long T = kp.T;
+    const size_t nchunks = (size_t)((T + TR_CH - 1) / TR_CH);
+    // group g = clips [g0, g1): every buffer is clip-major, so a group is just a pointer offset
+    auto run_group = [&](int g0, int g1, hipStream_t s1, hipStream_t s2, hipEvent_t between) -> int {
+        KParams gp = kp;
+        gp.B = g1 - g0;
+        const float *a = d_audio + (size_t)g0 * 4 * kp.N;
+        float *o = d_out + (size_t)g0 * 7 * T * kp.F;
+        float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
+        unsigned long long *vm = valid ? valid + (size_t)g0 * nchunks * kp.nd : nullptr;
+        int m = mark_begin(pl, s1, "stft_logspec");
+        int rc = launch_stft(pl, gp, a, o, xs, s1);
+        mark_end(pl, s1, m);
+        if (rc || !full) return rc;
+        if (between) {
+            HIP_TRY(hipEventRecord(between, s1));
+            HIP_TRY(hipStreamWaitEvent(s2, between, 0));
+        }
+        if (gp.nd > 0 && gp.tracking) {
+            m = mark_begin(pl, s2, "noise_floor_tracker");
+            hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(gp.B * ((gp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
+            mark_end(pl, s2, m);
+            HIP_TRY(hipGetLastError());
+        }
+        m = mark_begin(pl, s2, "cov_eig");
+        dim3 grid((unsigned)((gp.T + K3_FT - 1) / K3_FT), (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
+        launch_cov_eig<true>(gp, grid, s2, xs, vm, o, (double *)nullptr, (unsigned char *)nullptr);
+        mark_end(pl, s2, m);
         HIP_TRY(hipGetLastError());
+        return SALSA_OK;
+    };
+    const int G = (!full || pl->n_groups <= 1 || batch < 2) ? 1 : (batch < pl->n_groups ? batch : pl->n_groups);
+    if (G == 1) return run_group(0, batch, s, s, nullptr);
+    HIP_TRY(hipEventRecord(pl->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(pl->streams[0], pl->ev_fork, 0));
+    for (int g = 0; g < G; g++) {
+        HIP_TRY(hipStreamWaitEvent(pl->streams[1 + g], pl->ev_fork, 0)); // orders this call after the caller's earlier work
+        const int g0 = (int)((long)batch * g / G), g1 = (int)((long)batch * (g + 1) / G);
+        const int rc = run_group(g0, g1, pl->streams[0], pl->streams[1 + g], pl->ev_stft[g]);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(pl->ev_join[1 + g], pl->streams[1 + g]));
+        HIP_TRY(hipStreamWaitEvent(s, pl->ev_join[1 + g], 0));
     }
-    mark(pl, s, "noise_floor_tracker");
-    {
-        dim3 grid((unsigned)((kp.T + K3_FT - 1) / K3_FT), (unsigned)kp.B, (unsigned)((kp.nd + 255) / 256));
-        launch_cov_eig<true>(kp, grid, s, Xs, valid, d_out, (double *)nullptr, (unsigned char *)nullptr);
-        HIP_TRY(hipGetLastError());
-    }
-    mark(pl, s, "cov_eig");
+    HIP_TRY(hipEventRecord(pl->ev_join[0], pl->streams[0]));
+    HIP_TRY(hipStreamWaitEvent(s, pl->ev_join[0], 0));
     return SALSA_OK;
 }
 
@@ -740,6 +818,8 @@ int salsa_logspec_batch(salsa_plan *pl, const float *d_audio, int batch, int n_c
     if (!pl || !d_audio || !d_out || batch <= 0 || n_samples <= 0) return fail(SALSA_EINVAL, "salsa_logspec_batch: bad argument%s");
     if (n_channels != 4) return fail(SALSA_EINVAL, "salsa_logspec_batch: n_channels must be 4 (pad with silent channels)%s");
     if (n_samples <= pl->p.n_fft / 2) return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
+    if (n_samples * 4 >= INT32_MAX || (1 + n_samples / pl->p.hop_len) * 7 * 256 >= INT32_MAX)
+        return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
     KParams kp = make_kparams(pl, batch, n_samples);
     kp.feature = FEATURE_LOGSPEC_ONLY;
     kp.OC = 4;
@@ -755,11 +835,12 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
 {
     if (!pl || !d_X || !d_out || batch <= 0 || n_bins <= 0 || n_frames <= 0)
         return fail(SALSA_EINVAL, "salsa_eigvec_batch: bad argument%s");
+    if ((int64_t)n_frames * 2 * n_bins >= INT32_MAX) return fail(SALSA_EINVAL, "block too large for 32-bit per-clip indexing%s");
     const size_t need = salsa_eigvec_workspace_bytes(pl, batch, n_bins, n_frames);
     if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
     hipStream_t s = (hipStream_t)hip_stream;
     KParams kp = make_kparams(pl, batch, 0);
-    kp.T = n_frames;
+    kp.T = (int)n_frames;
     kp.nd = n_bins;
     kp.lower = lower_bin;
     kp.upper = lower_bin + n_bins;
@@ -768,7 +849,7 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     float4 *Xs = (float4 *)d_workspace;
     unsigned long long *valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
     const long total = (long)batch * n_bins * n_frames * 2;
-    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (long)n_frames);
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
     if (kp.tracking) {
         hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
@@ -793,12 +874,19 @@ int salsa_plan_read_timing(salsa_plan *pl, float *ms, const char **names, int *n
     if (!pl || !ms || !n_out) return fail(SALSA_EINVAL, "salsa_plan_read_timing: NULL argument%s");
     *n_out = 0;
     if (!pl->timing || pl->n_kernels == 0) return SALSA_OK;
-    HIP_TRY(hipEventSynchronize(pl->ev[pl->n_kernels]));
     for (int i = 0; i < pl->n_kernels; i++) {
-        HIP_TRY(hipEventElapsedTime(&ms[i], pl->ev[i], pl->ev[i + 1]));
+        HIP_TRY(hipEventSynchronize(pl->ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], pl->ev0[i], pl->ev1[i]));
         if (names) names[i] = pl->names[i];
     }
     *n_out = pl->n_kernels;
+    return SALSA_OK;
+}
+
+int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
+{
+    if (!pl || n_groups < 1) return fail(SALSA_EINVAL, "salsa_plan_set_groups: bad argument%s");
+    pl->n_groups = n_groups > SALSA_MAX_GROUPS ? SALSA_MAX_GROUPS : n_groups;
     return SALSA_OK;
 }
 

@@ -159,6 +159,12 @@ class SalsaExtractor:
     def set_timing(self, enable: bool):
         self.L.salsa_plan_set_timing(self._plan, int(bool(enable)))
 
+    def set_groups(self, n_groups: int):
+        """Clip-group pipelining depth of extract() (1 = single stream)."""
+        rc = self.L.salsa_plan_set_groups(self._plan, int(n_groups))
+        if rc:
+            _raise(rc)
+
     def read_timing(self):
         """[(kernel name, milliseconds)] of the last extract() call (HIP events on its stream)."""
         ms = (C.c_float * _lib.MAX_KERNELS)()

@@ -244,3 +244,21 @@ def test_errors_mirror_reference(dev):
         _extractor(feature_type='salsa_lite', audio_format='foa')          # lite :72
     with pytest.raises(AssertionError):
         _extractor(feature_type='salsa_lite', audio_format='mic', fmax_doa=9500)   # lite :59
+
+
+def test_clip_group_pipeline_is_bit_identical(dev):
+    """The multi-stream clip-group pipeline only reorders independent clips: outputs must equal the single-stream run."""
+    ys = np.stack([synth_clip(700 + i, 4 * 24000) for i in range(5)])
+    a = torch.from_numpy(ys).to(dev)
+    ex = _extractor()
+    ex.set_groups(1)
+    ref = ex.extract(a).clone()
+    for g in (2, 3, 8):
+        ex.set_groups(g)
+        for _ in range(3):
+            assert torch.equal(ex.extract(a), ref)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                    # called from a non-default stream
+        o2 = ex.extract(a)
+    side.synchronize()
+    assert torch.equal(o2, ref)
