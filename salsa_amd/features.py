@@ -1,0 +1,217 @@
+"""Drop-in Python surface of the reference's full-SALSA module (dataset/salsa_feature_extraction.py): same function
+names, arguments, defaults, exceptions and file layout, with the arithmetic running in libsalsa_hip.so on an MI355X.
+
+  reference                                             here
+  extract_normalized_eigenvector(X, ...)   :17-129      extract_normalized_eigenvector  (numpy in / numpy out)
+  MagStftExtractor(...).W / .extract       :132-201     MagStftExtractor
+  compute_scaler(feature_dir, audio_format) :204-262    compute_scaler
+  extract_features(data_config, ...)       :265-391     extract_features  (+ ``python -m salsa_amd.features --flag=...``)
+
+There is no CPU path: without a GPU / without the built library these functions raise.
+"""
+import os
+import shutil
+import sys
+from timeit import default_timer as timer
+
+import numpy as np
+import yaml
+
+from . import io as sio
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('salsa_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback')
+    return torch
+
+
+def extract_normalized_eigenvector(X, condition_number: float = 5.0, n_hopframes: int = 3, is_tracking: bool = True,
+                                   audio_format: str = 'foa', fs: int = None, n_fft: int = None,
+                                   lower_bin: int = None):
+    """X <np.ndarray (n_bins, n_frames, n_chans=4)> clipped spectrogram -> (3, n_bins, n_frames) float64.
+    Mirrors dataset/salsa_feature_extraction.py:17 (values are taken at complex64 precision, which is what the
+    reference's STFT holds)."""
+    if audio_format not in ('foa', 'mic'):
+        raise ValueError('audio format {} is not valid'.format(audio_format))
+    torch = _torch()
+    from .extractor import SalsaExtractor
+    X = np.asarray(X)
+    assert X.ndim == 3 and X.shape[2] == 4, 'X must be (n_bins, n_frames, 4)'
+    # (the plan's own DOA band is irrelevant here: the band is whatever rows X holds)
+    ex = SalsaExtractor(fs=fs or 24000, n_fft=n_fft or 512, hop_len=300, fmin_doa=0, fmax_doa=(fs or 24000) // 8,
+                        cond_num=condition_number, n_hopframes=n_hopframes, is_tracking=is_tracking,
+                        audio_format=audio_format)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.astype(np.complex64))[None]).cuda()
+    out = ex.eigvec(Xd, lower_bin=int(lower_bin or 0))
+    return out[0].cpu().numpy()
+
+
+class MagStftExtractor:
+    """Log-linear spectrograms (n_channels, n_timesteps, 200|100|n_fft/2).  Mirrors :132-201."""
+
+    def __init__(self, n_fft: int, hop_length: int, win_length: int = None, window: str = 'hann',
+                 is_compress_high_freq: bool = True):
+        from .extractor import compress_matrix
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.window = window
+        self.win_length = self.n_fft if win_length is None else win_length
+        assert self.win_length <= self.n_fft, 'Windown length is greater than nfft!'
+        assert n_fft == 512 or n_fft == 256, 'nfft is not 512 or 256'
+        if window != 'hann':
+            raise ValueError('only the hann window of the reference configs is implemented')
+        self.is_compress_high_freq = is_compress_high_freq
+        self.W = compress_matrix(n_fft, is_compress_high_freq)
+        self._ex = None
+
+    def extract(self, audio_input: np.ndarray) -> np.ndarray:
+        torch = _torch()
+        from .extractor import SalsaExtractor
+        if self._ex is None:
+            self._ex = SalsaExtractor(n_fft=self.n_fft, hop_len=self.hop_length, win_len=self.win_length,
+                                      is_compress_high_freq=self.is_compress_high_freq)
+        a = np.ascontiguousarray(audio_input, np.float32)
+        n_ch = a.shape[0]
+        outs = []
+        for c0 in range(0, n_ch, 4):                       # the kernel works on groups of 4 channels
+            blk = a[c0:c0 + 4]
+            if blk.shape[0] < 4:
+                blk = np.concatenate([blk, np.zeros((4 - blk.shape[0], a.shape[1]), np.float32)])
+            o = self._ex.logspec(torch.from_numpy(np.ascontiguousarray(blk[None])).cuda())[0].cpu().numpy()
+            outs.append(o[:min(4, n_ch - c0)])
+        return np.concatenate(outs, axis=0)
+
+
+def compute_scaler(feature_dir: str, audio_format: str) -> None:
+    """Mean / std of the 4 spectrogram channels over ALL files of <audio_format>_dev -> <audio_format>_feature_scaler
+    (datasets 'mean', 'std', shape (4,1,F) float32).  Mirrors :204-262 (StandardScaler.partial_fit: population std)."""
+    print('============> Start calculating scaler')
+    start_time = timer()
+    train_feature_dir = os.path.join(feature_dir, audio_format + '_dev')
+    feature_fn_list = sio.feature_files(train_feature_dir)
+    afeature = sio.load_arrays(os.path.join(train_feature_dir, feature_fn_list[0]))['feature']
+    n_channels = afeature.shape[0]
+    assert n_channels == 7, 'only support n_channels = 7, got {}'.format(n_channels)
+    n_feature_channels = 4
+    shift = afeature[:n_feature_channels].astype(np.float64).mean(axis=1)     # conditioning of the one-pass variance
+    n, s, ss = 0, np.zeros_like(shift), np.zeros_like(shift)
+    for feature_fn in feature_fn_list:
+        afeature = sio.load_arrays(os.path.join(train_feature_dir, feature_fn))['feature']
+        d = afeature[:n_feature_channels].astype(np.float64) - shift[:, None, :]
+        s += d.sum(axis=1)
+        ss += (d * d).sum(axis=1)
+        n += afeature.shape[1]
+    feature_mean = (shift + s / n)[:, None, :]
+    feature_std = np.sqrt(np.maximum(ss / n - (s / n) ** 2, 0.0))[:, None, :]
+    scaler_path = os.path.join(feature_dir, audio_format + '_feature_scaler.h5')
+    written = sio.save_arrays(scaler_path, mean=feature_mean, std=feature_std)
+    print('Features shape: {}'.format(afeature.shape))
+    print('Scaler path: {}'.format(written))
+    print('Elapsed time: {:.3f} s'.format(timer() - start_time))
+
+
+def _parse(data_config):
+    with open(data_config, 'r') as stream:
+        cfg = yaml.safe_load(stream)
+    d = cfg['data']
+    return cfg, d['format'], d['fs'], d['n_fft'], d['hop_len'], d['win_len'], d['fmin_doa'], d['fmax_doa']
+
+
+def feature_name(audio_fn: str) -> str:
+    """The reference names the feature file ``audio_fn.replace('wav', 'h5')`` (:379, every occurrence)."""
+    out = audio_fn.replace('wav', 'h5')
+    return out if out != audio_fn else os.path.splitext(audio_fn)[0] + '.h5'
+
+
+def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear=True):
+    """Extract the clips of one split directory, batching clips of equal length (one device round trip per batch).
+    shard = (rank, world): this process takes a contiguous range of the sorted file list (salsa_amd.distributed)."""
+    torch = _torch()
+    if clear:
+        shutil.rmtree(feature_dir, ignore_errors=True)      # the reference empties the split's folder first (:344)
+    os.makedirs(feature_dir, exist_ok=True)
+    audio_fn_list = sorted(os.listdir(audio_dir))
+    todo = list(enumerate(audio_fn_list))
+    if shard is not None:
+        from .distributed import shard_range
+        lo, hi = shard_range(len(todo), *shard)
+        todo = todo[lo:hi]
+    pending = {}                                            # n_samples -> [(count, fn, audio)]
+
+    def flush(items):
+        batch = np.stack([a for _, _, a in items])
+        feats = ex.extract(torch.from_numpy(batch).cuda()).cpu().numpy()
+        for (count, fn, _), f in zip(items, feats):
+            sio.save_arrays(os.path.join(feature_dir, feature_name(fn)), feature=f)
+            print('{}, {}, {}'.format(count, fn, f.shape))
+
+    for count, audio_fn in todo:
+        audio_input = sio.load_audio(os.path.join(audio_dir, audio_fn), sr=fs)
+        assert audio_input.shape[0] == 4, '{}: expected a 4-channel clip'.format(audio_fn)
+        lst = pending.setdefault(audio_input.shape[1], [])
+        lst.append((count, audio_fn, audio_input))
+        if len(lst) == batch_size:
+            flush(lst)
+            lst.clear()
+    for lst in pending.values():
+        if lst:
+            flush(lst)
+
+
+def extract_features(data_config: str = 'configs/tnsse2021_salsa_feature_config.yml',
+                     cond_num: float = 5,
+                     n_hopframes: int = 3,
+                     is_tracking: bool = True,
+                     is_compress_high_freq: bool = True,
+                     task: str = 'feature_scaler',
+                     batch_size: int = 32) -> None:
+    """Extract salsa features (log-linear spectrogram + normalized eigenvector) for every clip of <format>_dev and
+    <format>_eval, then the scaler.  Mirrors :265-391 (same directory naming, split iteration, sorted file order,
+    (7,T,F) float32 'feature' per clip).  ``batch_size`` (clips per device call) is the only extra argument."""
+    cfg, audio_format, fs, n_fft, hop_length, win_length, fmin_doa, fmax_doa = _parse(data_config)
+    feature_type = 'salsa'
+    fmax_doa = int(np.min((fmax_doa, fs // 2)))
+    assert n_fft == 512 or n_fft == 256, 'only 256 or 512 fft is supported'
+    feature_description = '{}fs_{}nfft_{}nhop_{}cond_{}fmaxdoa'.format(fs, n_fft, hop_length, int(cond_num), int(fmax_doa))
+    if not is_tracking:
+        feature_description = feature_description + '_notracking'
+    if not is_compress_high_freq:
+        feature_description = feature_description + '_nocompress'
+    if audio_format == 'foa':
+        splits = ['foa_dev', 'foa_eval']
+    elif audio_format == 'mic':
+        splits = ['mic_dev', 'mic_eval']
+    else:
+        raise ValueError('Unknown audio format {}'.format(audio_format))
+    print('Feature description: {}'.format(feature_description))
+    if task in ['feature_scaler', 'feature']:
+        from .extractor import SalsaExtractor
+        ex = SalsaExtractor(fs=fs, n_fft=n_fft, hop_len=hop_length, win_len=win_length, fmin_doa=fmin_doa,
+                            fmax_doa=fmax_doa, cond_num=cond_num, n_hopframes=n_hopframes, is_tracking=is_tracking,
+                            is_compress_high_freq=is_compress_high_freq, audio_format=audio_format)
+        for split in splits:
+            print('============> Start extracting features for {} split'.format(split))
+            start_time = timer()
+            audio_dir = os.path.join(cfg['data_dir'], split)
+            feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description, split)
+            _extract_split(ex, audio_dir, feature_dir, fs, batch_size)
+            print('Extracting feature finished! Elapsed time: {:.3f} s'.format(timer() - start_time))
+    if task in ['feature_scaler', 'scaler']:
+        feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
+        compute_scaler(feature_dir=feature_dir, audio_format=audio_format)
+
+
+def _cli(fn, argv):
+    """python-fire style ``--name=value`` flags -> keyword arguments (the reference wraps the function in fire.Fire)."""
+    kw = {}
+    for a in argv:
+        assert a.startswith('--') and '=' in a, 'use --name=value'
+        k, v = a[2:].split('=', 1)
+        kw[k] = yaml.safe_load(v)
+    fn(**kw)
+
+
+if __name__ == '__main__':
+    _cli(extract_features, sys.argv[1:])

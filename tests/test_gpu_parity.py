@@ -2,6 +2,8 @@
 salsa_amd.extractor), against (i) the golden vectors produced by the reference itself and (ii) the CPU oracle on
 seeded inputs.  Tolerances (BASELINE.json north_star): bit-exact frame/bin indexing and gates, 1e-5 relative on
 floats.  A gate disagreement is admissible only inside float64 round-off of the threshold (|margin| < 1e-9)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -262,3 +264,74 @@ def test_clip_group_pipeline_is_bit_identical(dev):
         o2 = ex.extract(a)
     side.synchronize()
     assert torch.equal(o2, ref)
+
+
+# ----------------------------------------------------------------------------------------------- reference surface
+def _make_tree(tmp, fmt, clips, fmax, n_fft=512, hop=300):
+    import yaml
+    from scipy.io import wavfile
+    data_dir, feat_dir = os.path.join(tmp, 'data'), os.path.join(tmp, 'feat')
+    for key, y in clips.items():
+        split, name = key.split('|')
+        d = os.path.join(data_dir, '%s_%s' % (fmt, split))
+        os.makedirs(d, exist_ok=True)
+        wavfile.write(os.path.join(d, name + '.wav'), 24000, y.T)          # float32 WAV: samples survive exactly
+    os.makedirs(os.path.join(data_dir, fmt + '_eval'), exist_ok=True)
+    cfg = {'data_dir': data_dir, 'feature_dir': feat_dir,
+           'data': {'format': fmt, 'fs': 24000, 'n_fft': n_fft, 'win_len': n_fft, 'hop_len': hop, 'fmin_doa': 50,
+                    'fmax_doa': fmax}}
+    path = os.path.join(tmp, 'cfg.yml')
+    with open(path, 'w') as f:
+        yaml.safe_dump(cfg, f)
+    return path, feat_dir
+
+
+@pytest.mark.parametrize('fmt', ['foa', 'mic'])
+def test_extract_features_harness_reproduces_reference_tree(dev, oracle, tmp_path, fmt):
+    """salsa_amd.features.extract_features against the reference's own run (fixture g3): directory naming, one
+    feature file per clip, (7,T,200) float32 values, and the scaler over all dev files."""
+    from salsa_amd import io as sio
+    from salsa_amd.features import extract_features
+    meta, a = load_golden('g3_salsa_%s' % fmt)
+    clips = {k: golden_clip(*v) for k, v in meta['clips'].items()}
+    cfg, feat_dir = _make_tree(str(tmp_path), fmt, clips, meta['fmax_doa'])
+    extract_features(data_config=cfg, batch_size=2)
+    n_checked = 0
+    for key, ref in a.items():
+        parts = key.split('|')
+        got = sio.load_arrays(os.path.join(feat_dir, *parts[:-1]))[parts[-1]]
+        if parts[-1] == 'feature':
+            split, name = parts[3], parts[4][:-3]
+            y = clips[('dev|' if split.endswith('_dev') else 'eval|') + name]
+            _, aux = oracle.extract_salsa(y, fmax_doa=meta['fmax_doa'], audio_format=fmt, return_aux=True)
+            _check(got, ref, aux['margin'])
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+        n_checked += 1
+    assert n_checked == len(a)
+
+
+def test_lite_harness_and_python_surface(dev, tmp_path):
+    from salsa_amd import io as sio
+    from salsa_amd import lite_features
+    from salsa_amd.features import MagStftExtractor, extract_normalized_eigenvector
+    meta, a = load_golden('g4_salsa_lite')
+    clips = {k: golden_clip(*v) for k, v in meta['clips'].items()}
+    cfg, feat_dir = _make_tree(str(tmp_path), 'mic', clips, 2000)
+    lite_features.extract_features(data_config=cfg, feature_type='salsa_lite', batch_size=3)
+    for key, ref in a.items():
+        parts = key.split('|')
+        got = sio.load_arrays(os.path.join(feat_dir, *parts[:-1]))[parts[-1]]
+        if parts[-1] == 'feature':
+            _check_lite(got, ref)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+    # numpy-in / numpy-out functions with the reference's signatures
+    meta, g = load_golden('g1_eigvec_s1')
+    X = synth_stft_block(1, meta['n_bins'], meta['n_frames'], kind=meta['kind'])
+    out = extract_normalized_eigenvector(X.astype(complex), 5.0, 3, True, 'mic', fs=24000, n_fft=512, lower_bin=1)
+    np.testing.assert_allclose(out, g['mic_track'], rtol=1e-8, atol=1e-9)
+    y = synth_clip(5, 12000)
+    ex = MagStftExtractor(n_fft=512, hop_length=300, win_length=512)
+    assert ex.W.shape == (200, 257)
+    assert ex.extract(y[:3]).shape == (3, 41, 200)                          # any channel count, like the reference

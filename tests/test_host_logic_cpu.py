@@ -1,0 +1,54 @@
+"""CPU tests of the host-side logic around the hot path (file naming, WAV reading, feature containers, CLI flags,
+error behaviour without a GPU).  No compute calls."""
+import os
+
+import numpy as np
+import pytest
+
+from salsa_amd import io as sio
+
+
+def test_feature_name_follows_reference_replace_quirk():
+    from salsa_amd.features import feature_name
+    assert feature_name('fold1_room1_mix001.wav') == 'fold1_room1_mix001.h5'
+    assert feature_name('wavy_clip.wav') == 'h5y_clip.h5'          # reference: audio_fn.replace('wav','h5') (:379)
+    assert feature_name('clip.npy') == 'clip.h5'
+
+
+def test_wav_reader_matches_float_and_int16_conventions(tmp_path):
+    from scipy.io import wavfile
+    rng = np.random.RandomState(0)
+    x = (rng.uniform(-1, 1, (4, 1000)) * 0.5).astype(np.float32)
+    wavfile.write(tmp_path / 'f32.wav', 24000, x.T)
+    assert np.array_equal(sio.load_audio(str(tmp_path / 'f32.wav'), 24000), x)
+    i16 = (x * 32767).astype(np.int16)
+    wavfile.write(tmp_path / 'i16.wav', 24000, i16.T)
+    np.testing.assert_array_equal(sio.load_audio(str(tmp_path / 'i16.wav'), 24000), i16.astype(np.float32) / 32768.0)
+    with pytest.raises(ValueError):
+        sio.load_audio(str(tmp_path / 'f32.wav'), 48000)
+
+
+def test_feature_container_roundtrip(tmp_path):
+    f = np.random.RandomState(1).randn(7, 5, 200).astype(np.float32)
+    written = sio.save_arrays(str(tmp_path / 'a.h5'), feature=f)
+    assert os.path.exists(written)
+    assert np.array_equal(sio.load_arrays(str(tmp_path / 'a.h5'))['feature'], f)
+    assert sio.feature_files(str(tmp_path)) == [os.path.basename(written)]
+
+
+def test_cli_flag_parsing():
+    from salsa_amd.features import _cli
+    got = {}
+    _cli(lambda **kw: got.update(kw), ['--data_config=x.yml', '--cond_num=5', '--is_tracking=False', '--task=feature'])
+    assert got == {'data_config': 'x.yml', 'cond_num': 5, 'is_tracking': False, 'task': 'feature'}
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from salsa_amd.features import extract_normalized_eigenvector
+    with pytest.raises(RuntimeError):
+        extract_normalized_eigenvector(np.zeros((2, 8, 4), np.complex64))
+    with pytest.raises(ValueError):
+        extract_normalized_eigenvector(np.zeros((2, 8, 4), np.complex64), audio_format='xyz')
