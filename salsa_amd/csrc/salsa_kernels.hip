@@ -70,19 +70,22 @@ constexpr int FEATURE_LOGSPEC_ONLY = 3;
 //
 // Work item of ONE WAVE = one packed N-point complex FFT z = w*(y_c0 + i*y_c1) of a channel pair of one frame:
 // 64 lanes x R points, Stockham radix-R passes exchanged through a wave-private LDS buffer (no workgroup barrier:
-// the LDS serves a wave's DS instructions in order, so a wave-level scheduling fence is all the passes need), then
-// the unpack of the pair's two spectra X_c0, X_c1 (they depend on this transform only), rounded to float32 like the
-// reference's complex64 STFT, and straight from registers: 10*log10 of the power into output channels c0, c1 and
-// the DOA band of both channels as ONE float4 per bin into the spill.  A wave walks K1_NF consecutive frames x 2
-// pairs and prefetches the next item's samples while the current transform runs.  Twiddles and the window live in
-// registers for the whole walk.
+// the LDS serves a wave's DS instructions in order, so a wave-level scheduling fence is all the passes need).
+// LDS element e lives at slot e ^ ((e>>3)&7): with 16-byte complex-float64 elements this XOR swizzle makes every
+// pass's stride-R scatter (ds_write_b128, 8-lane groups) AND the unit-stride gather (ds_read_b128, its odd 16-lane
+// groups) bank-conflict free without padding.  After the last pass lane L holds Z[L + 64 r] in registers, which is
+// exactly the ownership the unpack wants: X_c0[k], X_c1[k] need Z[k] and Z[N-k], and Z[N-k] of k = L + 64 r sits in
+// register R-1-r of lane 64-L, so the mirror is fetched with cross-lane shuffles (R/2 complex values) instead of a
+// third trip through LDS.  The spectra are rounded to float32 like the reference's complex64 STFT and used straight
+// from registers: 10*log10 of the power into output channels c0, c1 and the DOA band of both channels as ONE float4
+// per bin into the spill.  A wave walks K1_NF consecutive frames x 2 pairs and prefetches the next item's samples
+// while the current transform runs.  Twiddles and the window live in registers for the whole walk.
 template <int N> struct fft_cfg {
     static constexpr int R = (N == 512) ? 8 : 4;                 // points per lane; 64 lanes per transform either way
-    static constexpr int PADN = N + N / 8;                       // one pad slot every 8: the stride-R scatter of 16-B elements is conflict-free
     static constexpr int NP = (N == 512) ? 2 : 3;                // twiddled passes (p = R, R^2, ...)
 };
 
-__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+__device__ __forceinline__ int swz(int e) { return e ^ ((e >> 3) & 7); }
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -93,35 +96,42 @@ __device__ __forceinline__ void wave_lds_fence()
 
 __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
+#ifndef K1_TW_REGS
+#define K1_TW_REGS 0
+#endif
+#ifndef K1_PREFETCH
+#define K1_PREFETCH 0 // measured: 162 VGPRs / 3 waves per SIMD without the prefetch beats 180 / 2 with it
+#endif
+#ifndef K1_MINWAVES
+#define K1_MINWAVES 1
+#endif
 constexpr int K1_NF = 8;                                          // frames per wave
 constexpr int K1_FRAMES_PER_BLOCK = 4 * K1_NF;
 
-template <int N, typename T>
-__global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+template <int N, typename T, bool LITE>
+__global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
 {
     constexpr int R = fft_cfg<N>::R;
-    constexpr int PADN = fft_cfg<N>::PADN;
     constexpr int NP = fft_cfg<N>::NP;
     constexpr int NB = N / 2 + 1;
-    __shared__ cplx<T> buf[4][PADN];
-    __shared__ float pw[4][2][64];     // powers of the compressed band (<= 63 bins) of the wave's two channels
-    __shared__ float2 x0s[4][NB];      // SALSA-Lite: channel-0 spectrum of the frame, kept for pair 1
+    __shared__ cplx<T> buf[4][N];
+    __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
+    __shared__ float2 x0s[LITE ? 4 : 1][LITE ? NB : 1]; // SALSA-Lite: channel-0 spectrum of the frame, kept for pair 1
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int Ns = kp.N, Tn = kp.T;
     const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
-    if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
     cplx<T> *z = buf[w];
-    const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
 
+#if K1_TW_REGS
     T win[R];
-    cplx<T> twr[NP][R - 1];
 #pragma unroll
     for (int r = 0; r < R; r++) win[r] = (T)(0.5 * window[salsa::stockham_in(lane, r, N, R)]); // 0.5: the unpack's /2, exact
+    cplx<T> twr[NP][R - 1];
     {
         int p = R;
 #pragma unroll
@@ -132,76 +142,132 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 twr[q][r - 1] = {(T)wd.re, (T)wd.im};
             }
     }
-
+#else
+    // Register diet (occupancy): only the first twiddle of each pass stays in registers, its powers are rebuilt by a
+    // multiplication chain of depth <= 3 (relative error ~4e-16, invisible after the float32 rounding of the spectra);
+    // the window (pre-scaled by the unpack's exact 1/2) is shared by the block's waves through LDS.
+    __shared__ T wins[N];
+    for (int i = threadIdx.x; i < N; i += 256) wins[i] = (T)(0.5 * window[i]);
+    __syncthreads(); // the only workgroup barrier, before any wave-uniform exit
+    cplx<T> w1[NP];
+    {
+        int p = R;
+#pragma unroll
+        for (int q = 0; q < NP; q++, p *= R) {
+            const cplx<double> wd = tw[salsa::stockham_tw(lane, 1, p, N, R)];
+            w1[q] = {(T)wd.re, (T)wd.im};
+        }
+    }
+#endif
+    if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
     const float *clip = audio + (long)b * 4 * Ns;
+    // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
+    // path -- no per-load branching; frames that overlap a clip end take the reflect path (np.pad(mode='reflect'); one
+    // fold suffices because Ns > N/2, checked on the host).
+    const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
+    const int sstride = planar ? 1 : 4;
     auto load_item = [&](int item, float *y0, float *y1) {
         const int t = t_begin + (item >> 1);
         const int c0 = 2 * (item & 1);
         const int base = t * kp.hop - N / 2;
-        const bool interior = base >= 0 && base + N <= Ns;
+        const float *p0 = clip + (planar ? c0 * Ns : c0);
+        const float *p1 = p0 + (planar ? Ns : 1);
+        if (base >= 0 && base + N <= Ns) {
+            const float *q0 = p0 + (base + lane) * sstride, *q1 = p1 + (base + lane) * sstride;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int s = base + salsa::stockham_in(lane, r, N, R);
-            if (!interior) { // np.pad(mode='reflect'); one fold suffices because Ns > N/2 (checked on the host)
-                if (s < 0) s = -s;
-                else if (s >= Ns) s = 2 * (Ns - 1) - s;
+            for (int r = 0; r < R; r++) {
+                y0[r] = q0[r * (N / R) * sstride];
+                y1[r] = q1[r * (N / R) * sstride];
             }
-            if (kp.layout == SALSA_LAYOUT_PLANAR) {
-                y0[r] = clip[c0 * Ns + s];
-                y1[r] = clip[(c0 + 1) * Ns + s];
-            } else {
-                const float2 yy = *reinterpret_cast<const float2 *>(clip + s * 4 + c0);
-                y0[r] = yy.x;
-                y1[r] = yy.y;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int s = base + salsa::stockham_in(lane, r, N, R);
+                s = s < 0 ? -s : s;
+                s = s >= Ns ? 2 * (Ns - 1) - s : s;
+                y0[r] = p0[s * sstride];
+                y1[r] = p1[s * sstride];
             }
         }
     };
 
     const int nitems = (Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF) * 2;
     float y0[R], y1[R];
+#if K1_PREFETCH
     load_item(0, y0, y1);
+#endif
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
+    const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
 
     for (int item = 0; item < nitems; item++) {
         const int t = t_begin + (item >> 1);
         const int pr = item & 1;
+#if !K1_PREFETCH
+        load_item(item, y0, y1);
+#endif
         cplx<T> v[R];
+#if K1_TW_REGS
 #pragma unroll
         for (int r = 0; r < R; r++) v[r] = {win[r] * (T)y0[r], win[r] * (T)y1[r]};
+#else
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const T wn = wins[salsa::stockham_in(lane, r, N, R)];
+            v[r] = {wn * (T)y0[r], wn * (T)y1[r]};
+        }
+#endif
+#if K1_PREFETCH
         if (item + 1 < nitems) load_item(item + 1, y0, y1); // prefetch: in flight during the passes below
+#endif
         // ---- Stockham passes, in place in the wave-private buffer
         salsa::dftR<R>(v); // pass p = 1 (no twiddles)
-        wave_lds_fence();  // previous item's unpack reads are done before we overwrite z
 #pragma unroll
-        for (int r = 0; r < R; r++) z[padi(salsa::stockham_out(lane, r, 1, R))] = v[r];
+        for (int r = 0; r < R; r++) z[swz(salsa::stockham_out(lane, r, 1, R))] = v[r];
         {
             int p = R;
 #pragma unroll
             for (int q = 0; q < NP; q++, p *= R) {
                 wave_lds_fence();
 #pragma unroll
-                for (int r = 0; r < R; r++) v[r] = z[padi(salsa::stockham_in(lane, r, N, R))];
+                for (int r = 0; r < R; r++) v[r] = z[swz(salsa::stockham_in(lane, r, N, R))];
                 wave_lds_fence();
+#if K1_TW_REGS
 #pragma unroll
                 for (int r = 1; r < R; r++) v[r] = salsa::cmul(v[r], twr[q][r - 1]);
+#else
+                {
+                    const cplx<T> a1 = w1[q], a2 = salsa::cmul(a1, a1), a3 = salsa::cmul(a2, a1);
+                    v[1] = salsa::cmul(v[1], a1);
+                    v[2] = salsa::cmul(v[2], a2);
+                    v[3] = salsa::cmul(v[3], a3);
+                    if (R == 8) {
+                        const cplx<T> a4 = salsa::cmul(a2, a2);
+                        v[4 % R] = salsa::cmul(v[4 % R], a4);
+                        v[5 % R] = salsa::cmul(v[5 % R], salsa::cmul(a4, a1));
+                        v[6 % R] = salsa::cmul(v[6 % R], salsa::cmul(a3, a3));
+                        v[7 % R] = salsa::cmul(v[7 % R], salsa::cmul(a4, a3));
+                    }
+                }
+#endif
                 salsa::dftR<R>(v);
+                if (q + 1 < NP) {
 #pragma unroll
-                for (int r = 0; r < R; r++) z[padi(salsa::stockham_out(lane, r, p, R))] = v[r];
+                    for (int r = 0; r < R; r++) z[swz(salsa::stockham_out(lane, r, p, R))] = v[r];
+                }
             }
         }
-        wave_lds_fence();
+        // lane now holds Z[lane + 64 r] in v[r] (the last pass writes y[i + r*64])
 
-        // ---- unpack this pair's two spectra; lane handles bins k = lane + 64 m (and lane 0 the Nyquist bin)
+        // ---- unpack this pair's two spectra: bins k = lane + 64 r, r < R/2 (+ lane 0: the Nyquist bin)
         const int c0 = 2 * pr;
-        auto unpack_bin = [&](const int k) {
-            const int km = (N - k) & (N - 1);
+        auto emit_bin = [&](const int k, const cplx<T> a, const cplx<T> bm) {
             cplx<T> Xa, Xb;
-            salsa::unpack_pair_prescaled(z[padi(k)], z[padi(km)], Xa, Xb);
+            salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
             const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
             const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
-            if (!lite) {
+            if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
                     xs[(t * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
                 if (k >= 1 && k <= kp.ident) {
@@ -222,7 +288,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                                                                          : kp.delta * (double)(k == 0 ? 1 : k);
                     // pair 0 contributes channel 1 (phase vs channel 0); pair 1 contributes channels 2 and 3
 #pragma unroll
-                    for (int h = (pr == 0 ? 1 : 0); h < 2; h++) {
+                    for (int h = 0; h < 2; h++) {
+                        if (pr == 0 && h == 0) continue;
                         const float2 xc = h == 0 ? xa : xb;
                         float ph = 0.f;
                         if (f < kp.upper) { // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
@@ -238,10 +305,17 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             }
         };
 #pragma unroll
-        for (int mi = 0; mi < N / 128; mi++) unpack_bin(lane + 64 * mi);
-        if (lane == 0) unpack_bin(N / 2);
+        for (int r = 0; r < R / 2; r++) {
+            // mirror of k = lane + 64 r is N-k = (64-lane) + 64 (R-1-r): register R-1-r of lane 64-lane;
+            // lane 0: N - 64 r = 64 (R-r), its own register (R-r) mod R
+            cplx<T> bm = {__shfl(v[R - 1 - r].re, mlane), __shfl(v[R - 1 - r].im, mlane)};
+            if (lane == 0) bm = v[(R - r) & (R - 1)];
+            emit_bin(lane + 64 * r, v[r], bm);
+            __builtin_amdgcn_sched_barrier(0); // one bin at a time: keeps the live set (and the VGPR count) small
+        }
+        if (lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2]);
         // ---- compressed high-frequency rows of W: sum of 8 (last row 7) bins times 1/8
-        if (!lite && kp.compress) {
+        if (!LITE && kp.compress) {
             wave_lds_fence();
             const int ng = kp.F - kp.ident;
             const int h = lane & 1, gi = lane >> 1;
@@ -252,6 +326,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 o[((c0 + h) * Tn + t) * kp.F + kp.ident + gi] = db10(acc);
             }
         }
+        wave_lds_fence(); // this item's LDS reads are done before the next item's first pass overwrites z / pw
     }
 }
 
@@ -261,9 +336,23 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 // bins of one clip: wave 0 runs the recurrence (a ~5-instruction dependent chain per frame) at raised priority, waves
 // 1-7 stay one chunk of TR_CH frames ahead computing mag[t][bin] into an LDS ring, with the loads of the chunk after
 // that already in flight.  Spill layout: Xs[b][t][pair][bin] as float4 (c0.re, c0.im, c1.re, c1.im); channel 0 is the
-// .xy of pair 0.  Output: one 64-bit mask per (clip, chunk, bin), bit i = indicator_sig of frame 64*chunk + i.
+// .xy of pair 0.  Output: valid[b][chunk][group][i] = 64-bit mask of frame 64*chunk+i, bit j = indicator_sig of bin
+// 64*group+j.
 constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
-constexpr int TR_WAVES = 8;     // 1 consumer + 7 producers
+#ifndef TR_WAVES_N
+#define TR_WAVES_N 8
+#endif
+constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
+
+// old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform value `val`.
+// (ROCm 7.2's clang does not expose __builtin_amdgcn_writelane; the data operand written by the preceding v_cmp has no
+// documented VALU->v_writelane hazard, the s_nop is a cheap margin.)
+template <int DUMMY>
+__device__ __forceinline__ int writelane_const(int val, const int lane, int old)
+{
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
+    return old;
+}
 
 template <int COUNT>
 __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, int stride, int c0,
@@ -310,7 +399,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     const int stride = 2 * kp.nd; // float4 elements per frame
     const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
     const int nchunks = (Tn + TR_CH - 1) / TR_CH;
-    constexpr int PER_ALL = TR_CH / TR_WAVES;               // prologue: all 8 waves produce chunk 0
+    constexpr int PER_ALL = TR_CH / TR_WAVES;               // prologue: all waves produce chunk 0
     constexpr int PER_PROD = (TR_CH + TR_WAVES - 2) / (TR_WAVES - 1);
     {
         float2 x[PER_ALL + 2];
@@ -321,8 +410,14 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     const int pfirst = (w - 1) * PER_PROD;
     if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xr);
     __syncthreads();
-    salsa::tracker_state st = {0.0, 3};
-    unsigned long long *vout = valid + (long)b * nchunks * kp.nd + (active ? bin : 0);
+    // Consumer state: noise floor + countdown (salsa_feature_extraction.py:30, :58).  The recurrence is evaluated with
+    // exactly the reference's operations (one float64 multiply by 1.02 / 1.002 / 0.98, the 1e-6 clamp, the two strict
+    // compares), but arranged so the dependent chain per frame is  multiply -> select -> max : both candidate
+    // products are formed before the above/below compare resolves.  indicator_sig is a wave-wide compare mask (bit =
+    // bin) dropped into lane i of a VGPR pair for frame i of the chunk: one coalesced 8-byte store per lane per chunk.
+    double fl = 0.0;
+    int cd = 3;
+    unsigned long long *vout = valid + (((long)b * nchunks) * ngroups + g) * TR_CH + lane; // [b][chunk][group][frame]
     if (w == 0) __builtin_amdgcn_s_setprio(3);
     for (int c = 0; c < nchunks; c++) {
         const double *cur = ring[c & 1];
@@ -331,17 +426,32 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 const int n0 = Tn < 5 ? Tn : 5;
                 double acc = 0.0;
                 for (int t = 0; t < n0; t++) acc += cur[t * 64 + lane];
-                st.floor = 0.5 * (acc / (double)n0);
+                fl = 0.5 * (acc / (double)n0);
             }
-            unsigned long long m = 0;
-            const int nfr = Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH;
-            if (nfr == TR_CH) {
-#pragma unroll 16
-                for (int i = 0; i < TR_CH; i++) m |= (unsigned long long)salsa::tracker_step(st, cur[i * 64 + lane]) << i;
+            int lo = 0, hi = 0;
+            const int nfr = __builtin_amdgcn_readfirstlane(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH); // scalar
+            if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
+#pragma unroll
+                for (int i0 = 0; i0 < TR_CH; i0 += 16) {
+                    double m[16]; // one LDS round trip per 16 frames, not per frame
+#pragma unroll
+                    for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const bool s1 = salsa::tracker_step(fl, cd, m[i]);                // :65-87
+                        const unsigned long long sig = __ballot(s1);                        // bit = lane = bin of this group
+                        lo = writelane_const<0>((int)(unsigned)sig, i0 + i, lo);
+                        hi = writelane_const<0>((int)(unsigned)(sig >> 32), i0 + i, hi);
+                    }
+                }
             } else {
-                for (int i = 0; i < nfr; i++) m |= (unsigned long long)salsa::tracker_step(st, cur[i * 64 + lane]) << i;
+                for (int i = 0; i < nfr; i++) {
+                    const bool s1 = salsa::tracker_step(fl, cd, cur[i * 64 + lane]);
+                    const unsigned long long sig = __ballot(s1);
+                    if (lane == i) { lo = (int)(unsigned)sig; hi = (int)(unsigned)(sig >> 32); }
+                }
             }
-            if (active) vout[c * kp.nd] = m;
+            vout[(long)c * ngroups * TR_CH] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
         } else if (c + 1 < nchunks) {
             float2 xn[PER_PROD + 2];
             if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, xn);
@@ -362,8 +472,11 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 // to F); otherwise write the float64 (3, n_bins, n_frames) array of extract_normalized_eigenvector (+ gate codes).
 constexpr int K3_FT = 16; // frames per tile; divides TR_CH so a tile's gate bits sit in one mask word per bin
 
+#ifndef K3_MINWAVES
+#define K3_MINWAVES 1
+#endif
 template <bool FEAT, int NHOP>
-__global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+__global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned long long *__restrict__ valid,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
@@ -397,15 +510,18 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         // lane = bin (consecutive lanes, consecutive bins); frames outer, so the list is frame-major / bin-minor
         const int bl = tid;
         const bool in = bl < nbc;
-        unsigned long long word = ~0ull;
-        if (in && kp.tracking) {
-            const int nchunks = (Tn + TR_CH - 1) / TR_CH;
-            word = valid[((long)b * nchunks + t0 / TR_CH) * kp.nd + bin0 + bl] >> (t0 % TR_CH);
-        }
+        const int nchunks = (Tn + TR_CH - 1) / TR_CH, ngroups = (kp.nd + 63) / 64;
+        const int bin = bin0 + bl;
+        // gate words of this tile: [chunk][group][frame], bit = bin within its group of 64
+        // (a wave covers exactly one 64-bin group, so the word address is wave-uniform: scalar loads)
+        const int grp = __builtin_amdgcn_readfirstlane(bin >> 6) < ngroups ? __builtin_amdgcn_readfirstlane(bin >> 6) : ngroups - 1;
+        const unsigned long long *vw = valid + (((long)b * nchunks + t0 / TR_CH) * ngroups + grp) * TR_CH + t0 % TR_CH;
         for (int ft = 0; ft < nft; ft++) {
+            const unsigned long long word = kp.tracking ? vw[ft] : ~0ull;
             if (in) {
-                if ((word >> ft) & 1) list[atomicAdd(&count, 1)] = (unsigned short)(ft * 256 + bl); // wave-aggregated: lane order survives
-                else emit(t0 + ft, bin0 + bl, zero3, 0);
+                const bool v = ((word >> (bin & 63)) & 1) != 0;
+                if (v) list[atomicAdd(&count, 1)] = (unsigned short)(ft * 256 + bl); // wave-aggregated: lane order survives
+                else emit(t0 + ft, bin, zero3, 0);
             }
         }
     }
@@ -678,13 +794,13 @@ size_t salsa_workspace_bytes(const salsa_plan *pl, int batch, int64_t n_samples)
 {
     if (!pl || batch <= 0 || n_samples <= 0 || pl->p.feature_type != SALSA_FEATURE_SALSA) return 0;
     const size_t T = 1 + n_samples / pl->p.hop_len;
-    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + align256((size_t)batch * ((T + 63) / 64) * pl->nd * 8) + 256;
+    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + align256((size_t)batch * ((T + 63) / 64) * ((pl->nd + 63) / 64) * 64 * 8) + 256;
 }
 
 size_t salsa_eigvec_workspace_bytes(const salsa_plan *pl, int batch, int n_bins, int64_t n_frames)
 {
     if (!pl || batch <= 0 || n_bins <= 0 || n_frames <= 0) return 0;
-    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + align256((size_t)batch * ((n_frames + 63) / 64) * n_bins * 8) + 256;
+    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + align256((size_t)batch * ((n_frames + 63) / 64) * ((n_bins + 63) / 64) * 64 * 8) + 256;
 }
 
 static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
@@ -732,10 +848,14 @@ static void mark_end(salsa_plan *pl, hipStream_t s, int i)
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
     dim3 grid((unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK), (unsigned)kp.B);
-    if (pl->p.n_fft == 512)
-        hipLaunchKernelGGL((stft_kernel<512, double>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
-    else
-        hipLaunchKernelGGL((stft_kernel<256, double>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
+    if (pl->p.n_fft == 512) {
+        if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<512, double, false>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    } else {
+        if (lite) hipLaunchKernelGGL((stft_kernel<256, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<256, double, false>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    }
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }
@@ -773,7 +893,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         const float *a = d_audio + (size_t)g0 * 4 * kp.N;
         float *o = d_out + (size_t)g0 * 7 * T * kp.F;
         float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
-        unsigned long long *vm = valid ? valid + (size_t)g0 * nchunks * kp.nd : nullptr;
+        unsigned long long *vm = valid ? valid + (size_t)g0 * nchunks * ((kp.nd + 63) / 64) * 64 : nullptr;
         int m = mark_begin(pl, s1, "stft_logspec");
         int rc = launch_stft(pl, gp, a, o, xs, s1);
         mark_end(pl, s1, m);

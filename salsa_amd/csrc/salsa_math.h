@@ -305,19 +305,26 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     for (int i = 0; i < 4; i++) A.d[i] = R.d[i] * sc;
 #pragma unroll
     for (int k = 0; k < 6; k++) A.o[k] = {R.o[k].re * sc, R.o[k].im * sc};
-    const minors4<T> m = herm4_minors(A);
     T nrm = 0; // sum |a_ij|^2, i<j
 #pragma unroll
     for (int k = 0; k < 6; k++) nrm += A.o[k].re * A.o[k].re + A.o[k].im * A.o[k].im;
     const T e1 = A.d[0] + A.d[1] + A.d[2] + A.d[3];
     const T e2 = A.d[0] * A.d[1] + A.d[0] * A.d[2] + A.d[0] * A.d[3] + A.d[1] * A.d[2] + A.d[1] * A.d[3] + A.d[2] * A.d[3] - nrm;
+    const T p2 = e1 * e1 - (T)2 * e2;             // tr(A^2) = sum mu_i^2 >= mu1^2
+    if (!need_vector_always && cond > (T)1) {
+        // Cheap certain-fail test before any minor is formed.  For a PSD spectrum with mu1 > cond*mu2 (>= cond*mu3,4)
+        // and sum mu = e1, sum mu^2 is smallest at mu = e1*(cond,1,1,1)/(cond+3), i.e. tr(A^2) >= (cond^2+3)/(cond+3)^2
+        // * e1^2.  Anything below that bound cannot pass the coherence test (flat, noise-like covariances).
+        const T bound = (cond * cond + (T)3) / ((cond + (T)3) * (cond + (T)3));
+        if (p2 < bound * e1 * e1 * (T)(1.0 - 1e-9)) return res;
+    }
+    const minors4<T> m = herm4_minors(A);
     T dg[4];
     herm4_adj_diag(A, m, dg);
     const T e3 = dg[0] + dg[1] + dg[2] + dg[3];
     // det = s0 c5 - s1 c4 + s2 c3 + s3 c2 - s4 c1 + s5 c0 (real for Hermitian A)
     const T e4 = m.s0 * m.c5 - re_mul(m.s1, m.c4) + re_mul(m.s2, m.c3) + re_mul(m.s3, m.c2) - re_mul(m.s4, m.c1) + re_mul(m.s5, m.c0);
     const T a3 = -e1, a2 = e2, a1 = -e3, a0 = e4; // q(x) = x^4 + a3 x^3 + a2 x^2 + a1 x + a0
-    const T p2 = e1 * e1 - (T)2 * e2;             // tr(A^2) >= mu1^2
     T x = p2 * (T)approx_rsqrt((double)p2) * (T)(1.0 + 1.0 / 1048576.0); // just above sqrt(p2)
     if (!(x < e1)) x = e1;
     for (int it = 0; it < 64; it++) {
@@ -428,23 +435,22 @@ SALSA_HD int stockham_out(int i, int r, int p, int R) { int k = i & (p - 1); ret
 
 // ---------------------------------------------------------------------------------------------------------------
 // Noise-floor tracker step (salsa_feature_extraction.py:65-87).  Returns indicator_sig.
-struct tracker_state {
-    double floor;
-    int countdown;
-};
-
-SALSA_HD bool tracker_step(tracker_state &s, double mag)
+// Written so the dependent chain per frame is  multiply -> select -> max : both candidate products are formed before
+// the above/below compare resolves.  Same operations and constants as the reference: floor_up = 1+alpha,
+// floor_up_slow = 1+slow_scale*alpha, floor_down = 1-alpha (:31-35); "countdown -= 1; negative = countdown < 0" (:68-69)
+// is (cd < 1) on the value before the decrement; the 1e-6 clamp (:85) is an fmax (the floor is never NaN).
+SALSA_HD bool tracker_step(double &floor, int &countdown, double mag)
 {
-    const double floor_up = 1 + 0.02, floor_up_slow = 1 + 0.1 * 0.02, floor_down = 1 - 0.02, snr_ratio = 1.5;
-    if (mag > s.floor) {
-        s.countdown -= 1;
-        s.floor = (s.countdown < 0 ? floor_up_slow : floor_up) * s.floor;
-    } else {
-        s.countdown = 3;
-        s.floor = floor_down * s.floor;
-    }
-    if (s.floor < 1e-6) s.floor = 1e-6;
-    return mag > snr_ratio * s.floor;
+    const double up = (countdown < 1) ? 1.0 + 0.1 * 0.02 : 1.0 + 0.02;
+    double pa = up * floor, pb = (1.0 - 0.02) * floor;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(pa), "+v"(pb)); // keep TWO products: the compiler would otherwise select the factor first and
+                                           // put compare -> select -> multiply back on the dependent chain
+#endif
+    const bool above = mag > floor;
+    countdown = above ? countdown - 1 : 3;
+    floor = fmax(above ? pa : pb, 1e-6);
+    return mag > 1.5 * floor;
 }
 
 } // namespace salsa

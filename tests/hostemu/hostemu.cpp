@@ -82,9 +82,10 @@ int hostemu_eigvec(const float *X, int nb, long nt, double cond, int n_hop, int 
         long n0 = nt < 5 ? nt : 5;
         double acc = 0;
         for (long t = 0; t < n0; t++) acc += mag(t);
-        tracker_state st = {0.5 * (acc / (double)n0), 3};
+        double fl = 0.5 * (acc / (double)n0);
+        int cd = 3;
         for (long t = 0; t < nt; t++) {
-            bool sig = tracker_step(st, mag(t));
+            bool sig = tracker_step(fl, cd, mag(t));
             rank[(size_t)b * nt + t] = 0;
             if (tracking && !sig) continue;
             herm4<double> R = {};
