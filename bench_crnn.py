@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""bench_crnn.py -- secondary bench (BASELINE.json config 3/4): SELD CRNN training throughput on N MI355X.
+
+A step = forward + loss + backward + Adam update on a batch of 32 synthetic 8-s SALSA chunks (7,640,200) per GPU, bf16
+autocast, channels-last; data-parallel ranks all-reduce gradients over RCCL (DDP, overlapped with backward).
+--on-the-fly adds the feature extraction in front of every step (config 4: SALSA-MIC from raw 8-s audio on device).
+Prints ONE JSON line on rank 0.  (The headline bench of this repo is bench.py: the feature path.)
+
+  python bench_crnn.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_crnn.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md
+GFLOP_PER_CHUNK_FWD = 44.74 + 0.19       # conv + GRU forward per 8-s chunk (probed)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='chunks per GPU per step')
+    ap.add_argument('--on-the-fly', action='store_true', help='extract SALSA-MIC features from raw audio every step')
+    ap.add_argument('--fp32-grads', action='store_true', help='all-reduce fp32 gradients instead of bf16-compressed')
+    args = ap.parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+
+    import torch
+    import torch.distributed as dist
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+
+    assert torch.cuda.is_available(), 'bench_crnn.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    tr = Trainer(dev, bf16_grad_allreduce=not args.fp32_grads)
+    x, sed, doa = synthetic_batch(args.batch, dev, seed=2021 + rank)
+    ex, audio = None, None
+    if args.on_the_fly:
+        from salsa_amd.extractor import SalsaExtractor
+        ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
+        audio = 0.1 * torch.randn(args.batch, 4, 8 * 24000, device=dev, generator=torch.Generator(dev).manual_seed(rank))
+
+    def step():
+        xb = x
+        if ex is not None:
+            xb = ex.extract(audio)[:, :, :640]                      # (B,7,641,200) -> 640 frames
+        return tr.train_step(xb, sed, doa)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    clips = world * args.batch * args.steps
+    cps = clips / elapsed
+    tflops = 3 * GFLOP_PER_CHUNK_FWD * cps / 1e3                     # fwd + bwd ~ 3x forward
+    print(json.dumps({
+        'metric': 'CRNN train clips/s', 'value': round(cps, 1), 'unit': '8-s chunks/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,640,200), batch %d per GPU, Adam'
+                               % ('on-the-fly extracted MIC' if args.on_the_fly else 'precomputed-FOA-shaped', args.batch),
+                   'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if args.fp32_grads else 'bf16'},
+        'roofline': {'bound': 'mfma', 'achieved': round(tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                     'note': '134.8 GFLOP per chunk (3x the 44.93 GFLOP forward); convs run in MIOpen via torch'},
+        'final_loss': float(loss)}))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,153 @@
+"""SELD CRNN with the reference's architecture and initialisation (models/encoders.py:26-56 PannResNet22,
+models/model_utils.py:187-228 ConvBlock, :312-367 basic block, :429-500 ResNet, models/decoders.py:13-154 SeldDecoder
+with decoder_type='bigru', freq_pool='avg', decoder_size=256 -- experiments/configs/seld.yml:25-32).
+
+Shapes for an 8-s training chunk (7,640,200): stem (64,320,100) -> stage1 (64,320,100) -> stage2 (128,160,50) ->
+stage3 (256,80,25) -> stage4 (512,40,12) -> mean over frequency (40,512) -> BiGRU (40,512) -> SED logits (40,12) and
+xyz (40,36).  14.11 M parameters (11.21 M encoder + 2.90 M decoder)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _xavier(layer):
+    nn.init.xavier_uniform_(layer.weight)
+    if getattr(layer, 'bias', None) is not None:
+        layer.bias.data.zero_()
+    return layer
+
+
+def _conv(cin, cout, k):
+    return _xavier(nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=k // 2, bias=False))
+
+
+class Stem(nn.Module):
+    """two 3x3 conv + BN + ReLU, then 2x2 average pool (model_utils.py:187-228 with pool_type='avg')"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(cin, cout, 3), nn.BatchNorm2d(cout)
+        self.conv2, self.bn2 = _conv(cout, cout, 3), nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
+        return F.avg_pool2d(x, 2)
+
+
+class ResBlock(nn.Module):
+    """basic residual block; stride 2 is an average pool followed by stride-1 convs; dropout 0.1 after the first ReLU;
+    the last BN starts at zero (zero_init_residual) -- model_utils.py:312-367."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.stride = stride
+        self.conv1, self.bn1 = _conv(cin, cout, 3), nn.BatchNorm2d(cout)
+        self.conv2, self.bn2 = _conv(cout, cout, 3), nn.BatchNorm2d(cout)
+        nn.init.zeros_(self.bn2.weight)
+        self.short_conv, self.short_bn = None, None
+        if stride != 1 or cin != cout:                      # 1x1 conv + BN shortcut (after the pool when strided)
+            self.short_conv, self.short_bn = _conv(cin, cout, 1), nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        y = F.avg_pool2d(x, 2) if self.stride == 2 else x
+        out = F.relu(self.bn1(self.conv1(y)), inplace=True)
+        out = F.dropout(out, p=0.1, training=self.training)
+        out = self.bn2(self.conv2(out))
+        if self.short_conv is not None:
+            x = self.short_bn(self.short_conv(y))
+        return F.relu(out + x, inplace=True)
+
+
+class Encoder(nn.Module):
+    """PANN ResNet22-style: stem + 4 stages x 2 blocks (64/128/256/512); time and frequency /16 (encoders.py:26-56)."""
+    time_downsample_ratio = 16
+    n_output_channels = 512
+
+    def __init__(self, n_input_channels=7, p_dropout=0.0):
+        super().__init__()
+        self.p_dropout = p_dropout
+        self.stem = Stem(n_input_channels, 64)
+        blocks, cin = [], 64
+        for cout, stride in ((64, 1), (128, 2), (256, 2), (512, 2)):
+            blocks += [ResBlock(cin, cout, stride), ResBlock(cout, cout, 1)]
+            cin = cout
+        self.stages = nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.stem(x)
+        x = F.dropout(x, p=self.p_dropout, training=self.training)
+        return self.stages(x)
+
+
+def _init_gru(rnn):
+    """reference init (model_utils.py:156-184): per-gate uniform(+-sqrt(3/fan_in)) for W_ih and the r,z blocks of W_hh,
+    orthogonal for the n block of W_hh, zero biases."""
+    def uni(t):
+        b = math.sqrt(3.0 / t.shape[1])
+        nn.init.uniform_(t, -b, b)
+
+    for name, p in rnn.named_parameters():
+        if 'bias' in name:
+            nn.init.zeros_(p)
+            continue
+        h = p.shape[0] // 3
+        with torch.no_grad():
+            for g in range(3):
+                blk = p[g * h:(g + 1) * h]
+                if 'weight_hh' in name and g == 2:
+                    nn.init.orthogonal_(blk)
+                else:
+                    uni(blk)
+
+
+class Head(nn.Module):
+    def __init__(self, d, n_out):
+        super().__init__()
+        self.fc1, self.fc2 = _xavier(nn.Linear(d, d // 2)), _xavier(nn.Linear(d // 2, n_out))
+        self.drop1, self.drop2 = nn.Dropout(0.2), nn.Dropout(0.2)
+
+    def forward(self, x):
+        return self.fc2(self.drop2(F.relu(self.fc1(self.drop1(x)), inplace=True)))
+
+
+class Decoder(nn.Module):
+    """mean over frequency -> 2-layer BiGRU(256) with dropout 0.3 -> SED head + x/y/z heads (decoders.py:13-154)."""
+
+    def __init__(self, n_in=512, n_classes=12, size=256):
+        super().__init__()
+        self.n_classes = n_classes
+        self.gru = nn.GRU(n_in, size, num_layers=2, batch_first=True, bidirectional=True, dropout=0.3)
+        _init_gru(self.gru)
+        self.event = Head(2 * size, n_classes)
+        self.x, self.y, self.z = Head(2 * size, n_classes), Head(2 * size, n_classes), Head(2 * size, n_classes)
+
+    def forward(self, feat):
+        seq = feat.mean(dim=3).transpose(1, 2)                  # (B, T', 512)
+        seq, _ = self.gru(seq)
+        doa = torch.cat([torch.tanh(self.x(seq)), torch.tanh(self.y(seq)), torch.tanh(self.z(seq))], dim=-1)
+        return {'event_frame_logit': self.event(seq), 'doa_frame_output': doa}
+
+
+def interpolate_tensor(t, ratio: float):
+    """nearest-index resampling along time (model_utils.py:57-75): out[j] = in[floor(j / ratio)]."""
+    n_out = int(round(t.shape[1] * float(ratio)))
+    idx = torch.floor(torch.arange(n_out, device=t.device) / float(ratio)).long()
+    return t[:, idx]
+
+
+class SeldCRNN(nn.Module):
+    """forward(x (B,7,T,200)) -> dict at the LABEL rate (seld_models.py:39-66: encoder, decoder, then
+    interpolate by time_downsample_ratio * label_rate / feature_rate = 16 * 10 / 80 = 2)."""
+
+    def __init__(self, n_input_channels=7, n_classes=12, label_rate=10, feature_rate=80):
+        super().__init__()
+        self.encoder = Encoder(n_input_channels)
+        self.decoder = Decoder(self.encoder.n_output_channels, n_classes)
+        self.ratio = self.encoder.time_downsample_ratio * label_rate / feature_rate
+
+    def forward(self, x):
+        out = self.decoder(self.encoder(x))
+        return {k: interpolate_tensor(v, self.ratio) for k, v in out.items()}

@@ -1,0 +1,103 @@
+"""CPU tests of the CRNN consumer: parameter counts and forward outputs against the REFERENCE model (fixture g9,
+tools/make_golden_crnn.py), loss against an independent numpy statement of models/interfaces.py:304-355, the
+learning-rate schedule, and a world-size-2 gloo DDP step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def test_parameter_counts_match_reference():
+    from salsa_amd.crnn import SeldCRNN
+    m = SeldCRNN()
+    assert sum(p.numel() for p in m.encoder.parameters()) == 11208128
+    assert sum(p.numel() for p in m.decoder.parameters()) == 2903088
+
+
+def test_forward_matches_reference_model():
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn.testing import seeded_fill
+    meta, a = load_golden('g9_crnn')
+    m = SeldCRNN()
+    seeded_fill(m, meta['weight_seed'])
+    m.eval()
+    x = torch.randn(*meta['input_shape'], generator=torch.Generator().manual_seed(meta['input_seed']))
+    with torch.no_grad():
+        out = m(x)
+    np.testing.assert_allclose(out['event_frame_logit'].numpy(), a['event_frame_logit'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['doa_frame_output'].numpy(), a['doa_frame_output'], rtol=1e-4, atol=1e-5)
+    assert out['event_frame_logit'].shape == (2, 8, 12)              # 64 frames -> /16 -> x2 (label rate)
+
+
+def test_training_chunk_shapes():
+    from salsa_amd.crnn import SeldCRNN
+    m = SeldCRNN().eval()
+    with torch.no_grad():
+        out = m(torch.zeros(1, 7, 640, 200))
+    assert out['event_frame_logit'].shape == (1, 80, 12) and out['doa_frame_output'].shape == (1, 80, 36)
+
+
+def test_loss_matches_numpy_statement():
+    from salsa_amd.crnn import seld_loss
+    g = torch.Generator().manual_seed(3)
+    logit, doa = torch.randn(3, 80, 12, generator=g), torch.tanh(torch.randn(3, 80, 36, generator=g))
+    sed = (torch.rand(3, 80, 12, generator=g) < 0.2).float()
+    gt = torch.randn(3, 80, 36, generator=g)
+    loss, s, d = seld_loss({'event_frame_logit': logit, 'doa_frame_output': doa}, sed, gt)
+    z, y = logit.numpy().astype(np.float64), sed.numpy().astype(np.float64)
+    bce = np.mean(np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z))))
+    mae = sum((np.abs(doa.numpy()[..., i * 12:(i + 1) * 12] - gt.numpy()[..., i * 12:(i + 1) * 12]) * y).sum() / y.sum()
+              for i in range(3))
+    assert abs(float(s) - bce) < 1e-5 and abs(float(d) - mae) < 1e-4
+    assert abs(float(loss) - (0.3 * bce + 0.7 * mae)) < 1e-4
+
+
+def test_lr_schedule_and_interpolate():
+    from salsa_amd.crnn import interpolate_tensor
+    from salsa_amd.crnn.train import lr_at
+    assert lr_at(0.0) == lr_at(0.5) == pytest.approx(3e-4)
+    assert lr_at(0.85) == pytest.approx(2e-4) and lr_at(1.0) == pytest.approx(1e-4)
+    t = torch.arange(5.0)[None, :, None]
+    assert interpolate_tensor(t, 2.0)[0, :, 0].tolist() == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+    assert interpolate_tensor(t, 0.4)[0, :, 0].tolist() == [0, 2]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = Trainer('cpu', amp_dtype=None, total_steps=10)
+    before = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()]).clone()
+    x, sed, doa = synthetic_batch(2, 'cpu', seed=100 + rank, n_frames=64)       # different data per rank
+    loss, _, _ = tr.train_step(x, sed, doa)
+    after = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()])
+    torch.save({'after': after, 'moved': float((after - before).abs().max()), 'loss': float(loss)},
+               os.path.join(tmp, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_step_keeps_replicas_identical(tmp_path):
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
+    assert r0['moved'] > 0 and np.isfinite(r0['loss']) and np.isfinite(r1['loss'])
+    assert r0['loss'] != r1['loss']                                   # ranks saw different chunks ...
+    assert torch.equal(r0['after'], r1['after'])                      # ... but the all-reduced update is identical
