@@ -14,6 +14,8 @@
  *   extract_normalized_eigenvector, dataset/salsa_feature_extraction.py:17-129    salsa_eigvec_batch
  *   bin limits / freq_dim, dataset/salsa_feature_extraction.py:298-313 (+ lite :50-59)  salsa_bin_limits, salsa_output_shape
  *   MagStftExtractor.W, dataset/salsa_feature_extraction.py:152-175               salsa_compress_matrix (host)
+ *   compute_scaler, dataset/salsa_feature_extraction.py:204-262                   salsa_scaler_accumulate
+ *   Database.load_chunk_data normalisation, dataset/database.py:197-202           salsa_normalize_batch
  *
  * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
  * message of the calling thread's last failure.  Device pointers are caller-owned; work is enqueued asynchronously
@@ -97,6 +99,16 @@ size_t salsa_eigvec_workspace_bytes(const salsa_plan *plan, int batch, int n_bin
 int salsa_eigvec_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
                        double *d_out, unsigned char *d_gate, void *d_workspace, size_t workspace_bytes,
                        void *hip_stream);
+
+/* compute_scaler (salsa_feature_extraction.py:204-262) on device: accumulate float64 sum / sum-of-squares over time of
+ * the first n_scaler_channels channels per frequency into d_sums [2][n_scaler_channels][n_freq] (zeroed by the caller
+ * once; mean = sum/n, std = sqrt(sumsq/n - mean^2), population variance like sklearn's StandardScaler).  n_freq <= 256. */
+int salsa_scaler_accumulate(const float *d_feat, int batch, int n_channels, int64_t n_frames, int n_freq,
+                            int n_scaler_channels, double *d_sums, void *hip_stream);
+/* normalise-on-load (dataset/database.py:197-202): d_feat[:, :n_scaler_channels] = (x - mean) / std in place;
+ * d_mean / d_std float32 [n_scaler_channels][n_freq] (the scaler file's (4,1,F) arrays). */
+int salsa_normalize_batch(float *d_feat, int batch, int n_channels, int64_t n_frames, int n_freq, int n_scaler_channels,
+                          const float *d_mean, const float *d_std, void *hip_stream);
 
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
  * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the

@@ -56,6 +56,8 @@ def load():
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
     L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
+    L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
+    L.salsa_normalize_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp]
     _lib = L
     return L
 
@@ -67,4 +69,4 @@ def last_error() -> str:
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
-           'salsa_plan_read_timing', 'salsa_plan_set_groups']
+           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch']

@@ -609,6 +609,42 @@ __global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict
     Xs[idx] = X[(((long)b * nb + bin) * Tn + t) * 2 + pr];
 }
 
+// ------------------------------------------------------------------------------------------------------------ scaler
+// compute_scaler (:204-262) on device: float64 sum and sum of squares over time of the first n_sc channels, per
+// frequency.  One block per (clip, channel, tile of 64 frames); lane = frequency (coalesced rows); one float64 atomic
+// pair per lane per block.  sums: [2][n_sc][F] (sum, sumsq), accumulated into (caller zeroes it once).
+__global__ __launch_bounds__(256) void scaler_accumulate_kernel(const float *__restrict__ feat, int C, int T, int F,
+                                                                int n_sc, double *__restrict__ sums)
+{
+    const int f = threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int t0 = blockIdx.x * 64, t1 = t0 + 64 < T ? t0 + 64 : T;
+    if (f >= F) return;
+    const float *p = feat + (((long)b * C + c) * T) * F + f;
+    double s = 0.0, ss = 0.0;
+    for (int t = t0; t < t1; t++) {
+        const double v = (double)p[(long)t * F];
+        s += v;
+        ss += v * v;
+    }
+    atomicAdd(&sums[(long)c * F + f], s);
+    atomicAdd(&sums[((long)n_sc + c) * F + f], ss);
+}
+
+// normalise-on-load (dataset/database.py:197-202): feature[:n_sc] = (feature[:n_sc] - mean) / std, in place;
+// mean/std: [n_sc][F] float32.  Channels >= n_sc (the spatial channels) are left untouched.
+__global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ feat, long rows, int C, int T, int F, int n_sc,
+                                                        const float *__restrict__ mean, const float *__restrict__ std)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); // one wave per (b, c, t) row of F floats
+    if (row >= rows) return;
+    const int t = (int)(row % T);
+    const int c = (int)((row / T) % n_sc);
+    const long b = row / ((long)T * n_sc);
+    float *p = feat + ((b * C + c) * T + t) * F;
+    for (int f = threadIdx.x & 63; f < F; f += 64) p[f] = (p[f] - mean[c * F + f]) / std[c * F + f];
+}
+
 } // namespace
 
 // ================================================================================================== plan + C ABI
@@ -1000,6 +1036,33 @@ int salsa_plan_read_timing(salsa_plan *pl, float *ms, const char **names, int *n
         if (names) names[i] = pl->names[i];
     }
     *n_out = pl->n_kernels;
+    return SALSA_OK;
+}
+
+int salsa_scaler_accumulate(const float *d_feat, int batch, int n_channels, int64_t n_frames, int n_freq,
+                            int n_scaler_channels, double *d_sums, void *hip_stream)
+{
+    if (!d_feat || !d_sums || batch <= 0 || n_channels <= 0 || n_frames <= 0 || n_freq <= 0 || n_freq > 256 ||
+        n_scaler_channels <= 0 || n_scaler_channels > n_channels || n_frames >= INT32_MAX)
+        return fail(SALSA_EINVAL, "salsa_scaler_accumulate: bad argument%s");
+    dim3 grid((unsigned)((n_frames + 63) / 64), (unsigned)n_scaler_channels, (unsigned)batch);
+    hipLaunchKernelGGL(scaler_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, d_feat, n_channels,
+                       (int)n_frames, n_freq, n_scaler_channels, d_sums);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_normalize_batch(float *d_feat, int batch, int n_channels, int64_t n_frames, int n_freq, int n_scaler_channels,
+                          const float *d_mean, const float *d_std, void *hip_stream)
+{
+    if (!d_feat || !d_mean || !d_std || batch <= 0 || n_channels <= 0 || n_frames <= 0 || n_freq <= 0 ||
+        n_scaler_channels <= 0 || n_scaler_channels > n_channels || n_frames >= INT32_MAX)
+        return fail(SALSA_EINVAL, "salsa_normalize_batch: bad argument%s");
+    const long rows = (long)batch * n_scaler_channels * n_frames;
+    if ((rows + 3) / 4 >= INT32_MAX) return fail(SALSA_EINVAL, "salsa_normalize_batch: too many rows for one launch%s");
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, d_feat,
+                       rows, n_channels, (int)n_frames, n_freq, n_scaler_channels, d_mean, d_std);
+    HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }
 

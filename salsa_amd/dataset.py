@@ -1,0 +1,108 @@
+"""On-device counterpart of the reference's data layer (dataset/database.py + dataset/dataloader.py) for training
+straight from raw audio (BASELINE.json config 4): clips are extracted on the GPU, kept there in the reference's
+concatenated ``(C, sum T, F)`` layout (database.py:230-231), normalised on load with the scaler (first 4 channels only,
+:197-202) and sliced into chunks with the reference's segment index arithmetic (:98-119).  ``__getitem__`` returns the
+same 4-tuple contract as SeldDataset (dataloader.py:37-62) minus augmentation: (X (7,chunk,F), sed, doa, name).
+
+Nothing here runs in DataLoader worker processes: HIP contexts do not survive fork, so extraction happens on the
+training process' stream (SURVEY.md section 7 'hard parts')."""
+import numpy as np
+import torch
+
+from .extractor import SalsaExtractor, normalize_, scaler_accumulate, scaler_finish
+
+
+def second2frame(second: float, fs: int, hop_len: int) -> int:
+    """database.py:75-81"""
+    return int(round(int(second * fs) / hop_len))
+
+
+def get_segment_idxes(n_frames: int, chunk_len: int, chunk_hop_len: int, downsample_ratio: int, pointer: int):
+    """database.py:98-119 verbatim semantics: chunk start indices (at the segment rate) + the advanced pointer."""
+    assert n_frames % downsample_ratio == 0, 'n_features_frames is not divisible by downsample ratio'
+    n_crop = n_frames // downsample_ratio
+    cl, ch = chunk_len // downsample_ratio, chunk_hop_len // downsample_ratio
+    assert cl <= n_crop, 'Number of cropped frame is less than chunk len'
+    idxes = np.arange(pointer, pointer + n_crop - cl + 1, ch).tolist()
+    if (n_crop - cl) % ch != 0:
+        idxes.append(pointer + n_crop - cl)             # include the leftover of the cropped data
+    return idxes, pointer + n_crop
+
+
+class GpuFeatureBank(torch.utils.data.Dataset):
+    def __init__(self, extractor: SalsaExtractor, fs=24000, hop_len=300, label_rate=10, chunk_len_s=8.0,
+                 chunk_hop_len_s=0.5, n_classes=12, max_clip_s=60):
+        self.ex = extractor
+        self.fs, self.hop_len, self.label_rate, self.n_classes = fs, hop_len, label_rate, n_classes
+        self.chunk_len = second2frame(chunk_len_s, fs, hop_len)
+        self.chunk_hop_len = second2frame(chunk_hop_len_s, fs, hop_len)
+        self.upsample = int((fs / hop_len) / label_rate)                       # feature frames per label frame (8)
+        self.max_frames = int(max_clip_s * label_rate) * self.upsample         # "make sure we have 4800 frames" (:205-207)
+        self.blocks, self.names, self.chunk_idx, self.chunk_name = [], [], [], []
+        self.sed, self.doa, self.gt_idx = [], [], []
+        self.pointer = self.gt_pointer = 0
+        self.features = None
+        self.mean = self.std = None
+        self._sums, self._n = None, 0
+
+    # -------------------------------------------------------------------------------------------- ingest
+    def add_clips(self, audio, names, sed=None, doa=None):
+        """audio: float32 [B,4,N] (numpy or CUDA tensor).  sed/doa: optional per-clip label arrays at label rate,
+        (T_lab, n_classes) and (T_lab, 3*n_classes); absent -> zeros (inference)."""
+        a = audio if torch.is_tensor(audio) else torch.from_numpy(np.ascontiguousarray(audio, np.float32))
+        feats = self.ex.extract(a.to(self.ex.device).contiguous())
+        n_frames = min(feats.shape[2], self.max_frames)
+        n_frames -= n_frames % self.upsample
+        feats = feats[:, :, :n_frames].contiguous()
+        self._sums = scaler_accumulate(feats, self._sums)
+        self._n += feats.shape[0] * n_frames
+        for i, name in enumerate(names):
+            idxes, self.pointer = get_segment_idxes(n_frames, self.chunk_len, self.chunk_hop_len, 1, self.pointer)
+            gidx, self.gt_pointer = get_segment_idxes(n_frames, self.chunk_len, self.chunk_hop_len, self.upsample,
+                                                      self.gt_pointer)
+            assert len(idxes) == len(gidx), 'nchunks for sed and gt are different'
+            self.blocks.append(feats[i])
+            self.names.append(name)
+            self.chunk_idx += idxes
+            self.gt_idx += gidx
+            self.chunk_name += [name] * len(idxes)
+            n_lab = n_frames // self.upsample
+            dev = feats.device
+            self.sed.append(torch.zeros(n_lab, self.n_classes, device=dev) if sed is None
+                            else torch.as_tensor(sed[i][:n_lab], dtype=torch.float32, device=dev))
+            self.doa.append(torch.zeros(n_lab, 3 * self.n_classes, device=dev) if doa is None
+                            else torch.as_tensor(doa[i][:n_lab], dtype=torch.float32, device=dev))
+        self.features = None
+
+    def fit_scaler(self):
+        """scaler over everything ingested so far (the reference fits it on all dev files)."""
+        self.mean, self.std = scaler_finish(self._sums, self._n)
+        return self.mean, self.std
+
+    def set_scaler(self, mean, std):
+        self.mean, self.std = torch.as_tensor(mean), torch.as_tensor(std)
+
+    def finalize(self):
+        """concatenate along time (database.py:230) and normalise the spectrogram channels in place."""
+        assert self.mean is not None, 'call fit_scaler() or set_scaler() first'
+        feats = torch.cat(self.blocks, dim=1).contiguous()                   # (7, sum T, F)
+        normalize_(feats[None], self.mean, self.std)
+        self.features = feats
+        self.sed_all, self.doa_all = torch.cat(self.sed), torch.cat(self.doa)
+        self.blocks = []
+        return self
+
+    # -------------------------------------------------------------------------------------------- Dataset
+    def __len__(self):
+        return len(self.chunk_idx)
+
+    def __getitem__(self, i):
+        assert self.features is not None, 'call finalize() first'
+        s, g = self.chunk_idx[i], self.gt_idx[i]
+        x = self.features[:, s:s + self.chunk_len]
+        n_lab = self.chunk_len // self.upsample
+        return x, self.sed_all[g:g + n_lab], self.doa_all[g:g + n_lab], self.chunk_name[i]
+
+    def batch(self, indices):
+        xs, ss, ds, ns = zip(*(self[i] for i in indices))
+        return torch.stack(xs), torch.stack(ss), torch.stack(ds), list(ns)

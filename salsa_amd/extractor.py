@@ -174,3 +174,36 @@ class SalsaExtractor:
         if rc:
             _raise(rc)
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def scaler_accumulate(feat: torch.Tensor, sums: torch.Tensor = None, n_scaler_channels: int = 4) -> torch.Tensor:
+    """Device-side compute_scaler accumulation: feat float32 CUDA [B,C,T,F] -> sums float64 [2,n_sc,F] (+= in place)."""
+    assert feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 4 and feat.is_contiguous()
+    B, Cn, T, F = feat.shape
+    if sums is None:
+        sums = torch.zeros((2, n_scaler_channels, F), dtype=torch.float64, device=feat.device)
+    rc = _lib.load().salsa_scaler_accumulate(C.c_void_p(feat.data_ptr()), B, Cn, T, F, n_scaler_channels,
+                                             C.c_void_p(sums.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        _raise(rc)
+    return sums
+
+
+def scaler_finish(sums: torch.Tensor, n_frames_total: int):
+    """-> (mean, std) float32 CUDA tensors of shape (n_sc, 1, F), population std (sklearn StandardScaler.var_)."""
+    mean = sums[0] / n_frames_total
+    var = torch.clamp(sums[1] / n_frames_total - mean * mean, min=0.0)
+    return mean[:, None, :].float(), torch.sqrt(var)[:, None, :].float()
+
+
+def normalize_(feat: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """In-place normalise-on-load of the first mean.shape[0] channels (dataset/database.py:197-202)."""
+    assert feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 4 and feat.is_contiguous()
+    B, Cn, T, F = feat.shape
+    m = mean.reshape(-1, F).contiguous().float().to(feat.device)
+    s = std.reshape(-1, F).contiguous().float().to(feat.device)
+    rc = _lib.load().salsa_normalize_batch(C.c_void_p(feat.data_ptr()), B, Cn, T, F, m.shape[0], C.c_void_p(m.data_ptr()),
+                                           C.c_void_p(s.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        _raise(rc)
+    return feat
