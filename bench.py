@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--format', default=None, choices=['foa', 'mic'])
     ap.add_argument('--fmax-doa', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pcie', action='store_true', help='also time host->device->extract->device->host (reported, never `value`)')
     ap.add_argument('--groups', type=int, default=0, help='clip-group pipelining depth (0 = library default)')
     args = ap.parse_args()
 
@@ -122,6 +123,7 @@ def main():
     kernels = []
     roofline = None
     cpu = None
+    pcie = None
     if rank == 0:
         ex.set_timing(True)
         tot, cnt, n_t = {}, {}, max(3, min(args.steps, 10))
@@ -152,6 +154,23 @@ def main():
                                  'frac': round(pipe_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  'note': 'whole step (all kernels, wall clock of the timed region)'},
                     'kernels': kernels}
+        if args.pcie:
+            # boundary note: when the caller hands HOST buffers (the Python surface does), every step also
+            # moves the clips in and the features out over PCIe; pinned memory, async copies on the compute stream
+            hp = torch.from_numpy(host).pin_memory()
+            op = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            for _ in range(2):
+                audio.copy_(hp, non_blocking=True); ex.extract(audio, out=out); op.copy_(out, non_blocking=True)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            n_p = max(3, min(args.steps, 5))
+            for _ in range(n_p):
+                audio.copy_(hp, non_blocking=True); ex.extract(audio, out=out); op.copy_(out, non_blocking=True)
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp) / n_p
+            pcie = {'ms_per_step': round(1e3 * tp, 3), 'audio_s_per_s': round(args.batch * args.seconds / tp, 1),
+                    'bytes_h2d': int(hp.numel() * 4), 'bytes_d2h': int(op.numel() * 4),
+                    'note': 'serial H2D + extract + D2H per step, pinned host memory'}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
 
@@ -184,6 +203,8 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu,
     }
+    if pcie:
+        line['pcie_inclusive'] = pcie
     print(json.dumps(line))
 
 

@@ -22,6 +22,66 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARC
 GFLOP_PER_CHUNK_FWD = 44.74 + 0.19       # conv + GRU forward per 8-s chunk (probed)
 
 
+def infer_bench(args, rank, world, dev, tr):
+    """Batched inference (config 5): per step, `clips` 60-s FOA clips per GPU go raw audio -> SALSA features (HIP) ->
+    normalise-on-load (HIP) -> CRNN forward (bf16) -> SED probabilities + xyz at label rate, all on device.  Clips are
+    sharded over ranks, no collective.  Latency = wall time of one sub-batch of 8 clips end to end."""
+    import torch
+    import torch.distributed as dist
+    from salsa_amd.extractor import SalsaExtractor, normalize_
+    ex = SalsaExtractor(audio_format='foa', fmax_doa=9000, device=dev)
+    g = torch.Generator(dev).manual_seed(rank)
+    audio = 0.1 * torch.randn(args.clips, 4, 60 * 24000, device=dev, generator=g)
+    mean = torch.full((4, 1, 200), -60.0, device=dev)
+    std = torch.full((4, 1, 200), 12.0, device=dev)
+    sub = 8
+    lat = []
+
+    def step(timed=False):
+        outs = []
+        for s0 in range(0, args.clips, sub):
+            if timed:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            f = ex.extract(audio[s0:s0 + sub])[:, :, :4800].contiguous()
+            normalize_(f, mean, std)
+            outs.append(tr.infer(f))
+            if timed:
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+        return outs
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    step(timed=True)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    lat.sort()
+    print(json.dumps({
+        'metric': 'SALSA+CRNN inference clips/s', 'value': round(world * args.clips * args.steps / elapsed, 2),
+        'unit': '60-s clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 (features)', 'data': 'synthetic',
+        'p50_latency_ms_per_8clip_subbatch': round(1e3 * lat[len(lat) // 2], 2),
+        'config': {'workload': 'batched inference: %d x 60-s 4-ch clips per GPU per step, SALSA-FOA + CRNN forward, '
+                               'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -30,6 +90,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='chunks per GPU per step')
     ap.add_argument('--on-the-fly', action='store_true', help='extract SALSA-MIC features from raw audio every step')
     ap.add_argument('--fp32-grads', action='store_true', help='all-reduce fp32 gradients instead of bf16-compressed')
+    ap.add_argument('--infer', action='store_true', help='config 5: batched inference, SALSA + CRNN forward on 60-s clips')
+    ap.add_argument('--clips', type=int, default=32, help='--infer: 60-s clips per GPU per step')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -52,6 +114,9 @@ def main():
         from salsa_amd.extractor import SalsaExtractor
         ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
         audio = 0.1 * torch.randn(args.batch, 4, 8 * 24000, device=dev, generator=torch.Generator(dev).manual_seed(rank))
+
+    if args.infer:
+        return infer_bench(args, rank, world, dev, tr)
 
     def step():
         xb = x

@@ -3,6 +3,8 @@ reference's piecewise-linear learning-rate schedule (utilities/learning_utils.py
 37-52), and data parallelism as one process per GPU with torch DDP = bucketed gradient all-reduce on RCCL over xGMI,
 overlapped with the backward pass (the reference only has Lightning's implicit ddp_spawn, experiments/train.py:98).
 BatchNorm statistics stay per rank, as in the reference (no SyncBN)."""
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -40,11 +42,14 @@ class Trainer:
                  bf16_grad_allreduce: bool = True, seed: int = 2021):
         torch.manual_seed(seed)
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and os.environ.get('SALSA_MIOPEN_FIND', '0') == '1':
+            torch.backends.cudnn.benchmark = True           # MIOpen solver search: measured SLOWER here (701 vs 724 chunks/s), off by default
         self.amp_dtype = amp_dtype
         self.total_steps = total_steps
         self.step_idx = 0
         model = SeldCRNN().to(self.device)
-        if self.device.type == 'cuda':
+        self.channels_last = self.device.type == 'cuda' and os.environ.get('SALSA_CHANNELS_LAST', '1') == '1'
+        if self.channels_last:
             model = model.to(memory_format=torch.channels_last)
         self.raw_model = model
         use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
@@ -63,7 +68,7 @@ class Trainer:
         lr = lr_at(self.step_idx / max(1, self.total_steps))
         for gparam in self.opt.param_groups:
             gparam['lr'] = lr
-        if self.device.type == 'cuda':
+        if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
@@ -78,7 +83,7 @@ class Trainer:
     def infer(self, x):
         """eval forward (bf16 autocast): sigmoid SED probabilities and xyz at label rate (inference path, config 5)."""
         self.model.eval()
-        if self.device.type == 'cuda':
+        if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.raw_model(x)
