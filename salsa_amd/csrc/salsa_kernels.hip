@@ -60,6 +60,7 @@ struct KParams {
     int tracking;
     int n_hop;
     double cond;
+    double inv_cond;      // 1/cond (0 when cond == 0: unused, cond <= 1 short-circuits the gate)
     double delta;         // 2 pi fs / (n_fft * 343)
 };
 
@@ -470,7 +471,10 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 // (lane order preserved, so neighbouring lanes still read neighbouring bins), writes zeros for the rest, and then the
 // 256 lanes walk the dense list.  FEAT: write float32 channels 4-6 of the feature array (zeros above the DOA band up
 // to F); otherwise write the float64 (3, n_bins, n_frames) array of extract_normalized_eigenvector (+ gate codes).
-constexpr int K3_FT = 16; // frames per tile; divides TR_CH so a tile's gate bits sit in one mask word per bin
+#ifndef K3_FT_N
+#define K3_FT_N 8 // measured 2/4/8/16/32/64: 8 is fastest (tiles in bursts do ~10x the work of quiet ones: small tiles balance)
+#endif
+constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gate words sit in one chunk
 
 #ifndef K3_MINWAVES
 #define K3_MINWAVES 1
@@ -507,22 +511,36 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
     };
     const double zero3[3] = {0.0, 0.0, 0.0};
     {
-        // lane = bin (consecutive lanes, consecutive bins); frames outer, so the list is frame-major / bin-minor
+        // Compaction.  lane = bin; a wave covers exactly one 64-bin group, so the gate word of (frame, group) is a
+        // wave-uniform scalar whose bits ARE the lanes to keep.  Each wave counts its K3_FT words with scalar popcounts,
+        // reserves its slice of the work list with ONE LDS atomic, and every kept lane drops its (frame, bin) at
+        // slice + (bits below it): lane order survives, so neighbouring list entries are neighbouring bins.
         const int bl = tid;
         const bool in = bl < nbc;
         const int nchunks = (Tn + TR_CH - 1) / TR_CH, ngroups = (kp.nd + 63) / 64;
         const int bin = bin0 + bl;
-        // gate words of this tile: [chunk][group][frame], bit = bin within its group of 64
-        // (a wave covers exactly one 64-bin group, so the word address is wave-uniform: scalar loads)
+        const int lane = tid & 63;
         const int grp = __builtin_amdgcn_readfirstlane(bin >> 6) < ngroups ? __builtin_amdgcn_readfirstlane(bin >> 6) : ngroups - 1;
         const unsigned long long *vw = valid + (((long)b * nchunks + t0 / TR_CH) * ngroups + grp) * TR_CH + t0 % TR_CH;
-        for (int ft = 0; ft < nft; ft++) {
-            const unsigned long long word = kp.tracking ? vw[ft] : ~0ull;
-            if (in) {
-                const bool v = ((word >> (bin & 63)) & 1) != 0;
-                if (v) list[atomicAdd(&count, 1)] = (unsigned short)(ft * 256 + bl); // wave-aggregated: lane order survives
+        const unsigned long long inmask = __ballot(in);
+        unsigned long long words[K3_FT];
+        int total = 0;
+#pragma unroll
+        for (int ft = 0; ft < K3_FT; ft++) {
+            words[ft] = ft < nft ? ((kp.tracking ? vw[ft] : ~0ull) & inmask) : 0ull;
+            total += __popcll(words[ft]);
+        }
+        int base = 0;
+        if (lane == 0 && total) base = atomicAdd(&count, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int ft = 0; ft < K3_FT; ft++) {
+            if (ft < nft && in) {
+                const unsigned long long wd = words[ft];
+                if ((wd >> lane) & 1) list[base + __popcll(wd & ((1ull << lane) - 1))] = (unsigned short)(ft * 256 + bl);
                 else emit(t0 + ft, bin, zero3, 0);
             }
+            base += __popcll(words[ft]);
         }
     }
     if (FEAT && blockIdx.z == gridDim.z - 1) { // zero the feature bins above the DOA band (:373-374)
@@ -572,11 +590,11 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
                 salsa::herm4_rank1_add(R, x);
             }
         }
-        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, !kp.tracking);
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, !kp.tracking);
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || !kp.tracking) { // :111-112 the coherence test only gates when tracking
-            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e);
+            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e, !kp.tracking);
             else salsa::normalise_mic(er.u, kp.delta * (double)(bin + kp.lower), e);
             g = 2;
         }
@@ -861,6 +879,7 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.tracking = pl->p.is_tracking;
     kp.n_hop = pl->p.n_hopframes;
     kp.cond = pl->p.cond_num;
+    kp.inv_cond = pl->p.cond_num > 0 ? 1.0 / pl->p.cond_num : 0.0;
     kp.delta = pl->delta;
     return kp;
 }

@@ -290,7 +290,7 @@ template <typename T> struct eig_result {
 // is exactly one.
 // Eigenvector: a column of adj(A - mu1 I) = prod_{i>=2}(mu_i - mu1) u u^H (again from 2x2 minors), taking the column
 // with the largest diagonal cofactor.  Exact for any spectral gap (also with tracking off, where nothing gates it).
-template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, bool need_vector_always)
+template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, bool need_vector_always)
 {
     eig_result<T> res;
     res.rank1 = false;
@@ -342,7 +342,7 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     if (cond <= (T)1) {
         res.rank1 = mu1 > (T)0; // mu2*cond < mu1 whenever mu1 > 0 (cond == 1: strict s0 > s1, a measure-zero tie)
     } else {
-        const T c = mu1 / cond;
+        const T c = mu1 * inv_cond; // inv_cond = 1/cond from the host: a float64 divide is ~25 instructions per bin
         const T t0 = (((c + a3) * c + a2) * c + a1) * c + a0;
         const T t1 = (((T)4 * c + (T)3 * a3) * c + (T)2 * a2) * c + a1;
         const T t2 = ((T)6 * c + (T)3 * a3) * c + a2;
@@ -357,11 +357,25 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
         res.margin = t0;
     }
     if (!res.rank1 && !need_vector_always) return res;
-    // B = A - mu1 I ; adj(B) column with the largest |diagonal cofactor|
+    // B = A - mu1 I ; adj(B) column with the largest |diagonal cofactor|.  Only the diagonal changes, so B's 2x2 minors
+    // are A's plus terms linear (s0, c5: quadratic) in mu1; s5 and c0 contain no diagonal entry at all.
     herm4<T> B = A;
 #pragma unroll
     for (int i = 0; i < 4; i++) B.d[i] -= mu1;
-    const minors4<T> n = herm4_minors(B);
+    minors4<T> n = m;
+    {
+        const cplx<T> a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4];
+        n.s0 = B.d[0] * B.d[1] - (A.o[0].re * A.o[0].re + A.o[0].im * A.o[0].im);
+        n.c5 = B.d[2] * B.d[3] - (A.o[5].re * A.o[5].re + A.o[5].im * A.o[5].im);
+        n.s1 = {m.s1.re - mu1 * a12.re, m.s1.im - mu1 * a12.im}; // (a00-mu) a12 - a10 a02
+        n.s2 = {m.s2.re - mu1 * a13.re, m.s2.im - mu1 * a13.im}; // (a00-mu) a13 - a10 a03
+        n.s3 = {m.s3.re + mu1 * a02.re, m.s3.im + mu1 * a02.im}; // a01 a12 - (a11-mu) a02
+        n.s4 = {m.s4.re + mu1 * a03.re, m.s4.im + mu1 * a03.im}; // a01 a13 - (a11-mu) a03
+        n.c4 = {m.c4.re - mu1 * a12.re, m.c4.im + mu1 * a12.im}; // conj(a12) (a33-mu) - a31 a23
+        n.c3 = {m.c3.re + mu1 * a13.re, m.c3.im - mu1 * a13.im}; // a21 a32 - conj(a13) (a22-mu)
+        n.c2 = {m.c2.re - mu1 * a02.re, m.c2.im + mu1 * a02.im}; // conj(a02) (a33-mu) - a30 a23
+        n.c1 = {m.c1.re + mu1 * a03.re, m.c1.im - mu1 * a03.im}; // a20 a32 - conj(a03) (a22-mu)
+    }
     T bd[4];
     herm4_adj_diag(B, n, bd);
     const cplx<T> b01 = B.o[0], b02 = B.o[1], b03 = B.o[2], b12 = B.o[3], b13 = B.o[4], b23 = B.o[5];
@@ -393,13 +407,16 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
 // FOA: real(u[1:]/u[0]) then L2-normalise (salsa_feature_extraction.py:118-119).  Re(u_i/u_0) = Re(u_i conj(u_0))
 // / |u_0|^2 and the positive factor 1/|u_0|^2 cancels in the normalisation, so e = v/||v|| with v_i = Re(u_i
 // conj(u_0)); u_0 = 0 gives 0/0 = NaN exactly where the reference (no guard) does.
-template <typename T> SALSA_HD void normalise_foa(const cplx<T> *u, T *e)
+template <typename T> SALSA_HD void normalise_foa(const cplx<T> *u, T *e, bool rescale = true)
 {
-    // scale u so |v| is O(1): adjugate columns can be tiny when the spectral gap is (tracking off)
+    // scale u so |v| is O(1): adjugate columns can be tiny when the spectral gap is (tracking off, no gate).  With the
+    // gate (mu1 > cond*mu2 on a trace-1..2 matrix) the chosen column is O(gap^3 |u_j|) >= 1e-2: no rescale needed.
     T s = 0;
+    if (rescale) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) { s = fmax(s, fabs(u[i].re)); s = fmax(s, fabs(u[i].im)); }
-    const T r = s > (T)0 ? (T)pow2_unscale((double)s) : (T)1;
+        for (int i = 0; i < 4; i++) { s = fmax(s, fabs(u[i].re)); s = fmax(s, fabs(u[i].im)); }
+    }
+    const T r = (rescale && s > (T)0) ? (T)pow2_unscale((double)s) : (T)1;
     const cplx<T> u0 = {u[0].re * r, u[0].im * r};
     T ss = 0;
 #pragma unroll

@@ -95,11 +95,11 @@ int hostemu_eigvec(const float *X, int nb, long nt, double cond, int n_hop, int 
                 for (int c = 0; c < 4; c++) x[c] = {(double)Xb[tt * 8 + 2 * c], (double)Xb[tt * 8 + 2 * c + 1]};
                 herm4_rank1_add(R, x);
             }
-            eig_result<double> er = herm4_gate_eigvec(R, cond, !tracking);
+            eig_result<double> er = herm4_gate_eigvec(R, cond, 1.0 / cond, !tracking);
             rank[(size_t)b * nt + t] = er.rank1 ? 2 : 1;
             if (tracking && !er.rank1) continue;
             double e[3];
-            if (format == 0) normalise_foa(er.u, e);
+            if (format == 0) normalise_foa(er.u, e, !tracking);
             else normalise_mic(er.u, delta * (double)(b + lower_bin), e);
             for (int i = 0; i < 3; i++) out[((size_t)i * nb + b) * nt + t] = e[i];
         }
