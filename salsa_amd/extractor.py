@@ -207,3 +207,38 @@ def normalize_(feat: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> tor
     if rc:
         _raise(rc)
     return feat
+
+
+class StreamedExtractor:
+    """Bulk extraction of many independent batches: ``n_streams`` plans on their own HIP streams, fed round-robin, so
+    the latency-bound noise-floor tracker of one batch overlaps the STFT / eigen kernels of its neighbours (+9 % on
+    MI355X with 2 streams).  ``extract_many`` yields the feature tensors in input order; each yielded tensor is only
+    valid until ``n_streams`` further batches have been produced (its buffer is then reused)."""
+
+    def __init__(self, n_streams: int = 2, **extractor_kwargs):
+        self.exs = [SalsaExtractor(**extractor_kwargs) for _ in range(n_streams)]
+        self.streams = [torch.cuda.Stream(device=self.exs[0].device) for _ in range(n_streams)]
+        self.outs = [None] * n_streams
+
+    def extract_many(self, batches):
+        n = len(self.exs)
+        pending = []
+        for i, audio in enumerate(batches):
+            j = i % n
+            self.streams[j].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.streams[j]):
+                want = (audio.shape[0],) + tuple(self.exs[j].output_shape(
+                    audio.shape[2] if self.exs[j].audio_layout == 'planar' else audio.shape[1]))
+                if self.outs[j] is None or tuple(self.outs[j].shape) != want:
+                    self.outs[j] = torch.empty(want, dtype=torch.float32, device=audio.device)
+                self.exs[j].extract(audio, out=self.outs[j])
+                ev = torch.cuda.Event()
+                ev.record(self.streams[j])
+            pending.append((ev, self.outs[j]))
+            if len(pending) == n:
+                e, o = pending.pop(0)
+                e.synchronize()
+                yield o
+        for e, o in pending:
+            e.synchronize()
+            yield o

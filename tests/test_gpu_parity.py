@@ -335,3 +335,13 @@ def test_lite_harness_and_python_surface(dev, tmp_path):
     ex = MagStftExtractor(n_fft=512, hop_length=300, win_length=512)
     assert ex.W.shape == (200, 257)
     assert ex.extract(y[:3]).shape == (3, 41, 200)                          # any channel count, like the reference
+
+
+def test_streamed_bulk_extraction_matches_single_stream(dev):
+    from salsa_amd.extractor import StreamedExtractor
+    batches = [torch.from_numpy(np.stack([synth_clip(800 + 3 * i + j, 3 * 24000) for j in range(3)])).to(dev)
+               for i in range(5)]
+    ex = _extractor()
+    ref = [ex.extract(b).clone() for b in batches]
+    got = [o.clone() for o in StreamedExtractor(n_streams=2).extract_many(batches)]
+    assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))

@@ -33,5 +33,23 @@ with open(out+'/pmc_summary.csv','w') as fo:
             fo.write('%s,%s,%.6g,%d\n'%(k,c,sum(v)/len(v),len(v)))
 print(open(out+'/pmc_summary.csv').read())
 PY
+# calibration of FETCH_SIZE / WRITE_SIZE on known byte counts
+for CTRS in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/calib_$CTRS -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $OUT/calib_$CTRS.log 2>&1
+done
+python - <<PY
+import csv, glob, collections
+out='$OUT'
+agg=collections.defaultdict(list)
+for f in sorted(glob.glob(out+'/calib_*/**/*counter_collection.csv', recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k=row['Kernel_Name'].replace('void ','').replace('(anonymous namespace)::','').split('(')[0].split('<')[0]
+        agg[(k,row['Counter_Name'])].append(float(row['Counter_Value']))
+with open(out+'/pmc_calibration.csv','w') as fo:
+    fo.write('kernel,counter,mean_per_dispatch_KB,n\n')
+    for (k,c),v in sorted(agg.items()):
+        fo.write('%s,%s,%.6g,%d\n'%(k,c,sum(v)/len(v),len(v)))
+print(open(out+'/pmc_calibration.csv').read())
+PY
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -size +4M -delete
 du -sh $OUT
