@@ -145,12 +145,23 @@ def main():
             kernels.append({'name': name, 'launches_per_step': launches, 'ms_per_launch': round(ms, 4),
                             'algorithmic_bytes_per_launch': int(b),
                             'GBps': round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
+        # measured HBM bytes per launch (rocprofv3 PMC, collected offline by tools/pmc_round.sh + tools/pmc_traffic.py:
+        # counters cannot be sampled from inside this process); only valid for the batch size they were taken at
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+            if tj.get('batch_clips_per_launch') == args.batch and args.feature == 'salsa' and abs(args.seconds - 60) < 1e-9:
+                traffic = {k: v['hbm_bytes'] for k, v in tj['kernels'].items()}
+        except Exception:
+            pass
+        for k in kernels:
+            k['traffic'] = traffic.get(k['name'])
         dom = max(kernels, key=lambda k: k['ms_per_launch'] * k['launches_per_step'])
         step_ms = 1e3 * elapsed / args.steps
         pipe_bytes = sum(ab.values())
         roofline = {'bound': 'hbm', 'kernel': dom['name'], 'kernel_ms': dom['ms_per_launch'],
                     'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(dom['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(dom['GBps'] / HBM_PEAK_GBS, 4), 'traffic': dom.get('traffic'),
                     'pipeline': {'ms': round(step_ms, 4), 'algorithmic_bytes': pipe_bytes,
                                  'achieved': round(pipe_bytes / (step_ms * 1e-3) / 1e9, 1),
                                  'frac': round(pipe_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
