@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     constexpr int NB = N / 2 + 1;
     __shared__ cplx<T> buf[4][N];
     __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
-    __shared__ float2 x0s[LITE ? 4 : 1][LITE ? NB : 1]; // SALSA-Lite: channel-0 spectrum of the frame, kept for pair 1
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
@@ -225,6 +224,7 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
     const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
+    float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
 
     for (int item = 0; item < nitems; item++) {
         const int t = t_begin + (item >> 1);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
 
         // ---- unpack this pair's two spectra: bins k = lane + 64 r, r < R/2 (+ lane 0: the Nyquist bin)
         const int c0 = 2 * pr;
-        auto emit_bin = [&](const int k, const cplx<T> a, const cplx<T> bm) {
+        auto emit_bin = [&](const int k, const cplx<T> a, const cplx<T> bm, float2 &x0k) {
             cplx<T> Xa, Xb;
             salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
             const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
@@ -304,29 +304,32 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
                     pw[w][1][k - kp.ident - 1] = pb;
                 }
             } else { // SALSA-Lite / SALSA-IPD (salsa_lite_feature_extraction.py:103-120)
-                if (pr == 0) x0s[w][k] = xa;
+                if (pr == 0) x0k = xa;
                 if (k >= kp.lower && k < kp.cutoff) {
                     const int f = k - kp.lower;
                     o[(c0 * Tn + t) * kp.F + f] = db10(pa);
                     o[((c0 + 1) * Tn + t) * kp.F + f] = db10(pb);
-                    const float2 x0 = pr == 0 ? xa : x0s[w][k];
-                    const double scale = kp.feature == SALSA_FEATURE_IPD ? 3.14159265358979323846
-                                                                         : kp.delta * (double)(k == 0 ? 1 : k);
+                    const float2 x0 = x0k;
+                    // angle(X_c conj(X_0)) / (delta*k) (lite :111-115) or / pi (ipd :113).  float32 throughout: the
+                    // product's rounding moves the angle by <= 1e-7 rad and 1/(delta*k) is the float64 quotient rounded
+                    // once, so the float32 result is within ~2 ulp of the reference's float64-then-cast value.
+                    const float inv_scale = kp.feature == SALSA_FEATURE_IPD ? 0.318309886183790672f
+                                                                           : (float)(1.0 / (kp.delta * (double)(k == 0 ? 1 : k)));
                     // pair 0 contributes channel 1 (phase vs channel 0); pair 1 contributes channels 2 and 3
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if (pr == 0 && h == 0) continue;
-                        const float2 xc = h == 0 ? xa : xb;
-                        float ph = 0.f;
-                        if (f < kp.upper) { // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
-                            double wr = (double)xc.x * x0.x + (double)xc.y * x0.y;
-                            double wi = (double)xc.y * x0.x - (double)xc.x * x0.y;
-                            const double m = fmax(fabs(wr), fabs(wi));
-                            if (m < 1e-30 && m > 0.0) { wr *= 0x1p200; wi *= 0x1p200; } // keep the float cast normal
-                            ph = (float)((double)atan2f((float)wi, (float)wr) / scale);
+                    auto phase = [&](const float2 xc) -> float {
+                        if (!(f < kp.upper)) return 0.f; // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
+                        float wr = xc.x * x0.x + xc.y * x0.y;
+                        float wi = xc.y * x0.x - xc.x * x0.y;
+                        const float m = fmaxf(fabsf(wr), fabsf(wi));
+                        if (m < 1e-30f && m > 0.f) { // products of tiny spectra: redo the product scaled up (exact)
+                            const float sx = 0x1p60f;
+                            wr = (xc.x * sx) * (x0.x * sx) + (xc.y * sx) * (x0.y * sx);
+                            wi = (xc.y * sx) * (x0.x * sx) - (xc.x * sx) * (x0.y * sx);
                         }
-                        o[((3 + c0 + h) * Tn + t) * kp.F + f] = ph;
-                    }
+                        return atan2f(wi, wr) * inv_scale;
+                    };
+                    if (pr == 1) o[((3 + c0) * Tn + t) * kp.F + f] = phase(xa);
+                    o[((4 + c0) * Tn + t) * kp.F + f] = phase(xb);
                 }
             }
         };
@@ -336,10 +339,10 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
             // lane 0: N - 64 r = 64 (R-r), its own register (R-r) mod R
             cplx<T> bm = {__shfl(v[R - 1 - r].re, mlane), __shfl(v[R - 1 - r].im, mlane)};
             if (lane == 0) bm = v[(R - r) & (R - 1)];
-            emit_bin(lane + 64 * r, v[r], bm);
+            emit_bin(lane + 64 * r, v[r], bm, x0keep[r]);
             __builtin_amdgcn_sched_barrier(0); // one bin at a time: keeps the live set (and the VGPR count) small
         }
-        if (lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2]);
+        if (lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2], x0keep[R / 2]);
         // ---- compressed high-frequency rows of W: sum of 8 (last row 7) bins times 1/8
         if (!LITE && kp.compress) {
             wave_lds_fence();
