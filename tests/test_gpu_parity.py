@@ -345,3 +345,29 @@ def test_streamed_bulk_extraction_matches_single_stream(dev):
     ref = [ex.extract(b).clone() for b in batches]
     got = [o.clone() for o in StreamedExtractor(n_streams=2).extract_many(batches)]
     assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref))
+
+
+def test_extract_is_hip_graph_capturable(dev):
+    """include/salsa_hip.h promises that the extract call allocates and synchronises nothing: capture it in a HIP graph
+    (torch.cuda.CUDAGraph), replay on fresh input, compare with the eager result."""
+    ys = [np.stack([synth_clip(900 + 2 * i + j, 2 * 24000) for j in range(2)]) for i in range(2)]
+    ex = _extractor()
+    static_in = torch.from_numpy(ys[0]).to(dev)
+    static_out = torch.empty((2,) + tuple(ex.output_shape(2 * 24000)), dtype=torch.float32, device=dev)
+    ex.extract(static_in, out=static_out)                                  # warm-up: sizes the workspace
+    ref0 = static_out.clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ex.extract(static_in, out=static_out)
+    static_out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref0)
+    static_in.copy_(torch.from_numpy(ys[1]).to(dev))
+    g.replay()
+    torch.cuda.synchronize()
+    eager = _extractor().extract(torch.from_numpy(ys[1]).to(dev))
+    assert torch.equal(static_out, eager)
