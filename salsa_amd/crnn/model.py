@@ -6,10 +6,14 @@ Shapes for an 8-s training chunk (7,640,200): stem (64,320,100) -> stage1 (64,32
 stage3 (256,80,25) -> stage4 (512,40,12) -> mean over frequency (40,512) -> BiGRU (40,512) -> SED logits (40,12) and
 xyz (40,36).  14.11 M parameters (11.21 M encoder + 2.90 M decoder)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
 
 
 def _xavier(layer):
@@ -126,7 +130,13 @@ class Decoder(nn.Module):
 
     def forward(self, feat):
         seq = feat.mean(dim=3).transpose(1, 2)                  # (B, T', 512)
-        seq, _ = self.gru(seq)
+        if seq.is_cuda and GRU_FP32:
+            # 0.4 % of the FLOPs but, under bf16 autocast, ~6000 per-timestep cell kernels per forward (torch's native
+            # fallback); in float32 the whole sequence goes through MIOpen's fused RNN
+            with torch.autocast(device_type='cuda', enabled=False):
+                seq, _ = self.gru(seq.float())
+        else:
+            seq, _ = self.gru(seq)
         doa = torch.cat([torch.tanh(self.x(seq)), torch.tanh(self.y(seq)), torch.tanh(self.z(seq))], dim=-1)
         return {'event_frame_logit': self.event(seq), 'doa_frame_output': doa}
 
