@@ -1,11 +1,19 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the CRNN benches (GPU box).  usage: tools/prof_crnn.sh <tag>
+# rocprofv3 kernel stats of the CRNN training step in steady state (GPU box).  usage: tools/prof_crnn.sh <tag>
+# MIOPEN_FIND_MODE=2 (fast/immediate) keeps MIOpen's solver search (and its naive reference kernels) out of the trace.
 TAG=${1:-crnn}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 python -c "import sys; sys.path.insert(0,'$GRAFT_REPO_ROOT'); import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
-for MODE in "--infer --steps 3 --warmup 1 --clips 16" "--steps 6 --warmup 3"; do
-  N=$(echo $MODE | cut -c3-7 | tr -d ' -')
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p_$N -o crnn -- python $GRAFT_REPO_ROOT/bench_crnn.py $MODE > $OUT/run_$N.log 2>&1
-  tail -1 $OUT/run_$N.log | cut -c1-200
-  f=$(find $OUT/p_$N -name '*kernel_stats.csv' | head -1); cp $f $OUT/crnn_${N}_kernel_stats.csv; head -16 $f | cut -c1-230
-  find $OUT/p_$N -name '*kernel_trace.csv' -delete
-done
+export MIOPEN_FIND_MODE=2
+python $GRAFT_REPO_ROOT/bench_crnn.py --steps 10 --warmup 4 | tail -1 | cut -c1-160
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o crnn -- python $GRAFT_REPO_ROOT/bench_crnn.py --steps 10 --warmup 4 > $OUT/run.log 2>&1
+f=$(find $OUT/p -name '*kernel_stats.csv' | head -1); cp $f $OUT/crnn_train_kernel_stats.csv
+find $OUT/p -name '*kernel_trace.csv' -delete
+python - <<PY
+import csv
+rows=list(csv.DictReader(open('$OUT/crnn_train_kernel_stats.csv')))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+print('total kernel ms (14 steps incl. warm-up):', tot/1e6)
+for r in rows[:22]:
+    n=r['Name']; n=n if len(n)<70 else n[:34]+'..'+n[-34:]
+    print('%-72s calls %6s total %8.2f ms  %5.1f%%'%(n,r['Calls'],float(r['TotalDurationNs'])/1e6,float(r['Percentage'])))
+PY
