@@ -122,6 +122,9 @@ __device__ __forceinline__ void st_stream(float4 *p, const float4 v)
 
 __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
+#ifndef GRID_CLIP_FASTEST
+#define GRID_CLIP_FASTEST 0 // 1 = all blocks of a clip on one XCD (L2 halo sharing); measured SLOWER (cov_eig 0.69 vs 0.53 ms)
+#endif
 #ifndef K1_TW_REGS
 #define K1_TW_REGS 0
 #endif
@@ -147,9 +150,13 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
+    // grid = (clips, frame blocks): linear workgroup id = clip + block * B, and the dispatcher sends id % 8 to one XCD
+    // (observed, speed only): with B a multiple of 8 every block of a clip lands on the same XCD, so the overlap between
+    // consecutive frames (and later K3's +-3-frame halo) is served from that XCD's L2, while the 8 XCDs each own whole
+    // clips and stay balanced.
+    const int b = GRID_CLIP_FASTEST ? blockIdx.x : blockIdx.y;
     const int Ns = kp.N, Tn = kp.T;
-    const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
+    const int t_begin = ((GRID_CLIP_FASTEST ? blockIdx.y : blockIdx.x) * 4 + w) * K1_NF;
     cplx<T> *z = buf[w];
 
 #if K1_TW_REGS
@@ -526,11 +533,11 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
     __shared__ unsigned short list[K3_FT * 256];
     __shared__ int count;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = GRID_CLIP_FASTEST ? blockIdx.x : blockIdx.y;
     const int Tn = kp.T;
     // XCD-aware tile order: workgroup i runs on XCD i % 8 (observed dispatch, speed only).  Give each XCD a contiguous
     // run of time tiles so the +-3-frame halo a tile shares with its neighbours is served by that XCD's own L2.
-    const int tile = K3_XCD_SWIZZLE ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int tile = GRID_CLIP_FASTEST ? (int)blockIdx.y : (K3_XCD_SWIZZLE ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
     const int t0 = tile * K3_FT;
     const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
     const int bin0 = blockIdx.z * 256;
@@ -943,7 +950,8 @@ static void mark_end(salsa_plan *pl, hipStream_t s, int i)
 
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
-    dim3 grid((unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK), (unsigned)kp.B);
+    const unsigned nblk = (unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK);
+    dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)kp.B, nblk) : dim3(nblk, (unsigned)kp.B);
     const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
     if (pl->p.n_fft == 512) {
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
@@ -967,6 +975,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         const int64_t T64 = 1 + n_samples / pl->p.hop_len;
         if (n_samples * 4 >= INT32_MAX || T64 * 7 * pl->F >= INT32_MAX || T64 * 2 * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX)
             return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
+        if ((T64 + K3_FT - 1) / K3_FT > 65535) return fail(SALSA_EINVAL, "clip too long for one launch (split it)%s");
     }
     hipStream_t s = (hipStream_t)hip_stream;
     KParams kp = make_kparams(pl, batch, n_samples);
@@ -1005,7 +1014,8 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
             HIP_TRY(hipGetLastError());
         }
         m = mark_begin(pl, s2, "cov_eig");
-        dim3 grid((unsigned)((gp.T + K3_FT - 1) / K3_FT), (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
+        const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
+        dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)gp.B, ntile, (unsigned)((gp.nd + 255) / 256)) : dim3(ntile, (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
         launch_cov_eig<true>(gp, grid, s2, xs, vm, o, (double *)nullptr, (unsigned char *)nullptr);
         mark_end(pl, s2, m);
         HIP_TRY(hipGetLastError());
@@ -1071,7 +1081,8 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
         hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
         HIP_TRY(hipGetLastError());
     }
-    dim3 grid((unsigned)((kp.T + K3_FT - 1) / K3_FT), (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
+    const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);
+    dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)kp.B, ntile, (unsigned)((n_bins + 255) / 256)) : dim3(ntile, (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
     launch_cov_eig<false>(kp, grid, s, Xs, valid, (float *)nullptr, d_out, d_gate);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
