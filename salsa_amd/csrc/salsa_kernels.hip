@@ -844,20 +844,6 @@ int salsa_plan_create(const salsa_params *params, salsa_plan **out_plan)
         return fail(SALSA_EHIP, "plan table upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     pl->n_groups = 1; // measured on ROCm 7.2: multi-stream issue costs more host time than the overlap returns
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
-        bool ok = true;
-        for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++)
-            ok = hipStreamCreateWithPriority(&pl->streams[i], hipStreamNonBlocking, i == 0 ? lo : hi) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            salsa_plan_destroy(pl);
-            return fail(SALSA_EHIP, "stream / event creation failed%s");
-        }
-    }
     *out_plan = pl;
     return SALSA_OK;
 }
@@ -1137,9 +1123,27 @@ int salsa_normalize_batch(float *d_feat, int batch, int n_channels, int64_t n_fr
     return SALSA_OK;
 }
 
+static int ensure_group_streams(salsa_plan *pl)
+{
+    if (pl->streams[0]) return SALSA_OK;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
+    bool ok = true;
+    for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++)
+        ok = hipStreamCreateWithPriority(&pl->streams[i], hipStreamNonBlocking, i == 0 ? lo : hi) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    return ok ? SALSA_OK : fail(SALSA_EHIP, "stream / event creation failed%s");
+}
+
 int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
 {
     if (!pl || n_groups < 1) return fail(SALSA_EINVAL, "salsa_plan_set_groups: bad argument%s");
+    if (n_groups > 1) { // the plan-owned streams are only created when the pipeline is actually requested
+        const int rc = ensure_group_streams(pl);
+        if (rc) return rc;
+    }
     pl->n_groups = n_groups > SALSA_MAX_GROUPS ? SALSA_MAX_GROUPS : n_groups;
     return SALSA_OK;
 }

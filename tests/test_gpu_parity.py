@@ -371,3 +371,31 @@ def test_extract_is_hip_graph_capturable(dev):
     torch.cuda.synchronize()
     eager = _extractor().extract(torch.from_numpy(ys[1]).to(dev))
     assert torch.equal(static_out, eager)
+
+
+def test_full_size_scaling_invariance(dev):
+    """Size-independent property at BASELINE clip length: scaling the audio by an exact power of two scales every
+    spectrum, the 3-frame RMS and the noise floor exactly (as long as the 1e-6 floor clamp is not hit), so every gate
+    decision and every eigenvector is bit-identical, while the log-spectrogram moves by 20*log10(4) dB."""
+    ys = np.stack([synth_clip(2040 + i, 60 * 24000) for i in range(2)])
+    ex = _extractor()
+    a = torch.from_numpy(ys).to(dev)
+    f1 = ex.extract(a).clone()
+    f4 = ex.extract(a * 4.0)
+    assert torch.equal(f1[:, 4:], f4[:, 4:])
+    lo = f1[:, :4].cpu().numpy()
+    d = f4[:, :4].cpu().numpy() - lo
+    free = lo > -99.0                                    # bins not sitting on the amin = 1e-10 clamp (-100 dB)
+    assert free.mean() > 0.99 and np.abs(d[free] - 20 * np.log10(4.0)).max() < 5e-5
+
+
+def test_channel_permutation_equivariance(dev):
+    """Swapping FOA channels Y and Z (inputs 2 and 3) swaps log-spectrogram rows 2/3 and eigenvector components 5/6 and
+    changes nothing else (the covariance is permuted, its spectrum and gates are not) -- to float64 round-off."""
+    y = synth_clip(2050, 10 * 24000)
+    ex = _extractor()
+    f = ex.extract(torch.from_numpy(y[None]).to(dev))[0].cpu().numpy()
+    g = ex.extract(torch.from_numpy(np.ascontiguousarray(y[[0, 1, 3, 2]])[None]).to(dev))[0].cpu().numpy()
+    assert np.array_equal(f[:2], g[:2])                                    # pair 0 untouched: bit-identical
+    np.testing.assert_allclose(f[[3, 2]], g[2:4], rtol=0, atol=2e-5)       # pair 1 packs (y3 + i*y2): other rounding path
+    np.testing.assert_allclose(f[[4, 6, 5]], g[4:], rtol=1e-5, atol=1e-6)
