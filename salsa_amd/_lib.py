@@ -6,6 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libsalsa_hip.so')
 SRC_PATH = os.path.join(_HERE, 'csrc', 'salsa_kernels.hip')
+GRU_SRC_PATH = os.path.join(_HERE, 'csrc', 'gru_scan.hip')
 
 FORMAT = {'foa': 0, 'mic': 1}
 FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
@@ -26,7 +27,7 @@ _lib = None
 
 
 def build_command():
-    return ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB_PATH, SRC_PATH]
+    return ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB_PATH, SRC_PATH, GRU_SRC_PATH]
 
 
 def load():
@@ -56,6 +57,8 @@ def load():
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
     L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
+    L.salsa_gru_scan_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.salsa_gru_scan_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
     L.salsa_normalize_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp]
     _lib = L
@@ -70,3 +73,4 @@ EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_c
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
            'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch']
+GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_bwd']

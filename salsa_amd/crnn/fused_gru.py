@@ -1,0 +1,74 @@
+"""Bidirectional GRU layer whose time recurrence is ONE hand-written HIP launch (salsa_amd/csrc/gru_scan.hip, C ABI in
+include/salsa_gru.h) instead of ~500 tiny library kernels per layer per step.  The dense parts stay GEMMs: the input
+projection W_ih x + b_ih for all timesteps before the scan, dW_hh / dW_ih after the backward scan.  Same float32
+arithmetic as torch.nn.GRU (gate order r, z, n); parameters are read from an nn.GRU so state dicts are unchanged."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _GruScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, whh, bhh):
+        """gi (T,B,D,3H) float32 contiguous; whh (D,3H,H); bhh (D,3H) -> hs (T,B,D,H)."""
+        T, B, D, H3 = gi.shape
+        H = H3 // 3
+        L = _lib.load()
+        whh = whh.contiguous()
+        whh_t = whh.transpose(1, 2).contiguous()
+        hs = torch.empty((T, B, D, H), dtype=torch.float32, device=gi.device)
+        need_grad = gi.requires_grad or whh.requires_grad or bhh.requires_grad
+        saved = torch.empty((T, B, D, 4 * H), dtype=torch.float32, device=gi.device) if need_grad else None
+        rc = L.salsa_gru_scan_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh_t.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
+                                  C.c_void_p(hs.data_ptr()), C.c_void_p(saved.data_ptr() if saved is not None else 0),
+                                  T, B, D, H, _stream())
+        if rc:
+            raise RuntimeError('salsa_gru_scan_fwd failed (%d)' % rc)
+        if need_grad:
+            ctx.save_for_backward(whh, hs, saved)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        whh, hs, saved = ctx.saved_tensors
+        T, B, D, H = hs.shape
+        L = _lib.load()
+        dhs = dhs.contiguous()
+        dgi = torch.empty((T, B, D, 3 * H), dtype=torch.float32, device=hs.device)
+        dgh = torch.empty_like(dgi)
+        rc = L.salsa_gru_scan_bwd(C.c_void_p(dhs.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(hs.data_ptr()),
+                                  C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()),
+                                  T, B, D, H, _stream())
+        if rc:
+            raise RuntimeError('salsa_gru_scan_bwd failed (%d)' % rc)
+        hprev = torch.zeros_like(hs)                       # h before each step, per direction's scan order
+        hprev[1:, :, 0] = hs[:-1, :, 0]
+        if D > 1:
+            hprev[:-1, :, 1] = hs[1:, :, 1]
+        dwhh = torch.einsum('tbdr,tbdk->drk', dgh, hprev)  # one GEMM per direction
+        dbhh = dgh.sum(dim=(0, 1))
+        return dgi, dwhh, dbhh
+
+
+def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """x (B,T,In) float32 CUDA -> (B,T,2H); equivalent to ``gru(x)[0]`` for a batch_first bidirectional nn.GRU."""
+    assert gru.batch_first and gru.bidirectional and gru.bias
+    out = x
+    for layer in range(gru.num_layers):
+        names = ['_l%d' % layer, '_l%d_reverse' % layer]
+        wih = torch.stack([getattr(gru, 'weight_ih' + n) for n in names])          # (D,3H,In)
+        whh = torch.stack([getattr(gru, 'weight_hh' + n) for n in names])          # (D,3H,H)
+        bih = torch.stack([getattr(gru, 'bias_ih' + n) for n in names])
+        bhh = torch.stack([getattr(gru, 'bias_hh' + n) for n in names])
+        if layer > 0 and training and gru.dropout > 0:
+            out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
+        gi = torch.einsum('bti,dgi->tbdg', out, wih) + bih                          # (T,B,D,3H)
+        hs = _GruScan.apply(gi.contiguous(), whh, bhh)                              # (T,B,D,H)
+        out = hs.permute(1, 0, 2, 3).reshape(x.shape[0], x.shape[1], -1)
+    return out

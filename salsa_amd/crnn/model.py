@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
+FUSED_GRU = os.environ.get('SALSA_FUSED_GRU', '1') == '1'
 
 
 def _xavier(layer):
@@ -134,7 +135,11 @@ class Decoder(nn.Module):
             # 0.4 % of the FLOPs but, under bf16 autocast, ~6000 per-timestep cell kernels per forward (torch's native
             # fallback); in float32 the whole sequence goes through MIOpen's fused RNN
             with torch.autocast(device_type='cuda', enabled=False):
-                seq, _ = self.gru(seq.float())
+                if FUSED_GRU:
+                    from .fused_gru import bigru_forward
+                    seq = bigru_forward(self.gru, seq.float(), self.training)   # one HIP launch per layer for the scan
+                else:
+                    seq, _ = self.gru(seq.float())
         else:
             seq, _ = self.gru(seq)
         doa = torch.cat([torch.tanh(self.x(seq)), torch.tanh(self.y(seq)), torch.tanh(self.z(seq))], dim=-1)
