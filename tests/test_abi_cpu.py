@@ -29,6 +29,10 @@ def test_every_declared_symbol_is_exported(lib):
     from salsa_amd import _lib
     assert set(_lib.EXPORTS) == names
     assert lib.salsa_abi_version() == 1
+    gru = open(os.path.join(ROOT, 'include', 'salsa_gru.h')).read()
+    gru = re.sub(r'/\*.*?\*/', '', gru, flags=re.S)
+    gnames = set(re.findall(r'\b(salsa_gru_[a-z_]+)\s*\(', gru))
+    assert gnames == set(_lib.GRU_EXPORTS) and all(hasattr(lib, n) for n in gnames)
 
 
 def test_host_helpers_match_reference(lib):
