@@ -101,3 +101,31 @@ def test_two_rank_ddp_step_keeps_replicas_identical(tmp_path):
     assert r0['moved'] > 0 and np.isfinite(r0['loss']) and np.isfinite(r1['loss'])
     assert r0['loss'] != r1['loss']                                   # ranks saw different chunks ...
     assert torch.equal(r0['after'], r1['after'])                      # ... but the all-reduced update is identical
+
+
+def test_postprocess_matches_reference_statement(tmp_path):
+    """combine_chunks + DCASE row generation against a direct restatement of models/interfaces.py:97-139, :232-258."""
+    from salsa_amd.crnn.postprocess import combine_chunks, to_dcase_rows, write_dcase_csv
+    rng = np.random.RandomState(0)
+    # chunks of 80 label frames hopping 40 over a 600-frame file (8-s test chunks, 4-s hop)
+    starts = list(range(0, 600 - 80 + 1, 40))
+    chunks = rng.rand(len(starts), 80, 12).astype(np.float32)
+    ref = np.zeros((600, 12), np.float32)
+    for i, s in enumerate(starts):
+        if i == 0:
+            ref[s:s + 80] = chunks[i]
+        else:
+            ref[s:s + 40] = (ref[s:s + 40] + chunks[i, :40]) / 2
+            ref[s + 40:s + 80] = chunks[i, 40:]
+    np.testing.assert_array_equal(combine_chunks(chunks, 80, 40), ref)
+    prob = rng.rand(600, 12).astype(np.float32) * 0.5
+    xyz = rng.randn(600, 36).astype(np.float32)
+    xyz[5, 0], xyz[5, 12], xyz[5, 24] = -1.0, 0.0, 0.0        # azimuth exactly 180 -> written as -180
+    prob[5, 0] = 0.9
+    rows = to_dcase_rows(prob, xyz)
+    assert [5, 0, 0, -180, 0] in rows
+    n_active = int((prob >= 0.3).sum())
+    assert len(rows) == n_active and all(len(r) == 5 and -180 <= r[3] < 180 and -90 <= r[4] <= 90 for r in rows)
+    assert len(to_dcase_rows(prob, xyz, eval_version='2020')[0]) == 4
+    write_dcase_csv(str(tmp_path / 'o.csv'), rows)
+    assert sum(1 for _ in open(tmp_path / 'o.csv')) == len(rows)
