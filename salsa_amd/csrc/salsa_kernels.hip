@@ -514,6 +514,12 @@ constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gat
 #ifndef K3_MINWAVES
 #define K3_MINWAVES 1
 #endif
+#ifndef K3_LOAD_SPLIT
+#define K3_LOAD_SPLIT 0
+#endif
+#ifndef K3_UNROLLED_LOADS
+#define K3_UNROLLED_LOADS 1
+#endif
 #ifndef K3_XCD_SWIZZLE
 #define K3_XCD_SWIZZLE 0 // measured: 0.59 vs 0.54 ms -- bursts occupy ~25 % of a clip's time, so giving an XCD a contiguous
                          // time range trades halo L2 hits for a 3x load imbalance between XCDs
@@ -611,21 +617,32 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
         salsa::herm4<double> R = {};
         const float4 *xb = xclip + bin;
         if (NHOP >= 0) {
+            // the 2*NHOP+1 frames in two batches of independent 16-B loads: all 14 at once costs 56 VGPRs and a wave
+            // per SIMD; two batches keep the kernel at 4 waves/SIMD
             constexpr int NW = NHOP >= 0 ? 2 * NHOP + 1 : 1;
-            float4 xa[NW], xc[NW];
+            constexpr int NA = K3_LOAD_SPLIT ? (NW + 1) / 2 : NW;
 #pragma unroll
-            for (int k = 0; k <= 2 * NHOP; k++) {
-                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
-                while (tt < 0) tt += Tn;
-                while (tt >= Tn) tt -= Tn;
-                xa[k] = xb[tt * stride];
-                xc[k] = xb[tt * stride + kp.nd];
-            }
+            for (int k0 = 0; k0 < NW; k0 += NA) {
+                float4 xa[NA], xc[NA];
 #pragma unroll
-            for (int k = 0; k <= 2 * NHOP; k++) {
-                const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
-                                           {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
-                salsa::herm4_rank1_add(R, x);
+                for (int k = 0; k < NA; k++) {
+                    if (k0 + k < NW) {
+                        int tt = t + k0 + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
+                        while (tt < 0) tt += Tn;
+                        while (tt >= Tn) tt -= Tn;
+                        xa[k] = xb[tt * stride];
+                        xc[k] = xb[tt * stride + kp.nd];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NA; k++) {
+                    if (k0 + k < NW) {
+                        const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
+                                                   {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
+                        salsa::herm4_rank1_add(R, x);
+                    }
+                }
+                if (K3_LOAD_SPLIT) __builtin_amdgcn_sched_barrier(0); // keep the batches apart (the scheduler would re-merge them)
             }
         } else {
             for (int k = -nhop; k <= nhop; k++) {
@@ -654,7 +671,7 @@ template <bool FEAT>
 static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned long long *valid,
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
-    if (kp.n_hop == 3)
+    if (kp.n_hop == 3 && K3_UNROLLED_LOADS)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);

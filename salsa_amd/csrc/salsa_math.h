@@ -379,24 +379,28 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     T bd[4];
     herm4_adj_diag(B, n, bd);
     const cplx<T> b01 = B.o[0], b02 = B.o[1], b03 = B.o[2], b12 = B.o[3], b13 = B.o[4], b23 = B.o[5];
-    // upper triangle of adj(B) (Hermitian)
-    const cplx<T> adj01 = csub(csub(cmul(b02, n.c4), rmul(n.c5, b01)), cmul(b03, n.c3));                    // -a01 c5 + a02 c4 - a03 c3
-    const cplx<T> adj02 = cadd(csub(cmul(cconj(b13), n.s5), cmul(cconj(b23), n.s4)), rmul(B.d[3], n.s3));   //  a31 s5 - a32 s4 + a33 s3
-    const cplx<T> adj03 = csub(csub(rmul(B.d[2], n.s4), cmul(cconj(b12), n.s5)), cmul(b23, n.s3));          // -a21 s5 + a22 s4 - a23 s3
-    const cplx<T> adj12 = csub(csub(cmul(cconj(b23), n.s2), cmul(cconj(b03), n.s5)), rmul(B.d[3], n.s1));   // -a30 s5 + a32 s2 - a33 s1
-    const cplx<T> adj13 = cadd(csub(cmul(cconj(b02), n.s5), rmul(B.d[2], n.s2)), cmul(b23, n.s1));          //  a20 s5 - a22 s2 + a23 s1
-    const cplx<T> adj23 = csub(csub(cmul(cconj(b12), n.s2), cmul(cconj(b02), n.s4)), rmul(n.s0, b23));      // -a20 s4 + a21 s2 - a23 s0
     const T m0 = fabs(bd[0]), m1 = fabs(bd[1]), m2 = fabs(bd[2]), m3 = fabs(bd[3]);
     int j = 0;
     T best = m0;
     if (m1 > best) { best = m1; j = 1; }
     if (m2 > best) { best = m2; j = 2; }
     if (m3 > best) { best = m3; j = 3; }
-    // column j of adj: u_i = adj_{ij}
-    if (j == 0) { res.u[0] = {bd[0], 0}; res.u[1] = cconj(adj01); res.u[2] = cconj(adj02); res.u[3] = cconj(adj03); }
-    else if (j == 1) { res.u[0] = adj01; res.u[1] = {bd[1], 0}; res.u[2] = cconj(adj12); res.u[3] = cconj(adj13); }
-    else if (j == 2) { res.u[0] = adj02; res.u[1] = adj12; res.u[2] = {bd[2], 0}; res.u[3] = cconj(adj23); }
-    else { res.u[0] = adj03; res.u[1] = adj13; res.u[2] = adj23; res.u[3] = {bd[3], 0}; }
+    // column j of adj(B): u_i = adj_{ij}; adj is Hermitian, so entry (a,b), a<b, serves column b directly and column a
+    // conjugated.  Each entry is folded into u as soon as it is formed (keeps the live register set small).
+    res.u[0] = {j == 0 ? bd[0] : (T)0, (T)0};
+    res.u[1] = {j == 1 ? bd[1] : (T)0, (T)0};
+    res.u[2] = {j == 2 ? bd[2] : (T)0, (T)0};
+    res.u[3] = {j == 3 ? bd[3] : (T)0, (T)0};
+    auto put = [&](const int a, const int b, const cplx<T> v) {
+        if (j == b) res.u[a] = v;
+        if (j == a) res.u[b] = cconj(v);
+    };
+    put(0, 1, csub(csub(cmul(b02, n.c4), rmul(n.c5, b01)), cmul(b03, n.c3)));                    // -a01 c5 + a02 c4 - a03 c3
+    put(0, 2, cadd(csub(cmul(cconj(b13), n.s5), cmul(cconj(b23), n.s4)), rmul(B.d[3], n.s3)));   //  a31 s5 - a32 s4 + a33 s3
+    put(0, 3, csub(csub(rmul(B.d[2], n.s4), cmul(cconj(b12), n.s5)), cmul(b23, n.s3)));          // -a21 s5 + a22 s4 - a23 s3
+    put(1, 2, csub(csub(cmul(cconj(b23), n.s2), cmul(cconj(b03), n.s5)), rmul(B.d[3], n.s1)));   // -a30 s5 + a32 s2 - a33 s1
+    put(1, 3, cadd(csub(cmul(cconj(b02), n.s5), rmul(B.d[2], n.s2)), cmul(b23, n.s1)));          //  a20 s5 - a22 s2 + a23 s1
+    put(2, 3, csub(csub(cmul(cconj(b12), n.s2), cmul(cconj(b02), n.s4)), rmul(n.s0, b23)));      // -a20 s4 + a21 s2 - a23 s0
     if (!(best > (T)0)) { // A == mu1 I numerically (fully degenerate): any vector; match LAPACK's identity column
         res.u[0] = {(T)1, (T)0};
         res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
