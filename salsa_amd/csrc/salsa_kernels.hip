@@ -378,15 +378,23 @@ constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
 #ifndef TR_WAVES_N
 #define TR_WAVES_N 8
 #endif
+#ifndef TR_WRITELANE_NOP
+#define TR_WRITELANE_NOP 1 // REQUIRED: without the wait states v_writelane reads the v_cmp result (SGPR pair / VCC written
+                           // by the preceding VALU op) stale -- measured: wrong gate masks, parity test fails
+#endif
 constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
 
 // old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform value `val`.
-// (ROCm 7.2's clang does not expose __builtin_amdgcn_writelane; the data operand written by the preceding v_cmp has no
-// documented VALU->v_writelane hazard, the s_nop is a cheap margin.)
+// (ROCm 7.2's clang does not expose __builtin_amdgcn_writelane, hence inline asm; hipcc pads nothing inside an asm
+// statement, so the VALU-writes-SGPR -> v_writelane wait states are in the string: see TR_WRITELANE_NOP.)
 template <int DUMMY>
 __device__ __forceinline__ int writelane_const(int val, const int lane, int old)
 {
+#if TR_WRITELANE_NOP
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
+#else
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
+#endif
     return old;
 }
 

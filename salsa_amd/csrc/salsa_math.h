@@ -470,7 +470,15 @@ SALSA_HD bool tracker_step(double &floor, int &countdown, double mag)
 #endif
     const bool above = mag > floor;
     countdown = above ? countdown - 1 : 3;
-    floor = fmax(above ? pa : pb, 1e-6);
+    const double sel = above ? pa : pb;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one v_max_f64: fmax() would first canonicalise its operand (a second v_max on the dependent chain); sel is a
+    // product of finite numbers, never a signalling NaN
+    const double lim = 1e-6;
+    asm("v_max_f64 %0, %1, %2" : "=v"(floor) : "v"(sel), "v"(lim));
+#else
+    floor = fmax(sel, 1e-6);
+#endif
     return mag > 1.5 * floor;
 }
 

@@ -52,3 +52,12 @@ def test_no_silent_cpu_fallback():
         extract_normalized_eigenvector(np.zeros((2, 8, 4), np.complex64))
     with pytest.raises(ValueError):
         extract_normalized_eigenvector(np.zeros((2, 8, 4), np.complex64), audio_format='xyz')
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: with libsalsa_hip.so absent the binding raises and names the build command."""
+    from salsa_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libsalsa_hip.so'))
+    with pytest.raises(RuntimeError, match='hipcc'):
+        _lib.load()
