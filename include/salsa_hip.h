@@ -110,6 +110,11 @@ int salsa_scaler_accumulate(const float *d_feat, int batch, int n_channels, int6
 int salsa_normalize_batch(float *d_feat, int batch, int n_channels, int64_t n_frames, int n_freq, int n_scaler_channels,
                           const float *d_mean, const float *d_std, void *hip_stream);
 
+/* Fuse normalise-on-load into the extraction: with a scaler attached, salsa_extract_batch writes (x - mean) / std for the
+ * 4 spectrogram channels (same float32 arithmetic as salsa_normalize_batch), saving the separate pass over the features.
+ * d_mean / d_std: device float32 [4][F], caller-owned, must outlive the calls; (NULL, NULL) detaches. */
+int salsa_plan_set_scaler(salsa_plan *plan, const float *d_mean, const float *d_std);
+
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
  * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the
  * milliseconds of the last call's launches in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */

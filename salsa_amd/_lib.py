@@ -57,6 +57,7 @@ def load():
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
     L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
+    L.salsa_plan_set_scaler.argtypes = [vp, vp, vp]
     L.salsa_gru_scan_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_gru_scan_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
@@ -72,5 +73,5 @@ def last_error() -> str:
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
-           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch']
+           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_bwd']

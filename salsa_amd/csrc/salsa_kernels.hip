@@ -62,6 +62,8 @@ struct KParams {
     double cond;
     double inv_cond;      // 1/cond (0 when cond == 0: unused, cond <= 1 short-circuits the gate)
     double delta;         // 2 pi fs / (n_fft * 343)
+    const float *sc_mean; // optional fused normalise-on-load of the spectrogram channels: [4][F] mean / std, or NULL
+    const float *sc_std;
 };
 
 constexpr int FEATURE_LOGSPEC_ONLY = 3;
@@ -231,6 +233,11 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
     const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
+    // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
+    auto spec = [&](const float p, const int c, const int f) -> float {
+        const float v = db10(p);
+        return kp.sc_mean ? (v - kp.sc_mean[c * kp.F + f]) / kp.sc_std[c * kp.F + f] : v;
+    };
     float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
 
     for (int item = 0; item < nitems; item++) {
@@ -304,8 +311,8 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
                     st_stream(&xs[(t * 2 + pr) * kp.nd + (k - kp.lower)], make_float4(xa.x, xa.y, xb.x, xb.y));
                 if (k >= 1 && k <= kp.ident) {
-                    st_stream(&o[(c0 * Tn + t) * kp.F + (k - 1)], db10(pa));
-                    st_stream(&o[((c0 + 1) * Tn + t) * kp.F + (k - 1)], db10(pb));
+                    st_stream(&o[(c0 * Tn + t) * kp.F + (k - 1)], spec(pa, c0, k - 1));
+                    st_stream(&o[((c0 + 1) * Tn + t) * kp.F + (k - 1)], spec(pb, c0 + 1, k - 1));
                 } else if (k > kp.ident && k < N / 2) {
                     pw[w][0][k - kp.ident - 1] = pa;
                     pw[w][1][k - kp.ident - 1] = pb;
@@ -314,8 +321,8 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
                 if (pr == 0) x0k = xa;
                 if (k >= kp.lower && k < kp.cutoff) {
                     const int f = k - kp.lower;
-                    o[(c0 * Tn + t) * kp.F + f] = db10(pa);
-                    o[((c0 + 1) * Tn + t) * kp.F + f] = db10(pb);
+                    o[(c0 * Tn + t) * kp.F + f] = spec(pa, c0, f);
+                    o[((c0 + 1) * Tn + t) * kp.F + f] = spec(pb, c0 + 1, f);
                     const float2 x0 = x0k;
                     // angle(X_c conj(X_0)) / (delta*k) (lite :111-115) or / pi (ipd :113).  float32 throughout: the
                     // product's rounding moves the angle by <= 1e-7 rad and 1/(delta*k) is the float64 quotient rounded
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
                 const int cnt = gi < ng - 1 ? 8 : 7;
                 float acc = 0.f;
                 for (int q = 0; q < cnt; q++) acc += 0.125f * pw[w][h][8 * gi + q];
-                o[((c0 + h) * Tn + t) * kp.F + kp.ident + gi] = db10(acc);
+                o[((c0 + h) * Tn + t) * kp.F + kp.ident + gi] = spec(acc, c0 + h, kp.ident + gi);
             }
         }
         wave_lds_fence(); // this item's LDS reads are done before the next item's first pass overwrites z / pw
@@ -748,6 +755,7 @@ struct salsa_plan {
     double delta;
     double *d_window;
     cplx<double> *d_tw;
+    const float *sc_mean, *sc_std; // caller-owned device arrays set by salsa_plan_set_scaler (or NULL)
     int timing;
     int n_kernels;
     hipEvent_t ev0[SALSA_MAX_KERNELS], ev1[SALSA_MAX_KERNELS]; // start/stop of each launch (timing mode only)
@@ -940,6 +948,8 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.cond = pl->p.cond_num;
     kp.inv_cond = pl->p.cond_num > 0 ? 1.0 / pl->p.cond_num : 0.0;
     kp.delta = pl->delta;
+    kp.sc_mean = pl->sc_mean;
+    kp.sc_std = pl->sc_std;
     return kp;
 }
 
@@ -1060,6 +1070,7 @@ int salsa_logspec_batch(salsa_plan *pl, const float *d_audio, int batch, int n_c
     KParams kp = make_kparams(pl, batch, n_samples);
     kp.feature = FEATURE_LOGSPEC_ONLY;
     kp.OC = 4;
+    kp.sc_mean = kp.sc_std = nullptr; // MagStftExtractor.extract returns raw dB
     kp.layout = SALSA_LAYOUT_PLANAR;
     kp.F = freq_dim(pl->p.n_fft, pl->p.is_compress_high_freq);
     kp.ident = pl->p.is_compress_high_freq ? (pl->p.n_fft == 512 ? 192 : 96) : pl->p.n_fft / 2;
@@ -1160,6 +1171,14 @@ static int ensure_group_streams(salsa_plan *pl)
     for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming) == hipSuccess;
     return ok ? SALSA_OK : fail(SALSA_EHIP, "stream / event creation failed%s");
+}
+
+int salsa_plan_set_scaler(salsa_plan *pl, const float *d_mean, const float *d_std)
+{
+    if (!pl || ((d_mean == nullptr) != (d_std == nullptr))) return fail(SALSA_EINVAL, "salsa_plan_set_scaler: bad argument%s");
+    pl->sc_mean = d_mean;
+    pl->sc_std = d_std;
+    return SALSA_OK;
 }
 
 int salsa_plan_set_groups(salsa_plan *pl, int n_groups)

@@ -159,6 +159,21 @@ class SalsaExtractor:
     def set_timing(self, enable: bool):
         self.L.salsa_plan_set_timing(self._plan, int(bool(enable)))
 
+    def set_scaler(self, mean=None, std=None):
+        """Attach (or detach with None) the feature scaler: extract() then returns the spectrogram channels already
+        normalised, (x - mean) / std per frequency (dataset/database.py:197-202), fused into the STFT kernel's stores."""
+        if mean is None:
+            self._scaler = None
+            rc = self.L.salsa_plan_set_scaler(self._plan, None, None)
+        else:
+            F = self.output_shape(self.params.n_fft)[2]
+            m = torch.as_tensor(mean, dtype=torch.float32).reshape(4, F).contiguous().to(self.device)
+            s = torch.as_tensor(std, dtype=torch.float32).reshape(4, F).contiguous().to(self.device)
+            self._scaler = (m, s)                                   # keep the device arrays alive
+            rc = self.L.salsa_plan_set_scaler(self._plan, C.c_void_p(m.data_ptr()), C.c_void_p(s.data_ptr()))
+        if rc:
+            _raise(rc)
+
     def set_groups(self, n_groups: int):
         """Clip-group pipelining depth of extract() (1 = single stream)."""
         rc = self.L.salsa_plan_set_groups(self._plan, int(n_groups))

@@ -399,3 +399,21 @@ def test_channel_permutation_equivariance(dev):
     assert np.array_equal(f[:2], g[:2])                                    # pair 0 untouched: bit-identical
     np.testing.assert_allclose(f[[3, 2]], g[2:4], rtol=0, atol=2e-5)       # pair 1 packs (y3 + i*y2): other rounding path
     np.testing.assert_allclose(f[[4, 6, 5]], g[4:], rtol=1e-5, atol=1e-6)
+
+
+def test_fused_scaler_equals_separate_normalisation(dev):
+    from salsa_amd.extractor import normalize_
+    ys = np.stack([synth_clip(950 + i, 3 * 24000) for i in range(2)])
+    a = torch.from_numpy(ys).to(dev)
+    rng = np.random.RandomState(3)
+    mean = (rng.randn(4, 1, 200) * 5 - 50).astype(np.float32)
+    std = (rng.rand(4, 1, 200) * 10 + 5).astype(np.float32)
+    ex = _extractor()
+    raw = ex.extract(a).clone()
+    ref = normalize_(raw.clone(), torch.from_numpy(mean), torch.from_numpy(std))
+    ex.set_scaler(mean, std)
+    fused = ex.extract(a).clone()
+    assert torch.equal(fused, ref)                               # same float32 arithmetic, bit-identical
+    np.testing.assert_allclose(ref[:, :4].cpu().numpy(), (raw[:, :4].cpu().numpy() - mean) / std, rtol=1e-6, atol=1e-6)
+    ex.set_scaler(None)
+    assert torch.equal(ex.extract(a), raw)
