@@ -110,3 +110,17 @@ int hostemu_eigvec(const float *X, int nb, long nt, double cond, int n_hop, int 
 long hostemu_reflect(long i, long N) { return reflect_index(i, N); }
 
 } // extern "C"
+
+extern "C" {
+// Direct access to the per-bin solver: R packed as d[4], o[6] (re,im) -> rank1 flag, u[4] (re,im)
+int hostemu_solve(const double *d, const double *o, double cond, int need_vec, int *rank1, double *u)
+{
+    herm4<double> R;
+    for (int i = 0; i < 4; i++) R.d[i] = d[i];
+    for (int k = 0; k < 6; k++) R.o[k] = {o[2 * k], o[2 * k + 1]};
+    eig_result<double> er = herm4_gate_eigvec(R, cond, cond > 0 ? 1.0 / cond : 0.0, need_vec != 0);
+    *rank1 = er.rank1 ? 1 : 0;
+    for (int i = 0; i < 4; i++) { u[2 * i] = er.u[i].re; u[2 * i + 1] = er.u[i].im; }
+    return 0;
+}
+}

@@ -154,3 +154,38 @@ def test_random_spectra_gate_agrees_with_eigh(emu):
             e = e / np.sqrt((e ** 2).sum())
             gap = (w[-1] - w[-2]) / w[-1]
             assert np.abs(out[:, b, t] - e).max() < 1e-10 / max(gap, 1e-6) / max(abs(u[0]) ** 2, 1e-6)
+
+
+def _pack(R):
+    d = np.real(np.diag(R)).copy()
+    idx = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    o = np.array([[R[i, j].real, R[i, j].imag] for i, j in idx]).ravel()
+    return np.ascontiguousarray(d), np.ascontiguousarray(o)
+
+
+def test_solver_stress_controlled_spectra(emu):
+    """The gate/eigenvector solver on Hermitian PSD matrices with prescribed spectra: clustered and repeated eigenvalues,
+    exact rank deficiency, 60 orders of magnitude of scale, ratios hugging the threshold from both sides."""
+    emu.hostemu_solve.argtypes = [C.POINTER(C.c_double)] * 2 + [C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    rng = np.random.RandomState(11)
+    spectra = [(1, 0.19, 0.1, 0.01), (1, 0.21, 0.0, 0.0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 1), (1, 0.199999, 0.199999, 0.0),
+               (1, 0.2 - 1e-9, 0.05, 0.05), (1, 0.2 + 1e-9, 0.2 + 1e-9, 0.1), (1, 0.19, 0.19, 0.19), (1, 1e-12, 1e-13, 0),
+               (1, 0.5, 0.25, 0.125), (1, 0.0999, 0.0999, 0.0999)]
+    for lam in spectra:
+        for scale in (1.0, 1e-30, 1e+30, 3.7e-5):
+            for _ in range(4):
+                Q, _ = np.linalg.qr(rng.randn(4, 4) + 1j * rng.randn(4, 4))
+                lam_a = np.array(lam, float) * scale
+                R = (Q * lam_a) @ Q.conj().T
+                R = (R + R.conj().T) / 2
+                d, o = _pack(R)
+                rank1, u = C.c_int(), np.zeros(8)
+                emu.hostemu_solve(_dp(d), _dp(o), 5.0, 1, C.byref(rank1), _dp(u))
+                expect = lam[0] > 5.0 * lam[1]
+                if abs(lam[0] - 5.0 * lam[1]) > 1e-7:
+                    assert bool(rank1.value) == expect, (lam, scale)
+                if lam[0] - lam[1] > 1e-3:                                 # simple top eigenvalue: vector defined up to phase
+                    uu = u[0::2] + 1j * u[1::2]
+                    q = Q[:, 0]
+                    c = abs(np.vdot(q, uu)) / (np.linalg.norm(uu) + 1e-300)
+                    assert c > 1 - 1e-9, (lam, scale, c)
