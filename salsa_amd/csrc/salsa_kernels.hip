@@ -97,50 +97,15 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Optional streaming (non-temporal) stores for the 1.4 GB of spectrogram rows and spill this kernel never reads back.
-// Measured A/B on MI355X: SLOWER (stft 0.54 vs 0.49 ms) -- the write-back L2 merges the 4-byte row stores into full
-// lines, which nt stores forgo -- so off by default.
-#ifndef K_NT_STORES
-#define K_NT_STORES 0
-#endif
-typedef float native_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_stream(float *p, const float v)
-{
-#if K_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ void st_stream(float4 *p, const float4 v)
-{
-#if K_NT_STORES
-    native_f4 n = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(n, reinterpret_cast<native_f4 *>(p));
-#else
-    *p = v;
-#endif
-}
-
+// (Non-temporal stores for the spectrogram rows / spill were measured SLOWER -- 0.54 vs 0.49 ms: the write-back L2 merges the
+// 4-byte row stores into full lines, which nt stores forgo -- so plain stores are used throughout.)
 __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
-#ifndef GRID_CLIP_FASTEST
-#define GRID_CLIP_FASTEST 0 // 1 = all blocks of a clip on one XCD (L2 halo sharing); measured SLOWER (cov_eig 0.69 vs 0.53 ms)
-#endif
-#ifndef K1_TW_REGS
-#define K1_TW_REGS 0
-#endif
-#ifndef K1_PREFETCH
-#define K1_PREFETCH 0 // measured: 162 VGPRs / 3 waves per SIMD without the prefetch beats 180 / 2 with it
-#endif
-#ifndef K1_MINWAVES
-#define K1_MINWAVES 1
-#endif
 constexpr int K1_NF = 8;                                          // frames per wave
 constexpr int K1_FRAMES_PER_BLOCK = 4 * K1_NF;
 
 template <int N, typename T, bool LITE>
-__global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+__global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
@@ -152,31 +117,11 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // grid = (clips, frame blocks): linear workgroup id = clip + block * B, and the dispatcher sends id % 8 to one XCD
-    // (observed, speed only): with B a multiple of 8 every block of a clip lands on the same XCD, so the overlap between
-    // consecutive frames (and later K3's +-3-frame halo) is served from that XCD's L2, while the 8 XCDs each own whole
-    // clips and stay balanced.
-    const int b = GRID_CLIP_FASTEST ? blockIdx.x : blockIdx.y;
+    const int b = blockIdx.y;
     const int Ns = kp.N, Tn = kp.T;
-    const int t_begin = ((GRID_CLIP_FASTEST ? blockIdx.y : blockIdx.x) * 4 + w) * K1_NF;
+    const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
     cplx<T> *z = buf[w];
 
-#if K1_TW_REGS
-    T win[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) win[r] = (T)(0.5 * window[salsa::stockham_in(lane, r, N, R)]); // 0.5: the unpack's /2, exact
-    cplx<T> twr[NP][R - 1];
-    {
-        int p = R;
-#pragma unroll
-        for (int q = 0; q < NP; q++, p *= R)
-#pragma unroll
-            for (int r = 1; r < R; r++) {
-                const cplx<double> wd = tw[salsa::stockham_tw(lane, r, p, N, R)];
-                twr[q][r - 1] = {(T)wd.re, (T)wd.im};
-            }
-    }
-#else
     // Register diet (occupancy): only the first twiddle of each pass stays in registers, its powers are rebuilt by a
     // multiplication chain of depth <= 3 (relative error ~4e-16, invisible after the float32 rounding of the spectra);
     // the window (pre-scaled by the unpack's exact 1/2) is shared by the block's waves through LDS.
@@ -192,7 +137,6 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
             w1[q] = {(T)wd.re, (T)wd.im};
         }
     }
-#endif
     if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
     const float *clip = audio + (long)b * 4 * Ns;
     // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
@@ -227,9 +171,6 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
 
     const int nitems = (Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF) * 2;
     float y0[R], y1[R];
-#if K1_PREFETCH
-    load_item(0, y0, y1);
-#endif
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
     const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
@@ -243,23 +184,13 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
     for (int item = 0; item < nitems; item++) {
         const int t = t_begin + (item >> 1);
         const int pr = item & 1;
-#if !K1_PREFETCH
         load_item(item, y0, y1);
-#endif
         cplx<T> v[R];
-#if K1_TW_REGS
-#pragma unroll
-        for (int r = 0; r < R; r++) v[r] = {win[r] * (T)y0[r], win[r] * (T)y1[r]};
-#else
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const T wn = wins[salsa::stockham_in(lane, r, N, R)];
             v[r] = {wn * (T)y0[r], wn * (T)y1[r]};
         }
-#endif
-#if K1_PREFETCH
-        if (item + 1 < nitems) load_item(item + 1, y0, y1); // prefetch: in flight during the passes below
-#endif
         // ---- Stockham passes, in place in the wave-private buffer
         salsa::dftR<R>(v); // pass p = 1 (no twiddles)
 #pragma unroll
@@ -272,10 +203,6 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
 #pragma unroll
                 for (int r = 0; r < R; r++) v[r] = z[swz(salsa::stockham_in(lane, r, N, R))];
                 wave_lds_fence();
-#if K1_TW_REGS
-#pragma unroll
-                for (int r = 1; r < R; r++) v[r] = salsa::cmul(v[r], twr[q][r - 1]);
-#else
                 {
                     const cplx<T> a1 = w1[q], a2 = salsa::cmul(a1, a1), a3 = salsa::cmul(a2, a1);
                     v[1] = salsa::cmul(v[1], a1);
@@ -289,7 +216,6 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
                         v[7 % R] = salsa::cmul(v[7 % R], salsa::cmul(a4, a3));
                     }
                 }
-#endif
                 salsa::dftR<R>(v);
                 if (q + 1 < NP) {
 #pragma unroll
@@ -309,10 +235,10 @@ __global__ __launch_bounds__(256, K1_MINWAVES) void stft_kernel(const KParams kp
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    st_stream(&xs[(t * 2 + pr) * kp.nd + (k - kp.lower)], make_float4(xa.x, xa.y, xb.x, xb.y));
+                    xs[(t * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
                 if (k >= 1 && k <= kp.ident) {
-                    st_stream(&o[(c0 * Tn + t) * kp.F + (k - 1)], spec(pa, c0, k - 1));
-                    st_stream(&o[((c0 + 1) * Tn + t) * kp.F + (k - 1)], spec(pb, c0 + 1, k - 1));
+                    o[(c0 * Tn + t) * kp.F + (k - 1)] = spec(pa, c0, k - 1);
+                    o[((c0 + 1) * Tn + t) * kp.F + (k - 1)] = spec(pb, c0 + 1, k - 1);
                 } else if (k > kp.ident && k < N / 2) {
                     pw[w][0][k - kp.ident - 1] = pa;
                     pw[w][1][k - kp.ident - 1] = pb;
@@ -385,10 +311,6 @@ constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
 #ifndef TR_WAVES_N
 #define TR_WAVES_N 8
 #endif
-#ifndef TR_WRITELANE_NOP
-#define TR_WRITELANE_NOP 1 // REQUIRED: without the wait states v_writelane reads the v_cmp result (SGPR pair / VCC written
-                           // by the preceding VALU op) stale -- measured: wrong gate masks, parity test fails
-#endif
 constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
 
 // old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform value `val`.
@@ -397,11 +319,7 @@ constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
 template <int DUMMY>
 __device__ __forceinline__ int writelane_const(int val, const int lane, int old)
 {
-#if TR_WRITELANE_NOP
     asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
-#else
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
-#endif
     return old;
 }
 
@@ -526,27 +444,8 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 #endif
 constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gate words sit in one chunk
 
-#ifndef K3_MINWAVES
-#define K3_MINWAVES 1
-#endif
-#ifndef K3_LOAD_SPLIT
-#define K3_LOAD_SPLIT 0
-#endif
-#ifndef K3_UNROLLED_LOADS
-#define K3_UNROLLED_LOADS 1
-#endif
-#ifndef K3_XCD_SWIZZLE
-#define K3_XCD_SWIZZLE 0 // measured: 0.59 vs 0.54 ms -- bursts occupy ~25 % of a clip's time, so giving an XCD a contiguous
-                         // time range trades halo L2 hits for a 3x load imbalance between XCDs
-#endif
-// bijective remap of a 1-D grid so that the blocks the dispatcher sends to one XCD (id % 8) cover a contiguous range
-__device__ __forceinline__ int xcd_remap(int id, int n)
-{
-    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 template <bool FEAT, int NHOP>
-__global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+__global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned long long *__restrict__ valid,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
@@ -554,11 +453,9 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
     __shared__ unsigned short list[K3_FT * 256];
     __shared__ int count;
     const int tid = threadIdx.x;
-    const int b = GRID_CLIP_FASTEST ? blockIdx.x : blockIdx.y;
+    const int b = blockIdx.y;
     const int Tn = kp.T;
-    // XCD-aware tile order: workgroup i runs on XCD i % 8 (observed dispatch, speed only).  Give each XCD a contiguous
-    // run of time tiles so the +-3-frame halo a tile shares with its neighbours is served by that XCD's own L2.
-    const int tile = GRID_CLIP_FASTEST ? (int)blockIdx.y : (K3_XCD_SWIZZLE ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x);
+    const int tile = blockIdx.x;
     const int t0 = tile * K3_FT;
     const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
     const int bin0 = blockIdx.z * 256;
@@ -632,32 +529,23 @@ __global__ __launch_bounds__(256, K3_MINWAVES) void cov_eig_kernel(const KParams
         salsa::herm4<double> R = {};
         const float4 *xb = xclip + bin;
         if (NHOP >= 0) {
-            // the 2*NHOP+1 frames in two batches of independent 16-B loads: all 14 at once costs 56 VGPRs and a wave
-            // per SIMD; two batches keep the kernel at 4 waves/SIMD
+            // all 2*NHOP+1 frames as independent 16-B loads issued together (splitting them into batches to save VGPRs
+            // was measured slower: the loads' latency is what this kernel hides)
             constexpr int NW = NHOP >= 0 ? 2 * NHOP + 1 : 1;
-            constexpr int NA = K3_LOAD_SPLIT ? (NW + 1) / 2 : NW;
+            float4 xa[NW], xc[NW];
 #pragma unroll
-            for (int k0 = 0; k0 < NW; k0 += NA) {
-                float4 xa[NA], xc[NA];
+            for (int k = 0; k < NW; k++) {
+                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                xa[k] = xb[tt * stride];
+                xc[k] = xb[tt * stride + kp.nd];
+            }
 #pragma unroll
-                for (int k = 0; k < NA; k++) {
-                    if (k0 + k < NW) {
-                        int tt = t + k0 + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
-                        while (tt < 0) tt += Tn;
-                        while (tt >= Tn) tt -= Tn;
-                        xa[k] = xb[tt * stride];
-                        xc[k] = xb[tt * stride + kp.nd];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NA; k++) {
-                    if (k0 + k < NW) {
-                        const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
-                                                   {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
-                        salsa::herm4_rank1_add(R, x);
-                    }
-                }
-                if (K3_LOAD_SPLIT) __builtin_amdgcn_sched_barrier(0); // keep the batches apart (the scheduler would re-merge them)
+            for (int k = 0; k < NW; k++) {
+                const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
+                                           {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
+                salsa::herm4_rank1_add(R, x);
             }
         } else {
             for (int k = -nhop; k <= nhop; k++) {
@@ -686,7 +574,7 @@ template <bool FEAT>
 static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned long long *valid,
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
-    if (kp.n_hop == 3 && K3_UNROLLED_LOADS)
+    if (kp.n_hop == 3)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
@@ -972,7 +860,7 @@ static void mark_end(salsa_plan *pl, hipStream_t s, int i)
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
     const unsigned nblk = (unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK);
-    dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)kp.B, nblk) : dim3(nblk, (unsigned)kp.B);
+    dim3 grid(nblk, (unsigned)kp.B);
     const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
     if (pl->p.n_fft == 512) {
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
@@ -1036,7 +924,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
-        dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)gp.B, ntile, (unsigned)((gp.nd + 255) / 256)) : dim3(ntile, (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
+        dim3 grid(ntile, (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
         launch_cov_eig<true>(gp, grid, s2, xs, vm, o, (double *)nullptr, (unsigned char *)nullptr);
         mark_end(pl, s2, m);
         HIP_TRY(hipGetLastError());
@@ -1104,7 +992,7 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
         HIP_TRY(hipGetLastError());
     }
     const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);
-    dim3 grid = GRID_CLIP_FASTEST ? dim3((unsigned)kp.B, ntile, (unsigned)((n_bins + 255) / 256)) : dim3(ntile, (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
+    dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
     launch_cov_eig<false>(kp, grid, s, Xs, valid, (float *)nullptr, d_out, d_gate);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
