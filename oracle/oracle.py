@@ -39,6 +39,9 @@ def lib():
         L.salsa_oracle_extract_salsa.argtypes = [fp, C.c_long] + [C.c_int] * 6 + [C.c_double] + [C.c_int] * 4 + \
                                                 [fp, up, dp]
         L.salsa_oracle_extract_lite.argtypes = [fp, C.c_long] + [C.c_int] * 7 + [fp]
+        L.salsa_oracle_flex_bins.argtypes = [C.c_int] * 5 + [ip, ip, ip]
+        L.salsa_oracle_flex.argtypes = [fp, C.c_int, C.c_long] + [C.c_int] * 9 + [C.c_double, C.c_int, C.c_int,
+                                                                                   C.c_double, fp, dp]
         _lib = L
     return _lib
 
@@ -183,3 +186,26 @@ def compute_scaler(features):
     mean = shift + s / n
     var = ss / n - (s / n) ** 2
     return mean[:, None, :].astype(np.float32), np.sqrt(var)[:, None, :].astype(np.float32)
+
+
+def flexible(audio, kind='salsa', fs=24000, stft_winsize=512, hop_length=300, fmin_doa=50, fmax_doa=2000,
+             fmax_spec=9000, clip_freqs=True, clip_spatial_alias=False, ew_thresh=5.0, covmat_avg_neighbours=3,
+             is_tracking=True, floor_mask_ratio=1.5):
+    """contrib/salsa_flexible.py SalsaFeatures / SalsaLiteFeatures __call__ (:237-265): (C, N) float32 ->
+    (2C-1, F, T) float64 (freq-major, like the reference)."""
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    Cn, N = audio.shape
+    lo, up, cut = C.c_int(), C.c_int(), C.c_int()
+    if lib().salsa_oracle_flex_bins(fs, stft_winsize, fmin_doa, fmax_doa, fmax_spec, C.byref(lo), C.byref(up), C.byref(cut)):
+        raise AssertionError('Upper bin for spatial feature is higher than cutoff bin for spectrogram!')
+    nb = stft_winsize // 2 + 1
+    F = (min(cut.value, nb) - lo.value) if clip_freqs else nb
+    T = n_frames(N, hop_length)
+    spec = np.empty((Cn, F, T), np.float32)
+    spat = np.empty((Cn - 1, F, T), np.float64)
+    rc = lib().salsa_oracle_flex(_fp(audio), Cn, N, fs, stft_winsize, hop_length, fmin_doa, fmax_doa, fmax_spec,
+                                 int(kind == 'lite'), int(clip_freqs), int(clip_spatial_alias), float(ew_thresh),
+                                 int(covmat_avg_neighbours), int(is_tracking), float(floor_mask_ratio), _fp(spec), _dp(spat))
+    if rc != F:
+        raise ValueError('salsa_oracle_flex failed: %d' % rc)
+    return np.concatenate([spec.astype(np.float64), spat])

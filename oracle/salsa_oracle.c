@@ -470,3 +470,170 @@ int salsa_oracle_extract_lite(const float *audio, long N, int fs, int n_fft, int
     free(st);
     return 0;
 }
+
+/* ================================================================================================ contrib on-the-fly
+ * contrib/salsa_flexible.py: SpatialFeaturesAbstract.__init__ (:169-193), .spectrograms (:195-221),
+ * .__call__ (:237-265), SalsaNoiseFloorTracker (:80-146), stacked_covmat_eigh (:52-77), SalsaFeatures.features
+ * (:286-367), SalsaLiteFeatures.features (:386-400).  Arbitrary channel count (here 2..SALSA_FLEX_MAXCH).
+ *
+ * n x n Hermitian eigen-decomposition standing in for np.linalg.eigh(covmats, UPLO='U') (:75): cyclic complex Jacobi in
+ * float64, eigenvalues returned ASCENDING and signed like LAPACK's, v = eigenvector of the largest one (any unit phase:
+ * :362 only uses conj(v0)*v_i). */
+#define SALSA_FLEX_MAXCH 8
+static void hermn_eigh(int n, double ar[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH], double ai[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH],
+                       double *lam, double *vr, double *vi)
+{
+    double Vr[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH] = {{0}}, Vi[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH] = {{0}};
+    for (int i = 0; i < n; i++) Vr[i][i] = 1.0;
+    for (int sweep = 0; sweep < 80; sweep++) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < n; p++) {
+            diag += ar[p][p] * ar[p][p];
+            for (int q = p + 1; q < n; q++) off += ar[p][q] * ar[p][q] + ai[p][q] * ai[p][q];
+        }
+        if (off <= 1e-34 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double br = ar[p][q], bi = ai[p][q], b = hypot(br, bi);
+                if (b == 0.0) continue;
+                const double er = br / b, ei = bi / b;
+                const double theta = (ar[q][q] - ar[p][p]) / (2.0 * b);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) { /* A <- A J */
+                    const double pr = ar[k][p], pi = ai[k][p], qr = ar[k][q], qi = ai[k][q];
+                    const double cqr = qr * er + qi * ei, cqi = qi * er - qr * ei;
+                    ar[k][p] = c * pr - s * cqr; ai[k][p] = c * pi - s * cqi;
+                    ar[k][q] = s * pr + c * cqr; ai[k][q] = s * pi + c * cqi;
+                }
+                for (int k = 0; k < n; k++) { /* A <- J^H A */
+                    const double pr = ar[p][k], pi = ai[p][k], qr = ar[q][k], qi = ai[q][k];
+                    const double eqr = qr * er - qi * ei, eqi = qi * er + qr * ei;
+                    ar[p][k] = c * pr - s * eqr; ai[p][k] = c * pi - s * eqi;
+                    ar[q][k] = s * pr + c * eqr; ai[q][k] = s * pi + c * eqi;
+                }
+                ar[p][q] = ai[p][q] = ar[q][p] = ai[q][p] = 0.0;
+                ai[p][p] = ai[q][q] = 0.0;
+                for (int k = 0; k < n; k++) { /* V <- V J */
+                    const double pr = Vr[k][p], pi = Vi[k][p], qr = Vr[k][q], qi = Vi[k][q];
+                    const double cqr = qr * er + qi * ei, cqi = qi * er - qr * ei;
+                    Vr[k][p] = c * pr - s * cqr; Vi[k][p] = c * pi - s * cqi;
+                    Vr[k][q] = s * pr + c * cqr; Vi[k][q] = s * pi + c * cqi;
+                }
+            }
+    }
+    int idx[SALSA_FLEX_MAXCH];
+    for (int i = 0; i < n; i++) idx[i] = i;
+    for (int i = 0; i < n - 1; i++)
+        for (int j = i + 1; j < n; j++)
+            if (ar[idx[j]][idx[j]] < ar[idx[i]][idx[i]]) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+    for (int i = 0; i < n; i++) lam[i] = ar[idx[i]][idx[i]];
+    for (int k = 0; k < n; k++) { vr[k] = Vr[k][idx[n - 1]]; vi[k] = Vi[k][idx[n - 1]]; }
+}
+
+/* Bin limits of SpatialFeaturesAbstract.__init__ (:177-184): like the dataset scripts' but WITHOUT the fs/2 clamp on
+ * fmax_doa and with the spectrogram cutoff taken from fmax_spec.  Returns -4 for the assert at :183. */
+int salsa_oracle_flex_bins(int fs, int n_fft, int fmin_doa, int fmax_doa, int fmax_spec, int *lower, int *upper, int *cutoff)
+{
+    int lo = (int)floor((double)((long)fmin_doa * n_fft) / (double)fs);
+    if (lo < 1) lo = 1;
+    *lower = lo;
+    *upper = (int)floor((double)((long)fmax_doa * n_fft) / (double)fs);
+    *cutoff = (int)floor((double)((long)fmax_spec * n_fft) / (double)fs);
+    return *upper <= *cutoff ? 0 : -4;
+}
+
+/* obj(wavchans, clip_freqs, clip_spatial_alias, **kw) of SalsaFeatures (lite = 0) / SalsaLiteFeatures (lite = 1).
+ * audio [C][N] float32 -> out_spec [C][F][T] float32 (the float32 values the reference upcasts at :264) and
+ * out_spatial [C-1][F][T] float64; F = cutoff-lower (clip_freqs) or n_fft/2+1.  Returns F, or a negative error. */
+int salsa_oracle_flex(const float *audio, int C, long N, int fs, int n_fft, int hop, int fmin_doa, int fmax_doa,
+                      int fmax_spec, int lite, int clip_freqs, int clip_alias, double ew_thresh, int n_neigh,
+                      int tracking, double floor_mask_ratio, float *out_spec, double *out_spatial)
+{
+    if (C < 2 || C > SALSA_FLEX_MAXCH) return -2;
+    int lower, upper, cutoff;
+    if (salsa_oracle_flex_bins(fs, n_fft, fmin_doa, fmax_doa, fmax_spec, &lower, &upper, &cutoff)) return -4;
+    const int nb = n_fft / 2 + 1;
+    const int lo = clip_freqs ? lower : 0, hi = clip_freqs ? (cutoff < nb ? cutoff : nb) : nb; /* numpy slicing clips */
+    const int F = hi - lo;
+    if (F <= 0) return -3;
+    const long T = salsa_oracle_n_frames(N, hop);
+    const double delta = 2.0 * M_PI * fs / (n_fft * 343.0); /* :186 */
+    float *st = (float *)malloc(sizeof(float) * 2 * (size_t)nb * T * C);
+    for (int c = 0; c < C; c++) salsa_oracle_stft(audio + (size_t)c * N, N, n_fft, hop, n_fft, st + (size_t)c * 2 * nb * T);
+#define STF(c, k, t) (st + (size_t)(c) * 2 * nb * T + ((size_t)(k) * T + (t)) * 2)
+    memset(out_spatial, 0, sizeof(double) * (size_t)(C - 1) * F * T);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int f = 0; f < F; f++) {
+        const int k = f + lo;
+        /* norm_freq (:188-190): float32 arange, [0] = 1, multiplied IN float32 by delta */
+        const double nf = (double)((float)(k == 0 ? 1 : k) * (float)delta);
+        for (int c = 0; c < C; c++) /* :211-215 float32 power and dB */
+            for (long t = 0; t < T; t++) {
+                const float *x = STF(c, k, t);
+                const float a = hypotf(x[0], x[1]);
+                out_spec[((size_t)c * F + f) * T + t] = 10.0f * log10f(fmaxf(1e-10f, a * a));
+            }
+        if (lite) { /* :397-399 */
+            for (int c = 1; c < C; c++)
+                for (long t = 0; t < T; t++) {
+                    const float *x0 = STF(0, k, t), *xc = STF(c, k, t);
+                    const double pr = (double)x0[0] * xc[0] + (double)x0[1] * xc[1];
+                    const double pi = (double)x0[0] * xc[1] - (double)x0[1] * xc[0]; /* conj(X0) * Xc */
+                    out_spatial[((size_t)(c - 1) * F + f) * T + t] = atan2(pi, pr) / nf;
+                }
+            continue;
+        }
+        /* :326-333 raw |X0| and the initial floor (clamped to epsilon by the tracker's constructor :118-120) */
+        double floor_ = 0.0;
+        const long n0 = T < 5 ? T : 5;
+        for (long t = 0; t < n0; t++) floor_ += hypot((double)STF(0, k, t)[0], (double)STF(0, k, t)[1]);
+        floor_ = 0.5 * (floor_ / (double)n0);
+        if (floor_ < 1e-6) floor_ = 1e-6;
+        long count = 0; /* :123 */
+        int alive = 1;  /* is_tracking=False: ONE allpass mask array is created (:336-337) and then narrowed in place by
+                           'mask[mask] = good_coherence_mask' (:354) -- a bin that fails once stays off for the clip */
+        for (long t = 0; t < T; t++) {
+            const double m = hypot((double)STF(0, k, t)[0], (double)STF(0, k, t)[1]);
+            int mask;
+            if (tracking) { /* SalsaNoiseFloorTracker.__call__ :125-146 */
+                const int above = m > floor_;
+                count += above;
+                if (above && count <= 3) floor_ *= 1.02;
+                if (above && count > 3) floor_ *= 1.002;
+                if (!above) floor_ *= 0.98;
+                if (floor_ < 1e-6) floor_ = 1e-6;
+                if (!above) count = 0;
+                mask = m > floor_mask_ratio * floor_;
+            } else {
+                mask = alive;
+            }
+            if (!mask) continue;
+            double ar[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH] = {{0}}, ai[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH] = {{0}};
+            for (int d = -n_neigh; d <= n_neigh; d++) { /* :347-349, :70-74: SUM (not mean) of x_i conj(x_j), wrap in time */
+                const long tt = ((t + d) % T + T) % T;
+                for (int i = 0; i < C; i++)
+                    for (int j = 0; j < C; j++) {
+                        const float *xi = STF(i, k, tt), *xj = STF(j, k, tt);
+                        ar[i][j] += (double)xi[0] * xj[0] + (double)xi[1] * xj[1];
+                        ai[i][j] += (double)xi[1] * xj[0] - (double)xi[0] * xj[1];
+                    }
+            }
+            double lam[SALSA_FLEX_MAXCH], ur[SALSA_FLEX_MAXCH], ui[SALSA_FLEX_MAXCH];
+            hermn_eigh(C, ar, ai, lam, ur, ui);
+            const int good = lam[C - 1] > lam[C - 2] * ew_thresh; /* :353 */
+            if (!tracking) alive = good;
+            if (!good) continue;
+            for (int i = 1; i < C; i++) { /* :362-363 angle(conj(u0) u_i) / norm_freq */
+                const double pr = ur[0] * ur[i] + ui[0] * ui[i], pi = ur[0] * ui[i] - ui[0] * ur[i];
+                out_spatial[((size_t)(i - 1) * F + f) * T + t] = atan2(pi, pr) / nf;
+            }
+        }
+    }
+    if (clip_alias) /* :262-263 index into the (possibly cropped) axis */
+        for (int i = 0; i < C - 1; i++)
+            for (int f = upper; f < F; f++) memset(out_spatial + ((size_t)i * F + f) * T, 0, sizeof(double) * T);
+#undef STF
+    free(st);
+    return F;
+}

@@ -7,6 +7,7 @@ every array below is an output of the reference's own functions
   dataset/salsa_feature_extraction.py   extract_normalized_eigenvector (:17-129), MagStftExtractor (:132-201),
                                          compute_scaler (:204-262), extract_features (:265-391)
   dataset/salsa_lite_feature_extraction.py  extract_features (:18-137)
+  contrib/salsa_flexible.py             SalsaFeatures / SalsaLiteFeatures (:271-400), the on-the-fly surface
 driven through tools/ref_shims.py (librosa 0.8.0 / h5py / fire stand-ins -- third-party arithmetic restated there).
 Inputs are regenerated from seeds by salsa_amd/synth.py; each fixture stores the SHA-256 of every input so a drifted
 generator is detected.  Fixtures hold data only (inputs' hashes, parameters, expected outputs).
@@ -245,6 +246,49 @@ def g8_stft():
     save('g8_stft', {'seed': 151, 'n': 6000, 'sha': sha256_of(y), 'torch_rel_err': float(err)}, stft=S)
 
 
+# ----------------------------------------------------------------------------------------------- G10: contrib on-the-fly
+def g10_flexible():
+    """contrib/salsa_flexible.py: SalsaFeatures / SalsaLiteFeatures called as their docstrings show.
+    Spectrogram channels are stored as float32 (their working dtype), spatial channels as float64."""
+    import importlib.util
+    if not hasattr(np, 'bool'):
+        np.bool = bool        # removed in numpy >= 1.24; used at contrib/salsa_flexible.py:335
+    spec = importlib.util.spec_from_file_location('ref_salsa_flexible',
+                                                  os.path.join(ref_shims.REF_ROOT, 'contrib', 'salsa_flexible.py'))
+    flex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(flex)
+    n = 27000                                                     # 1.125 s -> 91 frames
+    cases = [  # name, kind, seed, n_ch, ctor kwargs, call kwargs
+        ('salsa_default', 'salsa', 171, 4, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('salsa_alias', 'salsa', 172, 4, {}, dict(clip_freqs=True, clip_spatial_alias=True)),
+        ('salsa_full_axis', 'salsa', 173, 4, {}, dict(clip_freqs=False, clip_spatial_alias=True)),
+        ('salsa_notrack', 'salsa', 174, 4, {}, dict(clip_freqs=True, clip_spatial_alias=False, is_tracking=False)),
+        ('salsa_kwargs', 'salsa', 175, 4, dict(fmin_doa=100, fmax_doa=4000, fmax_spec=8000),
+         dict(clip_freqs=True, clip_spatial_alias=True, ew_thresh=3.0, covmat_avg_neighbours=2, floor_mask_ratio=2.0)),
+        ('salsa_3mics', 'salsa', 176, 3, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('salsa_2mics', 'salsa', 177, 2, {}, dict(clip_freqs=True, clip_spatial_alias=True)),
+        ('lite_default', 'lite', 178, 4, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('lite_alias_full_axis', 'lite', 179, 4, {}, dict(clip_freqs=False, clip_spatial_alias=True)),
+        ('lite_2mics', 'lite', 180, 2, {}, dict(clip_freqs=True, clip_spatial_alias=True)),
+    ]
+    arrays, meta = {}, {'n': n, 'fs': 24000, 'stft_winsize': 512, 'hop_length': 300, 'cases': {}}
+    for name, kind, seed, n_ch, ckw, kw in cases:
+        y = synth_clip(seed, n, n_ch=n_ch)
+        ctor = dict(fs=24000, stft_winsize=512, hop_length=300, fmin_doa=50, fmax_doa=2000, fmax_spec=9000)
+        ctor.update(ckw)
+        obj = (flex.SalsaFeatures if kind == 'salsa' else flex.SalsaLiteFeatures)(**ctor)
+        out = obj(y, **kw)
+        assert out.shape[0] == 2 * n_ch - 1 and out.dtype == np.float64
+        arrays[name + '_spec'] = out[:n_ch].astype(np.float32)
+        assert np.array_equal(arrays[name + '_spec'].astype(np.float64), out[:n_ch])   # spectrograms ARE float32 values
+        arrays[name + '_spatial'] = out[n_ch:]
+        meta['cases'][name] = {'kind': kind, 'seed': seed, 'n_ch': n_ch, 'sha': sha256_of(y), 'ctor': ctor, 'call': kw,
+                               'nonzero': float((out[n_ch:] != 0).mean())}
+    save('g10_flexible', meta, **arrays)
+    for k, v in meta['cases'].items():
+        print('   ', k, 'spatial non-zero fraction %.3f' % v['nonzero'])
+
+
 if __name__ == '__main__':
     g5_w_and_bins()
     g1_eigvec()
@@ -252,3 +296,4 @@ if __name__ == '__main__':
     g3_end_to_end()
     g4_lite()
     g8_stft()
+    g10_flexible()
