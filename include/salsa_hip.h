@@ -16,6 +16,7 @@
  *   MagStftExtractor.W, dataset/salsa_feature_extraction.py:152-175               salsa_compress_matrix (host)
  *   compute_scaler, dataset/salsa_feature_extraction.py:204-262                   salsa_scaler_accumulate
  *   Database.load_chunk_data normalisation, dataset/database.py:197-202           salsa_normalize_batch
+ *   SalsaFeatures / SalsaLiteFeatures.__call__, contrib/salsa_flexible.py:237-265 (+ :286-400)   salsa_extract_batch with SALSA_FLAG_FLEX, salsa_to_freq_major
  *
  * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
  * message of the calling thread's last failure.  Device pointers are caller-owned; work is enqueued asynchronously
@@ -32,11 +33,23 @@
 extern "C" {
 #endif
 
-#define SALSA_ABI_VERSION 1
+#define SALSA_ABI_VERSION 2
 
 enum { SALSA_FORMAT_FOA = 0, SALSA_FORMAT_MIC = 1 };                      /* cfg['data']['format'] */
 enum { SALSA_FEATURE_SALSA = 0, SALSA_FEATURE_LITE = 1, SALSA_FEATURE_IPD = 2 }; /* 'salsa' | 'salsa_lite' | 'salsa_ipd' */
 enum { SALSA_LAYOUT_PLANAR = 0, SALSA_LAYOUT_INTERLEAVED = 1 };           /* [B][4][N] (librosa.load) | [B][N][4] (WAV) */
+
+/* salsa_params.flags.  SALSA_FLAG_FLEX selects the semantics of the on-the-fly re-implementation contrib/salsa_flexible.py
+ * (MIC-style features only), which differ from the dataset scripts: the noise-floor tracker follows the raw |X0| (not the
+ * 3-frame RMS) with its initial floor clamped to 1e-6 (:118-120, :326-333); the coherence test gates even without
+ * tracking -- and then switches a bin off for the rest of the clip once it fails (:336-337, :352-354); the frequency
+ * normalisation vector is float32 (:188-190); the log-spectrogram is uncompressed over the SAME band as the spatial
+ * features: bins [lower_bin, cutoff_bin(fmax_spec)) or, with SALSA_FLAG_NO_CLIP_FREQS, all n_fft/2+1 bins
+ * (clip_freqs, :252-257); SALSA_FLAG_CLIP_SPATIAL_ALIAS zeroes spatial rows >= upper_bin of that band
+ * (clip_spatial_alias, :262-263); fmax_doa is not clamped to fs/2.  cond_num = ew_thresh, n_hopframes =
+ * covmat_avg_neighbours.  Fewer than 4 microphones: pad the audio with silent channels (the covariance gains zero
+ * eigenvalues, the gate and the principal eigenvector are unchanged) and drop the padded output channels. */
+enum { SALSA_FLAG_FLEX = 1, SALSA_FLAG_NO_CLIP_FREQS = 2, SALSA_FLAG_CLIP_SPATIAL_ALIAS = 4 };
 
 enum {
     SALSA_OK = 0,
@@ -63,6 +76,9 @@ typedef struct salsa_params {
     int audio_format;          /* SALSA_FORMAT_* */
     int feature_type;          /* SALSA_FEATURE_* */
     int audio_layout;          /* SALSA_LAYOUT_* */
+    int flags;                 /* SALSA_FLAG_* (0 = the dataset scripts' semantics) */
+    double floor_mask_ratio;   /* indicator_sig = mag > ratio * floor; 0 = the reference's 1.5 (:36; contrib kwarg) */
+    int fmax_spec;             /* SALSA_FLAG_FLEX only: spectrogram cutoff in Hz; 0 = 9000 */
     int reserved;
 } salsa_params;
 
@@ -114,6 +130,10 @@ int salsa_normalize_batch(float *d_feat, int batch, int n_channels, int64_t n_fr
  * 4 spectrogram channels (same float32 arithmetic as salsa_normalize_batch), saving the separate pass over the features.
  * d_mean / d_std: device float32 [4][F], caller-owned, must outlive the calls; (NULL, NULL) detaches. */
 int salsa_plan_set_scaler(salsa_plan *plan, const float *d_mean, const float *d_std);
+
+/* Feature rows [n_rows][n_frames][n_freq] float32 (time-major, what salsa_extract_batch writes; n_rows = batch * 7) ->
+ * [n_rows][n_freq][n_frames] float64, the freq-major float64 array contrib/salsa_flexible.py returns (:264). */
+int salsa_to_freq_major(const float *d_feat, int64_t n_rows, int64_t n_frames, int n_freq, double *d_out, void *hip_stream);
 
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
  * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the

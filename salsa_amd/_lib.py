@@ -11,6 +11,7 @@ GRU_SRC_PATH = os.path.join(_HERE, 'csrc', 'gru_scan.hip')
 FORMAT = {'foa': 0, 'mic': 1}
 FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
 LAYOUT = {'planar': 0, 'interleaved': 1}
+FLAG_FLEX, FLAG_NO_CLIP_FREQS, FLAG_CLIP_SPATIAL_ALIAS = 1, 2, 4
 MAX_KERNELS = 32
 
 E_INVAL, E_NFFT, E_FORMAT, E_BINS, E_WORKSPACE, E_HIP = -1, -2, -3, -4, -5, -6
@@ -20,7 +21,8 @@ class SalsaParams(C.Structure):
     _fields_ = [('fs', C.c_int), ('n_fft', C.c_int), ('hop_len', C.c_int), ('win_len', C.c_int),
                 ('fmin_doa', C.c_int), ('fmax_doa', C.c_int), ('cond_num', C.c_double), ('n_hopframes', C.c_int),
                 ('is_tracking', C.c_int), ('is_compress_high_freq', C.c_int), ('audio_format', C.c_int),
-                ('feature_type', C.c_int), ('audio_layout', C.c_int), ('reserved', C.c_int)]
+                ('feature_type', C.c_int), ('audio_layout', C.c_int), ('flags', C.c_int),
+                ('floor_mask_ratio', C.c_double), ('fmax_spec', C.c_int), ('reserved', C.c_int)]
 
 
 _lib = None
@@ -62,6 +64,7 @@ def load():
     L.salsa_gru_scan_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
     L.salsa_normalize_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp]
+    L.salsa_to_freq_major.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -73,5 +76,6 @@ def last_error() -> str:
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
-           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler']
+           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
+           'salsa_to_freq_major']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_bwd']

@@ -53,6 +53,8 @@ struct KParams {
     int F;                // feature bins per frame
     int OC;               // output channels (7, or 4 for logspec-only)
     int ident;            // identity rows of W (192 | 96 | n_fft/2)
+    int spec_lo, spec_hi; // bins [spec_lo, spec_hi) map to spectrogram rows k - spec_lo (1 .. ident+1 for the dataset scripts)
+    int flex;             // contrib/salsa_flexible.py semantics (SALSA_FLAG_FLEX): raw-|X0| tracker, gate without tracking, ...
     int compress;
     int layout;
     int feature;          // SALSA_FEATURE_* ; 3 = logspec only
@@ -62,6 +64,7 @@ struct KParams {
     double cond;
     double inv_cond;      // 1/cond (0 when cond == 0: unused, cond <= 1 short-circuits the gate)
     double delta;         // 2 pi fs / (n_fft * 343)
+    double snr_ratio;     // indicator_sig = mag > snr_ratio * floor (1.5, :36; contrib: floor_mask_ratio)
     const float *sc_mean; // optional fused normalise-on-load of the spectrogram channels: [4][F] mean / std, or NULL
     const float *sc_std;
 };
@@ -236,10 +239,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
                     xs[(t * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
-                if (k >= 1 && k <= kp.ident) {
-                    o[(c0 * Tn + t) * kp.F + (k - 1)] = spec(pa, c0, k - 1);
-                    o[((c0 + 1) * Tn + t) * kp.F + (k - 1)] = spec(pb, c0 + 1, k - 1);
-                } else if (k > kp.ident && k < N / 2) {
+                if (k >= kp.spec_lo && k < kp.spec_hi) {
+                    o[(c0 * Tn + t) * kp.F + (k - kp.spec_lo)] = spec(pa, c0, k - kp.spec_lo);
+                    o[((c0 + 1) * Tn + t) * kp.F + (k - kp.spec_lo)] = spec(pb, c0 + 1, k - kp.spec_lo);
+                } else if (kp.compress && k > kp.ident && k < N / 2) {
                     pw[w][0][k - kp.ident - 1] = pa;
                     pw[w][1][k - kp.ident - 1] = pb;
                 }
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                     // angle(X_c conj(X_0)) / (delta*k) (lite :111-115) or / pi (ipd :113).  float32 throughout: the
                     // product's rounding moves the angle by <= 1e-7 rad and 1/(delta*k) is the float64 quotient rounded
                     // once, so the float32 result is within ~2 ulp of the reference's float64-then-cast value.
+                    // (contrib's float32 frequency vector differs from delta*k by <= 6e-8 relative: same float32 result)
                     const float inv_scale = kp.feature == SALSA_FEATURE_IPD ? 0.318309886183790672f
                                                                            : (float)(1.0 / (kp.delta * (double)(k == 0 ? 1 : k)));
                     // pair 0 contributes channel 1 (phase vs channel 0); pair 1 contributes channels 2 and 3
@@ -340,7 +344,7 @@ __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__
 }
 
 template <int COUNT>
-__device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][64]*/, int lane)
+__device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][64]*/, int lane, bool raw)
 {
     double p[COUNT + 2];
 #pragma unroll
@@ -350,8 +354,8 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
     }
 #pragma unroll
     for (int i = 0; i < COUNT; i++) {
-        if (first + i < TR_CH)
-            dst[(first + i) * 64 + lane] = sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3); // :53-55, reference's order
+        if (first + i < TR_CH) // :53-55 in the reference's order ; contrib :326-328 tracks the raw |X0| instead
+            dst[(first + i) * 64 + lane] = raw ? sqrt(p[i + 2]) : sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3);
     }
 }
 
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     {
         float2 x[PER_ALL + 2];
         tracker_load<PER_ALL>(kp, x0, stride, 0, w * PER_ALL, active, x);
-        tracker_mag<PER_ALL>(x, w * PER_ALL, ring[0], lane);
+        tracker_mag<PER_ALL>(x, w * PER_ALL, ring[0], lane, kp.flex != 0);
     }
     float2 xr[PER_PROD + 2];
     const int pfirst = (w - 1) * PER_PROD;
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     // bin) dropped into lane i of a VGPR pair for frame i of the chunk: one coalesced 8-byte store per lane per chunk.
     double fl = 0.0;
     int cd = 3;
+    const double snr = kp.snr_ratio;
     unsigned long long *vout = valid + (((long)b * nchunks) * ngroups + g) * TR_CH + lane; // [b][chunk][group][frame]
     if (w == 0) __builtin_amdgcn_s_setprio(3);
     for (int c = 0; c < nchunks; c++) {
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 double acc = 0.0;
                 for (int t = 0; t < n0; t++) acc += cur[t * 64 + lane];
                 fl = 0.5 * (acc / (double)n0);
+                if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
             }
             int lo = 0, hi = 0;
             const int nfr = __builtin_amdgcn_readfirstlane(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH); // scalar
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                     for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * 64 + lane];
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const bool s1 = salsa::tracker_step(fl, cd, m[i]);                // :65-87
+                        const bool s1 = salsa::tracker_step(fl, cd, m[i], snr);           // :65-87
                         const unsigned long long sig = __ballot(s1);                        // bit = lane = bin of this group
                         lo = writelane_const<0>((int)(unsigned)sig, i0 + i, lo);
                         hi = writelane_const<0>((int)(unsigned)(sig >> 32), i0 + i, hi);
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 }
             } else {
                 for (int i = 0; i < nfr; i++) {
-                    const bool s1 = salsa::tracker_step(fl, cd, cur[i * 64 + lane]);
+                    const bool s1 = salsa::tracker_step(fl, cd, cur[i * 64 + lane], snr);
                     const unsigned long long sig = __ballot(s1);
                     if (lane == i) { lo = (int)(unsigned)sig; hi = (int)(unsigned)(sig >> 32); }
                 }
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
         } else if (c + 1 < nchunks) {
             float2 xn[PER_PROD + 2];
             if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, xn);
-            tracker_mag<PER_PROD>(xr, pfirst, ring[(c + 1) & 1], lane);
+            tracker_mag<PER_PROD>(xr, pfirst, ring[(c + 1) & 1], lane, kp.flex != 0);
 #pragma unroll
             for (int i = 0; i < PER_PROD + 2; i++) xr[i] = xn[i];
         }
@@ -558,13 +564,19 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                 salsa::herm4_rank1_add(R, x);
             }
         }
-        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, !kp.tracking);
+        // :111-112 the coherence test only gates when tracking -- except in contrib, whose test always gates (:352-354)
+        const bool ungated = !kp.tracking && !kp.flex;
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, ungated);
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
-        if (er.rank1 || !kp.tracking) { // :111-112 the coherence test only gates when tracking
-            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e, !kp.tracking);
-            else salsa::normalise_mic(er.u, kp.delta * (double)(bin + kp.lower), e);
+        if (er.rank1 || ungated) {
+            const int k = bin + kp.lower;
+            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e, ungated);
+            else if (kp.flex) salsa::normalise_mic(er.u, (double)((float)(k == 0 ? 1 : k) * (float)kp.delta), e); // float32 norm_freq (:188-190)
+            else salsa::normalise_mic(er.u, kp.delta * (double)k, e);
             g = 2;
+        } else if (FEAT && kp.flex && !kp.tracking) {
+            e[0] = __builtin_nan(""); // marks "failed the test" for flex_allpass_kernel (a passing bin can be exactly 0)
         }
         emit(t, bin, e, g);
     }
@@ -631,6 +643,43 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ feat
     for (int f = threadIdx.x & 63; f < F; f += 64) p[f] = (p[f] - mean[c * F + f]) / std[c * F + f];
 }
 
+// contrib/salsa_flexible.py with is_tracking=False: ONE all-pass mask array is created (:336-337) and then narrowed in
+// place by "mask[mask] = good_coherence_mask" (:354), so a bin that fails the coherence test once is never looked at
+// again in that clip.  cov_eig_kernel marks failures with NaN in channel 4; this pass (lane = bin, coalesced rows,
+// sequential in time) zeroes everything from a bin's first failure on.
+__global__ __launch_bounds__(256) void flex_allpass_kernel(const KParams kp, float *__restrict__ out)
+{
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= kp.nd) return;
+    float *of = out + ((long)blockIdx.y * kp.OC + 4) * kp.T * kp.F + bin;
+    bool dead = false;
+    for (int t = 0; t < kp.T; t++) {
+        const float v = of[t * kp.F];
+        dead = dead || (v != v);
+        if (dead) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) of[(c * kp.T + t) * kp.F] = 0.f;
+        }
+    }
+}
+
+// [rows][T][F] float32 (time-major, what the extract kernels write) -> [rows][F][T] float64 (the freq-major float64
+// array contrib/salsa_flexible.py returns, :264).  64 x 64 tiles through LDS (+1 padding), both sides coalesced.
+__global__ __launch_bounds__(256) void to_freq_major_kernel(const float *__restrict__ in, double *__restrict__ out, int T, int F)
+{
+    __shared__ float tile[64][65];
+    const long row = blockIdx.z;
+    const int t0 = blockIdx.y * 64, f0 = blockIdx.x * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const float *src = in + row * (long)T * F;
+    double *dst = out + row * (long)T * F;
+    for (int i = ly; i < 64; i += 4)
+        if (t0 + i < T && f0 + lx < F) tile[i][lx] = src[(long)(t0 + i) * F + f0 + lx];
+    __syncthreads();
+    for (int i = ly; i < 64; i += 4)
+        if (f0 + i < F && t0 + lx < T) dst[(long)(f0 + i) * T + t0 + lx] = (double)tile[lx][i];
+}
+
 } // namespace
 
 // ================================================================================================== plan + C ABI
@@ -640,7 +689,8 @@ struct salsa_plan {
     salsa_params p;
     int device;
     int lower, upper, cutoff, nd, F, ident;
-    double delta;
+    int spec_lo, spec_hi, flex;
+    double delta, snr_ratio;
     double *d_window;
     cplx<double> *d_tw;
     const float *sc_mean, *sc_std; // caller-owned device arrays set by salsa_plan_set_scaler (or NULL)
@@ -717,9 +767,47 @@ int salsa_plan_create(const salsa_params *params, salsa_plan **out_plan)
     pl->p = p;
     salsa_bin_limits(p.fs, p.n_fft, p.fmin_doa, p.fmax_doa, &pl->lower, &pl->upper, &pl->cutoff);
     const int nbins = p.n_fft / 2 + 1;
-    if (p.feature_type == SALSA_FEATURE_SALSA) {
+    pl->flex = (p.flags & SALSA_FLAG_FLEX) != 0;
+    pl->snr_ratio = p.floor_mask_ratio > 0 ? p.floor_mask_ratio : 1.5;
+    if (pl->flex) {
+        // contrib/salsa_flexible.py SpatialFeaturesAbstract.__init__ (:177-184) + __call__ (:252-263): no fs/2 clamp on
+        // fmax_doa, the spectrogram cutoff comes from fmax_spec, spectrogram and spatial features share ONE band
+        // [lo, hi) (the cropped axis, or all n_fft/2+1 bins), spatial rows >= upper_bin OF THAT AXIS optionally zeroed.
+        if (p.audio_format != SALSA_FORMAT_MIC || p.feature_type == SALSA_FEATURE_IPD) {
+            delete pl;
+            return fail(SALSA_EFORMAT, "the contrib (flex) surface has the MIC-style SALSA and SALSA-Lite features only%s");
+        }
+        pl->upper = (int)floor((double)((int64_t)p.fmax_doa * p.n_fft) / (double)p.fs);
+        pl->cutoff = (int)floor((double)((int64_t)(p.fmax_spec > 0 ? p.fmax_spec : 9000) * p.n_fft) / (double)p.fs);
+        if (pl->upper > pl->cutoff) {
+            delete pl;
+            return fail(SALSA_EBINS, "Upper bin for spatial feature is higher than cutoff bin for spectrogram!%s");
+        }
+        const bool crop = !(p.flags & SALSA_FLAG_NO_CLIP_FREQS);
+        const int lo = crop ? pl->lower : 0, hi = crop ? (pl->cutoff < nbins ? pl->cutoff : nbins) : nbins;
+        const int zero_from = (p.flags & SALSA_FLAG_CLIP_SPATIAL_ALIAS) ? pl->upper : hi - lo; // index into the band
+        pl->lower = lo;
+        pl->cutoff = hi;
+        pl->F = hi - lo;
+        if (pl->F <= 0) {
+            delete pl;
+            return fail(SALSA_EBINS, "empty spectrogram band%s");
+        }
+        pl->ident = p.n_fft / 2;
+        pl->spec_lo = lo;
+        pl->spec_hi = hi;
+        if (p.feature_type == SALSA_FEATURE_SALSA) {
+            pl->nd = zero_from < pl->F ? zero_from : pl->F; // bins above it are never evaluated: cov_eig zero-fills them
+            pl->upper = lo + pl->nd;
+        } else {
+            pl->nd = 0;
+            pl->upper = zero_from;                           // the lite kernel zeroes band rows >= kp.upper
+        }
+    } else if (p.feature_type == SALSA_FEATURE_SALSA) {
         pl->F = freq_dim(p.n_fft, p.is_compress_high_freq);
         pl->ident = p.is_compress_high_freq ? (p.n_fft == 512 ? 192 : 96) : p.n_fft / 2;
+        pl->spec_lo = 1;
+        pl->spec_hi = pl->ident + 1;
         pl->nd = pl->upper - pl->lower;
         if (pl->nd < 0 || pl->nd > pl->F || pl->upper > nbins) {
             delete pl;
@@ -827,7 +915,11 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.F = pl->F;
     kp.OC = 7;
     kp.ident = pl->ident;
-    kp.compress = pl->p.is_compress_high_freq;
+    kp.spec_lo = pl->spec_lo;
+    kp.spec_hi = pl->spec_hi;
+    kp.flex = pl->flex;
+    kp.snr_ratio = pl->snr_ratio;
+    kp.compress = pl->flex ? 0 : pl->p.is_compress_high_freq;
     kp.layout = pl->p.audio_layout;
     kp.feature = pl->p.feature_type;
     kp.format = pl->p.audio_format;
@@ -916,7 +1008,11 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
             HIP_TRY(hipEventRecord(between, s1));
             HIP_TRY(hipStreamWaitEvent(s2, between, 0));
         }
-        if (gp.nd > 0 && gp.tracking) {
+        if (gp.nd == 0) { // empty DOA band: channels 4-6 are all zero (:373-374)
+            HIP_TRY(hipMemset2DAsync(o + 4 * T * kp.F, sizeof(float) * 7 * T * kp.F, 0, sizeof(float) * 3 * T * kp.F, (size_t)gp.B, s2));
+            return SALSA_OK;
+        }
+        if (gp.tracking) {
             m = mark_begin(pl, s2, "noise_floor_tracker");
             hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(gp.B * ((gp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
             mark_end(pl, s2, m);
@@ -928,6 +1024,12 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         launch_cov_eig<true>(gp, grid, s2, xs, vm, o, (double *)nullptr, (unsigned char *)nullptr);
         mark_end(pl, s2, m);
         HIP_TRY(hipGetLastError());
+        if (gp.flex && !gp.tracking && gp.nd > 0) {
+            m = mark_begin(pl, s2, "flex_allpass");
+            hipLaunchKernelGGL(flex_allpass_kernel, dim3((unsigned)((gp.nd + 255) / 256), (unsigned)gp.B), dim3(256), 0, s2, gp, o);
+            mark_end(pl, s2, m);
+            HIP_TRY(hipGetLastError());
+        }
         return SALSA_OK;
     };
     const int G = (!full || pl->n_groups <= 1 || batch < 2) ? 1 : (batch < pl->n_groups ? batch : pl->n_groups);
@@ -962,6 +1064,9 @@ int salsa_logspec_batch(salsa_plan *pl, const float *d_audio, int batch, int n_c
     kp.layout = SALSA_LAYOUT_PLANAR;
     kp.F = freq_dim(pl->p.n_fft, pl->p.is_compress_high_freq);
     kp.ident = pl->p.is_compress_high_freq ? (pl->p.n_fft == 512 ? 192 : 96) : pl->p.n_fft / 2;
+    kp.compress = pl->p.is_compress_high_freq;
+    kp.spec_lo = 1;
+    kp.spec_hi = kp.ident + 1;
     return launch_stft(pl, kp, d_audio, d_out, nullptr, (hipStream_t)hip_stream);
 }
 
@@ -1077,6 +1182,16 @@ int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
         if (rc) return rc;
     }
     pl->n_groups = n_groups > SALSA_MAX_GROUPS ? SALSA_MAX_GROUPS : n_groups;
+    return SALSA_OK;
+}
+
+int salsa_to_freq_major(const float *d_feat, int64_t n_rows, int64_t n_frames, int n_freq, double *d_out, void *hip_stream)
+{
+    if (!d_feat || !d_out || n_rows <= 0 || n_frames <= 0 || n_freq <= 0 || n_rows > 65535 || (n_frames + 63) / 64 > 65535)
+        return fail(SALSA_EINVAL, "salsa_to_freq_major: bad argument%s");
+    dim3 grid((unsigned)((n_freq + 63) / 64), (unsigned)((n_frames + 63) / 64), (unsigned)n_rows);
+    hipLaunchKernelGGL(to_freq_major_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, d_feat, d_out, (int)n_frames, n_freq);
+    HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }
 

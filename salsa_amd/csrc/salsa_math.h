@@ -460,7 +460,7 @@ SALSA_HD int stockham_out(int i, int r, int p, int R) { int k = i & (p - 1); ret
 // the above/below compare resolves.  Same operations and constants as the reference: floor_up = 1+alpha,
 // floor_up_slow = 1+slow_scale*alpha, floor_down = 1-alpha (:31-35); "countdown -= 1; negative = countdown < 0" (:68-69)
 // is (cd < 1) on the value before the decrement; the 1e-6 clamp (:85) is an fmax (the floor is never NaN).
-SALSA_HD bool tracker_step(double &floor, int &countdown, double mag)
+SALSA_HD bool tracker_step(double &floor, int &countdown, double mag, double snr_ratio = 1.5)
 {
     const double up = (countdown < 1) ? 1.0 + 0.1 * 0.02 : 1.0 + 0.02;
     double pa = up * floor, pb = (1.0 - 0.02) * floor;
@@ -479,7 +479,7 @@ SALSA_HD bool tracker_step(double &floor, int &countdown, double mag)
 #else
     floor = fmax(sel, 1e-6);
 #endif
-    return mag > 1.5 * floor;
+    return mag > snr_ratio * floor; // :87 (snr_ratio = 1.5 there; contrib's floor_mask_ratio kwarg)
 }
 
 } // namespace salsa

@@ -54,7 +54,7 @@ class SalsaExtractor:
 
     def __init__(self, fs=24000, n_fft=512, hop_len=300, win_len=None, fmin_doa=50, fmax_doa=9000, cond_num=5.0,
                  n_hopframes=3, is_tracking=True, is_compress_high_freq=True, audio_format='foa',
-                 feature_type='salsa', audio_layout='planar', device=None):
+                 feature_type='salsa', audio_layout='planar', device=None, flags=0, floor_mask_ratio=0.0, fmax_spec=0):
         if audio_format not in _lib.FORMAT:
             raise ValueError('Unknown audio format {}'.format(audio_format))
         assert feature_type in _lib.FEATURE, 'Invalid feature type {}'.format(feature_type)
@@ -65,7 +65,8 @@ class SalsaExtractor:
             fmax_doa=int(fmax_doa), cond_num=float(cond_num), n_hopframes=int(n_hopframes),
             is_tracking=int(bool(is_tracking)), is_compress_high_freq=int(bool(is_compress_high_freq)),
             audio_format=_lib.FORMAT[audio_format], feature_type=_lib.FEATURE[feature_type],
-            audio_layout=_lib.LAYOUT[audio_layout], reserved=0)
+            audio_layout=_lib.LAYOUT[audio_layout], flags=int(flags), floor_mask_ratio=float(floor_mask_ratio),
+            fmax_spec=int(fmax_spec), reserved=0)
         self.audio_layout = audio_layout
         self.feature_type = feature_type
         self._plan = C.c_void_p()

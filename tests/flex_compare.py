@@ -2,7 +2,8 @@
 import numpy as np
 
 
-def compare_flexible(out, spec_ref, spat_ref, case, n_samples, spec_tol=(2e-6, 2e-5), spat_tol=1e-9, gate_exact=True):
+def compare_flexible(out, spec_ref, spat_ref, case, n_samples, spec_tol=(2e-6, 2e-5), spat_tol=1e-9, spat_rtol=0.0,
+                     gate_exact=True):
     """out: (2C-1, F, T).  Spectrograms to float32 accuracy; spatial channels: zero pattern exact (gates), values to
     spat_tol -- except where the spectra are REAL up to round-off (frame 0 and, when the last frame is centred on the
     last sample, that frame: mirror-symmetric about the reflect point; bins 0 and n_fft/2), whose 0-or-+-pi phase has
@@ -29,4 +30,5 @@ def compare_flexible(out, spec_ref, spat_ref, case, n_samples, spec_tol=(2e-6, 2
     d = o - r
     period = (2 * np.pi / nf)[None, :, None]
     dw = d - period * np.round(d / period)
-    assert np.abs(np.where(real_tf[None], dw, d)).max() <= spat_tol, np.abs(np.where(real_tf[None], dw, d)).max()
+    err = np.abs(np.where(real_tf[None], dw, d))
+    assert np.all(err <= spat_tol + spat_rtol * np.abs(r)), err.max()

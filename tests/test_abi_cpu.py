@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), 'libsalsa_hip.so does not export %s' % n
     from salsa_amd import _lib
     assert set(_lib.EXPORTS) == names
-    assert lib.salsa_abi_version() == 1
+    assert lib.salsa_abi_version() == 2
     gru = open(os.path.join(ROOT, 'include', 'salsa_gru.h')).read()
     gru = re.sub(r'/\*.*?\*/', '', gru, flags=re.S)
     gnames = set(re.findall(r'\b(salsa_gru_[a-z_]+)\s*\(', gru))
@@ -50,5 +50,5 @@ def test_host_helpers_match_reference(lib):
 def test_params_struct_layout_matches_header():
     from salsa_amd import _lib
     # 6 ints, double (8-aligned), 7 ints, pad -> 64 bytes with natural alignment
-    assert C.sizeof(_lib.SalsaParams) == 64
+    assert C.sizeof(_lib.SalsaParams) == 80
     assert _lib.SalsaParams.cond_num.offset == 24

@@ -417,3 +417,54 @@ def test_fused_scaler_equals_separate_normalisation(dev):
     np.testing.assert_allclose(ref[:, :4].cpu().numpy(), (raw[:, :4].cpu().numpy() - mean) / std, rtol=1e-6, atol=1e-6)
     ex.set_scaler(None)
     assert torch.equal(ex.extract(a), raw)
+
+
+# ----------------------------------------------------------------------------------------------- contrib on-the-fly surface
+def test_contrib_flexible_surface_matches_reference_golden(dev):
+    """SalsaFeatures / SalsaLiteFeatures of contrib/salsa_flexible.py, called like the reference's docstrings."""
+    from flex_compare import compare_flexible
+    from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures
+    meta, g = load_golden('g10_flexible')
+    for name, c in meta['cases'].items():
+        y = synth_clip(c['seed'], meta['n'], n_ch=c['n_ch'])
+        assert sha256_of(y) == c['sha']
+        obj = (SalsaFeatures if c['kind'] == 'salsa' else SalsaLiteFeatures)(**c['ctor'])
+        out = obj(y, **c['call'])
+        assert out.dtype == np.float64, name
+        compare_flexible(out, g[name + '_spec'], g[name + '_spatial'], c, meta['n'], spec_tol=(RTOL, ATOL_DB),
+                         spat_tol=ATOL_SP, spat_rtol=RTOL)
+
+
+def test_contrib_flexible_batch_against_oracle(dev, oracle):
+    from flex_compare import compare_flexible
+    from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures
+    n = 3 * 24000 + 123
+    ys = np.stack([synth_clip(300 + i, n) for i in range(3)])
+    a = torch.from_numpy(ys).to(dev)
+    ctor = dict(fs=24000, stft_winsize=512, hop_length=300, fmin_doa=50, fmax_doa=4000, fmax_spec=9000)
+    for kind, cls, call in (('salsa', SalsaFeatures, dict(clip_freqs=True, clip_spatial_alias=True, ew_thresh=4.0)),
+                            ('salsa', SalsaFeatures, dict(clip_freqs=False, clip_spatial_alias=False, is_tracking=False,
+                                                          ew_thresh=1.05)),
+                            ('lite', SalsaLiteFeatures, dict(clip_freqs=False, clip_spatial_alias=False))):
+        out = cls(**ctor).extract_batch(a, **call).cpu().numpy()
+        for i in range(3):
+            kw = dict(ctor)
+            kw.update(call)
+            ref = oracle.flexible(ys[i], kind=kind, **kw)
+            case = {'n_ch': 4, 'ctor': ctor, 'call': {'clip_freqs': call['clip_freqs']}}
+            compare_flexible(out[i], ref[:4].astype(np.float32), ref[4:], case, n, spec_tol=(RTOL, ATOL_DB),
+                             spat_tol=ATOL_SP, spat_rtol=RTOL)
+        if kind == 'salsa':
+            assert (out[:, 4:] != 0).any(), 'degenerate case: nothing passed the gates'
+
+
+def test_to_freq_major(dev):
+    from salsa_amd.flexible import to_freq_major
+    x = torch.randn(3, 7, 131, 77, device=dev)
+    assert torch.equal(to_freq_major(x), x.permute(0, 1, 3, 2).double())
+    with pytest.raises(ValueError):
+        from salsa_amd.flexible import SalsaFeatures
+        SalsaFeatures().extract_batch(torch.zeros(1, 5, 4000, device=dev))
+    with pytest.raises(AssertionError):
+        from salsa_amd.flexible import SalsaFeatures
+        SalsaFeatures(fmax_doa=9500)                                            # contrib :183
