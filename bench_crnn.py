@@ -89,6 +89,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='chunks per GPU per step')
     ap.add_argument('--on-the-fly', action='store_true', help='extract SALSA-MIC features from raw audio every step')
+    ap.add_argument('--augment', action='store_true', help='apply the reference training augmentation on device every step')
     ap.add_argument('--fp32-grads', action='store_true', help='all-reduce fp32 gradients instead of bf16-compressed')
     ap.add_argument('--infer', action='store_true', help='config 5: batched inference, SALSA + CRNN forward on 60-s clips')
     ap.add_argument('--clips', type=int, default=32, help='--infer: 60-s clips per GPU per step')
@@ -118,11 +119,16 @@ def main():
     if args.infer:
         return infer_bench(args, rank, world, dev, tr)
 
+    aug_gen = torch.Generator().manual_seed(2021 + rank)
+
     def step():
-        xb = x
+        xb, sb, db = x, sed, doa
         if ex is not None:
             xb = ex.extract(audio)[:, :, :640]                      # (B,7,641,200) -> 640 frames
-        return tr.train_step(xb, sed, doa)
+        if args.augment:
+            from salsa_amd.augment import augment_batch
+            xb, sb, db = augment_batch(xb, sb, db, 'mic' if ex is not None else 'foa', gen=aug_gen)
+        return tr.train_step(xb, sb, db)
 
     for _ in range(args.warmup):
         step()
@@ -153,7 +159,8 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,640,200), batch %d per GPU, Adam'
-                               % ('on-the-fly extracted MIC' if args.on_the_fly else 'precomputed-FOA-shaped', args.batch),
+                               % ('on-the-fly extracted MIC' if args.on_the_fly else 'precomputed-FOA-shaped', args.batch)
+                               + (' + device augmentation' if args.augment else ''),
                    'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if args.fp32_grads else 'bf16'},
         'roofline': {'bound': 'mfma', 'achieved': round(tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,

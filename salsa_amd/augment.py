@@ -3,8 +3,18 @@
     feature channels (W Y Z X | Y Z X: rows 1/3 and 4/6 swap, rows 6, 4, 5 negate) and the xyz regression targets;
   * RandomShiftUpDownNp (:286-320): with p = 0.5, shift every channel 1..range-1 bins up or down in frequency with
     reflect padding.
-The deterministic cores take the random draw as an argument (tests pin them against numpy restatements); the ``random_*``
-wrappers draw per sample from a torch.Generator.  Pure index / sign operations: torch is used as plumbing only."""
+  * TfmapRandomSwapChannelMic (:440-523): m in {0,1}^3 -- swap M2/M3, swap M1/M4, swap (M1,M2)/(M3,M4) -- which permutes
+    the four spectrogram rows AND re-references the three phase rows (p12 p13 p14) by differences, plus the matching
+    swap / negation of the xyz targets;
+  * CompositeCutout (:257-283) = one of RandomCutoutNp (:58-121), SpecAugmentNp (:124-194), RandomCutoutHoleNp (:197-254),
+    all of which fill rectangles with a value drawn between the sample's min and max (zeros in the last
+    ``n_zero_channels`` spatial rows): one core, ``fill_rects``.
+The deterministic cores take the random draw as an argument; ``draw_*`` reproduce the reference's draws IN ITS CALL ORDER
+from a numpy RandomState-like source, so ``reference_train_transform`` under ``np.random.seed(s)`` equals the
+reference's SeldDataset augmentation under the same seed (golden g11); the ``random_*`` wrappers are the batched
+on-device forms drawing per sample from a torch.Generator.  Pure index / sign / difference operations: torch is used
+as plumbing only."""
+import numpy as np
 import torch
 
 
@@ -51,3 +61,209 @@ def random_shift_up_down(x, gen=None, p: float = 0.5, freq_shift_range: int = 10
     shift = torch.randint(1, freq_shift_range, (B,), generator=gen) * apply
     up = torch.randint(0, 2, (B,), generator=gen).bool()
     return shift_up_down(x, shift, up)
+
+
+# ------------------------------------------------------------------------------------------------------- MIC swap
+def swap_channels_mic(x, y_doa, m, n_classes: int = 12):
+    """x (B,7,T,F) rows M1 M2 M3 M4 p12 p13 p14, y_doa (B,T_lab,36), m (B,3) in {0,1} (transforms.py:469-523)."""
+    m = m.to(torch.bool)
+    x_new, y_new = x.clone(), y_doa.clone()
+    nc = n_classes
+    s = m[:, 0]
+    if s.any():                                                  # swap M2 and M3 -> swap x and y
+        x_new[s, 1], x_new[s, 2] = x[s, 2], x[s, 1]
+        x_new[s, 4], x_new[s, 5] = x[s, 5], x[s, 4]
+        y_new[s, :, :nc], y_new[s, :, nc:2 * nc] = y_doa[s, :, nc:2 * nc], y_doa[s, :, :nc]
+    s = m[:, 1]
+    if s.any():                                                  # swap M1 and M4 -> swap x and y, negate both
+        c, yc = x_new.clone(), y_new.clone()
+        x_new[s, 0], x_new[s, 3] = c[s, 3], c[s, 0]
+        x_new[s, 6] = -c[s, 6]
+        x_new[s, 5] = c[s, 5] - c[s, 6]
+        x_new[s, 4] = c[s, 4] - c[s, 6]
+        y_new[s, :, :nc], y_new[s, :, nc:2 * nc] = -yc[s, :, nc:2 * nc], -yc[s, :, :nc]
+    s = m[:, 2]
+    if s.any():                                                  # swap M1/M2 and M3/M4 -> negate y and z
+        c = x_new.clone()
+        x_new[s, 0], x_new[s, 1], x_new[s, 2], x_new[s, 3] = c[s, 1], c[s, 0], c[s, 3], c[s, 2]
+        x_new[s, 4] = -c[s, 4]
+        x_new[s, 5] = c[s, 6] - c[s, 4]
+        x_new[s, 6] = c[s, 5] - c[s, 4]
+        y_new[s, :, nc:2 * nc] = -y_new[s, :, nc:2 * nc]
+        y_new[s, :, 2 * nc:] = -y_new[s, :, 2 * nc:]
+    return x_new, y_new
+
+
+def random_swap_channels_mic(x, y_sed, y_doa, gen=None, p: float = 0.5, n_classes: int = 12):
+    B = x.shape[0]
+    apply = torch.rand(B, generator=gen) < p
+    m = torch.randint(0, 2, (B, 3), generator=gen) * apply[:, None]
+    xn, yn = swap_channels_mic(x, y_doa, m.to(x.device), n_classes)
+    return xn, y_sed, yn
+
+
+# ------------------------------------------------------------------------------------------------------- cutouts
+def fill_rects(x, top, h, left, w, value, n_zero_channels=None, is_filled_last_channels: bool = True):
+    """x (B,C,T,F); top/h/left/w (B,R) integer rectangles (h or w = 0: none), value (B,R): applied in order r = 0..R-1.
+    The first C - n_zero_channels rows get ``value``; the last n_zero_channels rows get 0 (or are left alone)."""
+    B, C, T, F = x.shape
+    out = x.clone()
+    dev = x.device
+    t = torch.arange(T, device=dev)[None, :, None]
+    f = torch.arange(F, device=dev)[None, None, :]
+    top, h, left, w = (a.to(dev) for a in (top, h, left, w))
+    value = value.to(dev, x.dtype)
+    nz = 0 if n_zero_channels is None else int(n_zero_channels)
+    for r in range(top.shape[1]):
+        mask = ((t >= top[:, r, None, None]) & (t < (top[:, r] + h[:, r])[:, None, None]) &
+                (f >= left[:, r, None, None]) & (f < (left[:, r] + w[:, r])[:, None, None]))[:, None]   # (B,1,T,F)
+        out[:, :C - nz] = torch.where(mask, value[:, r, None, None, None], out[:, :C - nz])
+        if nz and is_filled_last_channels:
+            out[:, C - nz:] = torch.where(mask, torch.zeros((), dtype=x.dtype, device=dev), out[:, C - nz:])
+    return out
+
+
+def _cutout_ratio_bounds(image_aspect_ratio):
+    r_1, r_2 = 0.3, 1 / 0.3                                      # transforms.py:78-85
+    if image_aspect_ratio > 1:
+        r_1 = r_1 * image_aspect_ratio
+    elif image_aspect_ratio < 1:
+        r_2 = r_2 * image_aspect_ratio
+    return r_1, r_2
+
+
+def draw_random_cutout(rng, T, F, vmin, vmax, image_aspect_ratio=1.0, random_value=None):
+    """RandomCutoutNp.apply's draws in order (transforms.py:99-110) -> [(top, h, left, w, value)]."""
+    r_1, r_2 = _cutout_ratio_bounds(image_aspect_ratio)
+    s = rng.uniform(0.02, 0.3) * T * F
+    r = rng.uniform(r_1, r_2)
+    w = min(int(np.sqrt(s / r)), F - 1)
+    h = min(int(np.sqrt(s * r)), T - 1)
+    left = rng.randint(0, F - w)
+    top = rng.randint(0, T - h)
+    c = rng.uniform(vmin, vmax) if random_value is None else random_value
+    return [(top, h, left, w, c)]
+
+
+def draw_spec_augment(rng, T, F, vmin, vmax, time_max_width=None, freq_max_width=None, n_time_stripes=1,
+                      n_freq_stripes=1):
+    """SpecAugmentNp.apply's draws in order (transforms.py:154-192): full-width time stripes, then full-height frequency
+    stripes."""
+    tmw = max(1, int(0.15 * T) if time_max_width is None else time_max_width)
+    fmw = max(1, int(0.2 * F) if freq_max_width is None else freq_max_width)
+    rects = []
+    for _ in range(n_time_stripes):
+        dur = rng.randint(1, tmw, 1)[0]
+        start = rng.randint(0, T - dur, 1)[0]
+        rects.append((start, dur, 0, F, rng.uniform(vmin, vmax, 1)[0]))
+    for _ in range(n_freq_stripes):
+        dur = rng.randint(1, fmw, 1)[0]
+        start = rng.randint(0, F - dur, 1)[0]
+        rects.append((0, T, start, dur, rng.uniform(vmin, vmax, 1)[0]))
+    return rects
+
+
+def draw_cutout_holes(rng, T, F, vmin, vmax, n_max_holes=8, max_h_size=8, max_w_size=8, filled_value=None):
+    """RandomCutoutHoleNp.apply's draws in order (transforms.py:233-246): n_max_holes holes of the maximum size."""
+    h, w = max(max_h_size, 5), max(max_w_size, 5)
+    rects = []
+    for _ in range(n_max_holes):
+        left = rng.randint(0, F - w)
+        top = rng.randint(0, T - h)
+        rects.append((top, h, left, w, rng.uniform(vmin, vmax) if filled_value is None else filled_value))
+    return rects
+
+
+def draw_composite_cutout(rng, T, F, vmin, vmax, image_aspect_ratio=1.0):
+    """CompositeCutout.apply (transforms.py:276-283)."""
+    choice = rng.randint(0, 3, 1)[0]
+    if choice == 0:
+        return draw_random_cutout(rng, T, F, vmin, vmax, image_aspect_ratio)
+    if choice == 1:
+        return draw_spec_augment(rng, T, F, vmin, vmax)
+    return draw_cutout_holes(rng, T, F, vmin, vmax)
+
+
+def _rects_to_tensors(rect_lists, n_rects=8):
+    B = len(rect_lists)
+    geo = torch.zeros((4, B, n_rects), dtype=torch.long)
+    val = torch.zeros((B, n_rects), dtype=torch.float64)
+    for b, rects in enumerate(rect_lists):
+        for r, (top, h, left, w, c) in enumerate(rects):
+            geo[0, b, r], geo[1, b, r], geo[2, b, r], geo[3, b, r], val[b, r] = int(top), int(h), int(left), int(w), float(c)
+    return geo[0], geo[1], geo[2], geo[3], val
+
+
+def reference_train_transform(x, y_sed, y_doa, audio_format='foa', rng=np.random, image_aspect_ratio=None,
+                              n_classes: int = 12, freq_shift_range: int = 10, p: float = 0.5):
+    """One sample through the reference's training augmentation for SALSA features (datamodule.py:45-52 FOA, :73-82 MIC;
+    applied joint-then-plain, dataloader.py:56-60), drawing from ``rng`` exactly as the reference draws from np.random.
+    x (7,T,F), y_sed (T_lab,n_classes), y_doa (T_lab,3*n_classes) tensors (any device) -> same."""
+    xb, yb = x[None], y_doa[None]
+    if rng.rand() < p:                                           # MapDataAugmentBase.__call__ :346-353
+        if audio_format == 'foa':
+            m = rng.randint(2, size=(4,))                        # :409
+            xb, yb = swap_channels_foa(xb, yb, torch.as_tensor(m)[None], n_classes)
+        else:
+            m = rng.randint(2, size=(3,))                        # :483
+            xb, yb = swap_channels_mic(xb, yb, torch.as_tensor(m)[None], n_classes)
+    if rng.rand() < p:                                           # RandomShiftUpDownNp :298-320
+        shift = rng.randint(1, freq_shift_range, 1)[0]
+        up = rng.choice(['up', 'down'], 1)[0] == 'up'
+        xb = shift_up_down(xb, torch.as_tensor([shift]), torch.as_tensor([bool(up)]))
+    if audio_format == 'mic' and rng.rand() < p:                 # CompositeCutout(n_zero_channels=3) is in the MIC recipe only
+        T, F = xb.shape[-2:]
+        ratio = T / 200 if image_aspect_ratio is None else image_aspect_ratio
+        rects = draw_composite_cutout(rng, T, F, float(xb.min()), float(xb.max()), ratio)
+        xb = fill_rects(xb, *_rects_to_tensors([rects]), n_zero_channels=3)
+    return xb[0], y_sed, yb[0]
+
+
+def random_composite_cutout(x, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0, n_zero_channels=3):
+    """Batched on-device CompositeCutout: per sample, with probability p, one of the three cutouts with the reference's
+    size distributions; fill values uniform between the sample's min and max."""
+    B, C, T, F = x.shape
+    u = lambda *shape: torch.rand(*shape, generator=gen, dtype=torch.float64)     # noqa: E731
+    ri = lambda hi, n: torch.floor(u(n) * hi.double()).long()                   # noqa: E731  randint(0, hi) per element
+    apply = u(B) < p
+    choice = torch.randint(0, 3, (B,), generator=gen)
+    r_1, r_2 = _cutout_ratio_bounds(image_aspect_ratio)
+    top, h, left, w = (torch.zeros((B, 8), dtype=torch.long) for _ in range(4))
+    # choice 0: one rectangle of random area and aspect
+    area = (0.02 + 0.28 * u(B)) * T * F
+    ratio = r_1 + (r_2 - r_1) * u(B)
+    w0 = torch.clamp(torch.sqrt(area / ratio).long(), max=F - 1)
+    h0 = torch.clamp(torch.sqrt(area * ratio).long(), max=T - 1)
+    c0 = choice == 0
+    w[c0, 0], h[c0, 0] = w0[c0], h0[c0]
+    left[c0, 0], top[c0, 0] = ri(F - w0, B)[c0], ri(T - h0, B)[c0]
+    # choice 1: a time stripe and a frequency stripe
+    tmw, fmw = max(1, int(0.15 * T)), max(1, int(0.2 * F))
+    c1 = choice == 1
+    td = 1 + ri(torch.full((B,), max(1, tmw - 1)), B)
+    fd = 1 + ri(torch.full((B,), max(1, fmw - 1)), B)
+    h[c1, 0], w[c1, 0], top[c1, 0] = td[c1], F, ri(T - td, B)[c1]
+    h[c1, 1], w[c1, 1], left[c1, 1] = T, fd[c1], ri(F - fd, B)[c1]
+    # choice 2: eight 8 x 8 holes
+    c2 = choice == 2
+    h[c2], w[c2] = 8, 8
+    left[c2] = torch.floor(u(B, 8) * (F - 8)).long()[c2]
+    top[c2] = torch.floor(u(B, 8) * (T - 8)).long()[c2]
+    h[~apply], w[~apply] = 0, 0
+    lo = x.amin(dim=(1, 2, 3)).double().cpu()
+    hi = x.amax(dim=(1, 2, 3)).double().cpu()
+    value = lo[:, None] + (hi - lo)[:, None] * u(B, 8)
+    return fill_rects(x, top, h, left, w, value, n_zero_channels=n_zero_channels)
+
+
+def augment_batch(x, y_sed, y_doa, audio_format='foa', gen=None, n_classes: int = 12):
+    """The reference's SALSA training recipe on a device batch: channel swap (format-specific, changes the targets), then
+    frequency shift, then -- MIC only -- CompositeCutout(n_zero_channels=3) (datamodule.py:45-52, :73-82)."""
+    if audio_format == 'foa':
+        x, y_sed, y_doa = random_swap_channels_foa(x, y_sed, y_doa, gen=gen, n_classes=n_classes)
+    else:
+        x, y_sed, y_doa = random_swap_channels_mic(x, y_sed, y_doa, gen=gen, n_classes=n_classes)
+    x = random_shift_up_down(x, gen=gen)
+    if audio_format == 'mic':
+        x = random_composite_cutout(x, gen=gen, image_aspect_ratio=x.shape[2] / 200, n_zero_channels=3)
+    return x, y_sed, y_doa

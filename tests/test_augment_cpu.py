@@ -61,3 +61,49 @@ def test_random_wrappers_shapes_and_rates():
     xs = random_shift_up_down(x, gen=g)
     changed = (xs != x).flatten(1).any(dim=1).float().mean()
     assert 0.2 < float(changed) < 0.8
+
+
+def test_reference_train_transform_reproduces_golden_under_the_same_seed():
+    """Same np.random seed -> same augmented sample as the reference's SeldDataset (golden g11, 48 seeds x 2 formats)."""
+    import hashlib
+    from conftest import load_golden
+    from salsa_amd.augment import reference_train_transform
+    meta, a = load_golden('g11_augment')
+    x, y_sed, y_doa = (torch.from_numpy(a[k]) for k in ('x', 'y_sed', 'y_doa'))
+    for fmt in ('foa', 'mic'):
+        changed = 0
+        for s, (hx, hd) in zip(meta['seeds'], meta['sha'][fmt]):
+            np.random.seed(s)
+            xo, so, do = reference_train_transform(x, y_sed, y_doa, audio_format=fmt, rng=np.random,
+                                                   image_aspect_ratio=meta['image_aspect_ratio'])
+            xo, do = xo.numpy(), do.numpy()
+            if ('%s_x_%d' % (fmt, s)) in a:
+                assert np.array_equal(xo, a['%s_x_%d' % (fmt, s)]) and np.array_equal(do, a['%s_doa_%d' % (fmt, s)])
+            assert hashlib.sha256(np.ascontiguousarray(xo).tobytes()).hexdigest() == hx, (fmt, s)
+            assert hashlib.sha256(np.ascontiguousarray(do).tobytes()).hexdigest() == hd, (fmt, s)
+            assert so is y_sed
+            changed += not np.array_equal(xo, a['x'])
+        assert changed > len(meta['seeds']) // 2
+
+
+def test_batched_mic_swap_and_cutout():
+    from salsa_amd.augment import fill_rects, random_composite_cutout, random_swap_channels_mic, swap_channels_mic
+    g = torch.Generator().manual_seed(3)
+    x, sed, doa = torch.randn(64, 7, 40, 200), torch.zeros(64, 4, 12), torch.randn(64, 4, 36)
+    xn, s2, dn = random_swap_channels_mic(x, sed, doa, gen=g)
+    assert s2 is sed and not torch.equal(xn, x)
+    # every draw is an involution on the microphone permutation: applying the same single swap twice restores x
+    for bit in range(3):
+        m = torch.zeros(64, 3, dtype=torch.long)
+        m[:, bit] = 1
+        x1, d1 = swap_channels_mic(x, doa, m)
+        x2, d2 = swap_channels_mic(x1, d1, m)
+        assert torch.allclose(x2, x, atol=1e-6) and torch.equal(d2, doa)
+    out = random_composite_cutout(x, gen=g, p=1.0, image_aspect_ratio=40 / 200)
+    diff = out != x
+    assert diff.any(dim=(1, 2, 3)).all()                                   # p = 1: every sample is cut
+    assert (out[:, 4:][diff[:, 4:]] == 0).all()                            # spatial rows are zero-filled
+    frac = diff[:, 0].float().mean(dim=(1, 2))
+    assert frac.max() <= 0.5 and frac.min() > 0
+    same = fill_rects(x, *(torch.zeros(64, 2, dtype=torch.long),) * 4, torch.zeros(64, 2))
+    assert torch.equal(same, x)

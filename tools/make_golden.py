@@ -8,6 +8,7 @@ every array below is an output of the reference's own functions
                                          compute_scaler (:204-262), extract_features (:265-391)
   dataset/salsa_lite_feature_extraction.py  extract_features (:18-137)
   contrib/salsa_flexible.py             SalsaFeatures / SalsaLiteFeatures (:271-400), the on-the-fly surface
+  utilities/transforms.py               the SALSA training augmentations (datamodule.py:45-52, :73-82)
 driven through tools/ref_shims.py (librosa 0.8.0 / h5py / fire stand-ins -- third-party arithmetic restated there).
 Inputs are regenerated from seeds by salsa_amd/synth.py; each fixture stores the SHA-256 of every input so a drifted
 generator is detected.  Fixtures hold data only (inputs' hashes, parameters, expected outputs).
@@ -289,6 +290,43 @@ def g10_flexible():
         print('   ', k, 'spatial non-zero fraction %.3f' % v['nonzero'])
 
 
+# ----------------------------------------------------------------------------------------------- G11: train augmentation
+def g11_augment():
+    """The reference's training augmentation for SALSA features (dataset/datamodule.py:45-52 FOA, :73-82 MIC) applied the
+    way SeldDataset.__getitem__ does (dataloader.py:56-60), under np.random.seed(s): SHA-256 of the outputs for 48 seeds
+    per format + three full outputs per format."""
+    import hashlib
+    from utilities import transforms as T
+    rng = np.random.RandomState(7)
+    x = rng.randn(7, 48, 64).astype(np.float32)
+    y_sed = (rng.rand(6, 12) < 0.2).astype(np.float32)
+    y_doa = rng.randn(6, 36).astype(np.float32)
+    arrays = {'x': x, 'y_sed': y_sed, 'y_doa': y_doa}
+    meta = {'image_aspect_ratio': 48 / 200, 'n_zero_channels': 3, 'seeds': list(range(1000, 1048)), 'sha': {}}
+    for fmt in ('foa', 'mic'):
+        if fmt == 'foa':
+            joint = T.ComposeMapTransform([T.TfmapRandomSwapChannelFoa(n_classes=12)])
+            plain = T.ComposeTransformNp([T.RandomShiftUpDownNp(freq_shift_range=10)])
+        else:
+            joint = T.ComposeMapTransform([T.TfmapRandomSwapChannelMic(n_classes=12)])
+            plain = T.ComposeTransformNp([T.RandomShiftUpDownNp(freq_shift_range=10),
+                                          T.CompositeCutout(image_aspect_ratio=48 / 200, n_zero_channels=3)])
+        hs = []
+        for s in meta['seeds']:
+            np.random.seed(s)
+            xo, so, do = joint(x, y_sed, y_doa)
+            xo = plain(xo)
+            assert xo.dtype == np.float32 and do.dtype == np.float32 and so is y_sed
+            hs.append([hashlib.sha256(np.ascontiguousarray(xo).tobytes()).hexdigest(),
+                       hashlib.sha256(np.ascontiguousarray(do).tobytes()).hexdigest()])
+            if s < 1003:
+                arrays['%s_x_%d' % (fmt, s)] = xo
+                arrays['%s_doa_%d' % (fmt, s)] = do
+        meta['sha'][fmt] = hs
+        print('    %s: %d distinct outputs of %d' % (fmt, len({h[0] for h in hs}), len(hs)))
+    save('g11_augment', meta, **arrays)
+
+
 if __name__ == '__main__':
     g5_w_and_bins()
     g1_eigvec()
@@ -297,3 +335,4 @@ if __name__ == '__main__':
     g4_lite()
     g8_stft()
     g10_flexible()
+    g11_augment()
