@@ -9,6 +9,7 @@ every array below is an output of the reference's own functions
   dataset/salsa_lite_feature_extraction.py  extract_features (:18-137)
   contrib/salsa_flexible.py             SalsaFeatures / SalsaLiteFeatures (:271-400), the on-the-fly surface
   utilities/transforms.py               the SALSA training augmentations (datamodule.py:45-52, :73-82)
+  metrics/SELD2021_evaluation_metrics.py, metrics/dcase_utils.py   SELD scores of DCASE-format CSV rows
 driven through tools/ref_shims.py (librosa 0.8.0 / h5py / fire stand-ins -- third-party arithmetic restated there).
 Inputs are regenerated from seeds by salsa_amd/synth.py; each fixture stores the SHA-256 of every input so a drifted
 generator is detected.  Fixtures hold data only (inputs' hashes, parameters, expected outputs).
@@ -327,6 +328,52 @@ def g11_augment():
     save('g11_augment', meta, **arrays)
 
 
+# ----------------------------------------------------------------------------------------------- G12: SELD metrics
+def g12_metrics():
+    """metrics/SELD2021_evaluation_metrics.py + metrics/dcase_utils.py on synthetic DCASE-format rows (CSV round trip
+    included): per-file cumulative (ER, F, LE, LR) and the raw counters."""
+    import types
+    sys.modules.setdefault('IPython', types.SimpleNamespace(embed=lambda *a, **k: None))   # imported, never called
+    from metrics import SELD2021_evaluation_metrics as M, dcase_utils as U
+    rng = np.random.RandomState(12)
+    tmp = tempfile.mkdtemp()
+    ev = M.SELDMetrics(nb_classes=12, doa_threshold=20)
+    arrays, cum = {}, []
+    for fi in range(4):
+        gt, pred = [], []
+        for _ in range(14):                                        # events: class, onset, duration, direction, drift
+            c, t0, dur = rng.randint(12), rng.randint(0, 560), rng.randint(5, 90)
+            azi, ele, tr = rng.randint(-180, 180), rng.randint(-45, 46), rng.randint(3)
+            fate = rng.rand()                                      # detected / missed / detected late with a big error
+            for t in range(t0, min(600, t0 + dur)):
+                gt.append([t, c, tr, azi, ele])
+                if fate < 0.6 or (fate > 0.8 and t > t0 + dur // 2):
+                    err = 8 if fate < 0.6 else 60
+                    a = int(azi + rng.randint(-err, err + 1))
+                    a = (a + 180) % 360 - 180
+                    pred.append([t, c, 0, a, int(np.clip(ele + rng.randint(-err, err + 1), -90, 90))])
+        for _ in range(3):                                         # false alarms
+            c, t0, dur = rng.randint(12), rng.randint(0, 560), rng.randint(5, 40)
+            for t in range(t0, min(600, t0 + dur)):
+                pred.append([t, c, 0, int(rng.randint(-180, 180)), int(rng.randint(-45, 46))])
+        gt.sort(key=lambda r: r[0])
+        pred.sort(key=lambda r: r[0])
+        for name, rows in (('gt', gt), ('pred', pred)):
+            np.savetxt(os.path.join(tmp, '%s%d.csv' % (name, fi)), np.array(rows, dtype=np.int64), fmt='%d', delimiter=',')
+            arrays['%s%d' % (name, fi)] = np.array(rows, dtype=np.int64)
+        g = U.segment_labels(U.load_output_format_file(os.path.join(tmp, 'gt%d.csv' % fi)), _max_frames=600, _nb_label_frames_1s=10)
+        p = U.segment_labels(U.load_output_format_file(os.path.join(tmp, 'pred%d.csv' % fi)), _max_frames=600, _nb_label_frames_1s=10)
+        ev.update_seld_scores(p, g)
+        cum.append([float(v) for v in ev.compute_seld_scores()] +
+                   [float(v) for v in (ev._TP, ev._FP, ev._FN, ev._S, ev._D, ev._I, ev._Nref, ev._DE_TP, ev._DE_FP, ev._DE_FN, ev._total_DE)])
+    empty = M.SELDMetrics(nb_classes=12, doa_threshold=20)
+    save('g12_metrics', {'n_files': 4, 'columns': 'ER F LE LR TP FP FN S D I Nref DE_TP DE_FP DE_FN total_DE',
+                         'no_data_scores': [float(v) for v in empty.compute_seld_scores()]},
+         cumulative=np.array(cum), **arrays)
+    print('    final ER %.4f F %.4f LE %.3f LR %.4f' % tuple(cum[-1][:4]))
+    shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
     g5_w_and_bins()
     g1_eigvec()
@@ -336,3 +383,4 @@ if __name__ == '__main__':
     g8_stft()
     g10_flexible()
     g11_augment()
+    g12_metrics()
