@@ -156,12 +156,26 @@ def main():
             pass
         for k in kernels:
             k['traffic'] = traffic.get(k['name'])
+        # the box's attainable HBM rate ("confirm with a device copy and use the measured peak as denominator too")
+        a1 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        a2 = torch.empty_like(a1)
+        a2.copy_(a1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            a2.copy_(a1)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * a1.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a1, a2
         dom = max(kernels, key=lambda k: k['ms_per_launch'] * k['launches_per_step'])
         step_ms = 1e3 * elapsed / args.steps
         pipe_bytes = sum(ab.values())
         roofline = {'bound': 'hbm', 'kernel': dom['name'], 'kernel_ms': dom['ms_per_launch'],
                     'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(dom['GBps'] / HBM_PEAK_GBS, 4), 'traffic': dom.get('traffic'),
+                    'peak_measured': round(copy_gbs, 1), 'frac_of_measured': round(dom['GBps'] / copy_gbs, 4),
+                    'peak_measured_note': '1 GiB device-to-device copy, read + write bytes / time',
                     'pipeline': {'ms': round(step_ms, 4), 'algorithmic_bytes': pipe_bytes,
                                  'achieved': round(pipe_bytes / (step_ms * 1e-3) / 1e9, 1),
                                  'frac': round(pipe_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -571,9 +571,10 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || ungated) {
             const int k = bin + kp.lower;
+            // delta*k (:121-123); contrib divides by a float32 frequency vector with [0] = 1 (:188-190)
+            const double den = kp.flex ? (double)((float)(k == 0 ? 1 : k) * (float)kp.delta) : kp.delta * (double)k;
             if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e, ungated);
-            else if (kp.flex) salsa::normalise_mic(er.u, (double)((float)(k == 0 ? 1 : k) * (float)kp.delta), e); // float32 norm_freq (:188-190)
-            else salsa::normalise_mic(er.u, kp.delta * (double)k, e);
+            else salsa::normalise_mic(er.u, den, e);
             g = 2;
         } else if (FEAT && kp.flex && !kp.tracking) {
             e[0] = __builtin_nan(""); // marks "failed the test" for flex_allpass_kernel (a passing bin can be exactly 0)
