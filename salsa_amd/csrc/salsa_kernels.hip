@@ -84,8 +84,8 @@ constexpr int FEATURE_LOGSPEC_ONLY = 3;
 // register R-1-r of lane 64-L, so the mirror is fetched with cross-lane shuffles (R/2 complex values) instead of a
 // third trip through LDS.  The spectra are rounded to float32 like the reference's complex64 STFT and used straight
 // from registers: 10*log10 of the power into output channels c0, c1 and the DOA band of both channels as ONE float4
-// per bin into the spill.  A wave walks K1_NF consecutive frames x 2 pairs and prefetches the next item's samples
-// while the current transform runs.  Twiddles and the window live in registers for the whole walk.
+// per bin into the spill.  A wave walks K1_NF consecutive frames x 2 pairs (no software prefetch: the registers it would
+// need cost a wave per SIMD, measured slower); the first twiddle of each pass lives in registers, the window in LDS.
 template <int N> struct fft_cfg {
     static constexpr int R = (N == 512) ? 8 : 4;                 // points per lane; 64 lanes per transform either way
     static constexpr int NP = (N == 512) ? 2 : 3;                // twiddled passes (p = R, R^2, ...)
@@ -338,8 +338,7 @@ __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__
         int t = c0 + first + i - 2;
         if (t >= Tn) t = Tn - 1;
         while (t < 0) t += Tn;
-        const float4 v = active ? x0[t * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
-        x[i] = make_float2(v.x, v.y);
+        x[i] = active ? *(const float2 *)&x0[t * stride] : make_float2(0.f, 0.f); // channel 0 = .xy of pair 0
     }
 }
 
