@@ -7,7 +7,7 @@
 //                       output and spills the DOA band of the spectra (float32-rounded, like the reference's
 //                       complex64 STFT) to the workspace as Xs[b][t][channel pair][bin] (float4).
 //   K2 tracker_kernel   one lane per (clip, bin): 3-frame RMS of channel 0 and the sequential noise-floor tracker
-//                       in float64 -> valid[b][t][bin].
+//                       in float64 -> valid[b][64-frame chunk][bin] (64-bit indicator history per bin).
 //   K3 cov_eig_kernel   one lane per TF bin (64 consecutive bins of one frame per wave, coalesced): 7-frame Hermitian
 //                       covariance accumulated in registers, eigen-gate + principal eigenvector (salsa_math.h),
 //                       FOA / MIC normalisation, writes channels 4-6 (zeros where gated).
@@ -305,27 +305,18 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 
 // ------------------------------------------------------------------------------------------------------------ K2
 // Noise-floor tracker.  The recurrence over time is strictly sequential per (clip, bin), but everything that feeds it
-// (|X0|^2, the 3-frame mean, the float64 divide and square root) is not.  One 512-lane workgroup serves 64 adjacent
+// (|X0|^2, the 3-frame mean, the float64 divide and square root) is not.  One 512-lane workgroup serves TR_BINS adjacent
 // bins of one clip: wave 0 runs the recurrence (a ~5-instruction dependent chain per frame) at raised priority, waves
 // 1-7 stay one chunk of TR_CH frames ahead computing mag[t][bin] into an LDS ring, with the loads of the chunk after
 // that already in flight.  Spill layout: Xs[b][t][pair][bin] as float4 (c0.re, c0.im, c1.re, c1.im); channel 0 is the
-// .xy of pair 0.  Output: valid[b][chunk][group][i] = 64-bit mask of frame 64*chunk+i, bit j = indicator_sig of bin
-// 64*group+j.
+// .xy of pair 0.  Output: valid[b][chunk][group][j] = 64-bit HISTORY of bin 64*group+j over the chunk: bit i =
+// indicator_sig at frame 64*chunk+i.  (A lane appends its own bit per frame -- two integer instructions -- instead of the
+// wave building per-frame masks over bins; K3 turns the words back into per-frame masks with one ballot per frame.)
 constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
 #ifndef TR_WAVES_N
 #define TR_WAVES_N 8
 #endif
 constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
-
-// old with lane `lane` (a compile-time constant after unrolling) replaced by the wave-uniform value `val`.
-// (ROCm 7.2's clang does not expose __builtin_amdgcn_writelane, hence inline asm; hipcc pads nothing inside an asm
-// statement, so the VALU-writes-SGPR -> v_writelane wait states are in the string: see TR_WRITELANE_NOP.)
-template <int DUMMY>
-__device__ __forceinline__ int writelane_const(int val, const int lane, int old)
-{
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
-    return old;
-}
 
 template <int COUNT>
 __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, int stride, int c0,
@@ -342,8 +333,8 @@ __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__
     }
 }
 
-template <int COUNT>
-__device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][64]*/, int lane, bool raw)
+template <int COUNT, int BINS>
+__device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][BINS]*/, int col, bool raw)
 {
     double p[COUNT + 2];
 #pragma unroll
@@ -354,88 +345,107 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 #pragma unroll
     for (int i = 0; i < COUNT; i++) {
         if (first + i < TR_CH) // :53-55 in the reference's order ; contrib :326-328 tracks the raw |X0| instead
-            dst[(first + i) * 64 + lane] = raw ? sqrt(p[i + 2]) : sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3);
+            dst[(first + i) * BINS + col] = raw ? sqrt(p[i + 2]) : sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3);
     }
 }
 
+// One workgroup = BINS adjacent bins of one clip.  Measured (probe builds): the kernel is bound by the PRODUCERS' float64
+// divide + square root, not by the consumer's recurrence (dropping the recurrence changes nothing; dropping the divide
+// and root saves 20 %), and a workgroup's producers all sit on one CU.  With BINS = 32 a producer instruction covers
+// 32 bins x 2 frames, so the same arithmetic is spread over twice as many workgroups / CUs (the consumer simply runs
+// with half its lanes; its chain is as long as before).
+template <int BINS>
 __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                                 unsigned long long *__restrict__ valid)
 {
-    __shared__ double ring[2][TR_CH * 64];
+    static_assert(BINS == 64 || BINS == 32 || BINS == 16, "bins per workgroup");
+    constexpr int FS = 64 / BINS;                               // frames per producer instruction
+    constexpr int PER_ALL = (TR_CH + TR_WAVES * FS - 1) / (TR_WAVES * FS);               // prologue: all waves produce chunk 0
+    constexpr int PER_PROD = (TR_CH + (TR_WAVES - 1) * FS - 1) / ((TR_WAVES - 1) * FS);  // frames per producer lane per chunk
+    __shared__ double ring[2][TR_CH * BINS];
     const int ngroups = (kp.nd + 63) / 64;
-    const int b = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    const int b = blockIdx.x / (ngroups * FS), g = (blockIdx.x / FS) % ngroups, h = blockIdx.x % FS;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bin = g * 64 + lane;
+    const int col = lane % BINS, fsub = lane / BINS;            // producers: lane = (frame sub-slot, bin column)
+    const int bin = g * 64 + h * BINS + col;
     const bool active = bin < kp.nd;
     const int Tn = kp.T;
     const int stride = 2 * kp.nd; // float4 elements per frame
     const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
     const int nchunks = (Tn + TR_CH - 1) / TR_CH;
-    constexpr int PER_ALL = TR_CH / TR_WAVES;               // prologue: all waves produce chunk 0
-    constexpr int PER_PROD = (TR_CH + TR_WAVES - 2) / (TR_WAVES - 1);
     {
         float2 x[PER_ALL + 2];
-        tracker_load<PER_ALL>(kp, x0, stride, 0, w * PER_ALL, active, x);
-        tracker_mag<PER_ALL>(x, w * PER_ALL, ring[0], lane, kp.flex != 0);
+        const int first = (w * FS + fsub) * PER_ALL;
+        tracker_load<PER_ALL>(kp, x0, stride, 0, first, active, x);
+        tracker_mag<PER_ALL, BINS>(x, first, ring[0], col, kp.flex != 0);
     }
     float2 xr[PER_PROD + 2];
-    const int pfirst = (w - 1) * PER_PROD;
+    const int pfirst = ((w - 1) * FS + fsub) * PER_PROD;
     if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xr);
     __syncthreads();
     // Consumer state: noise floor + countdown (salsa_feature_extraction.py:30, :58).  The recurrence is evaluated with
     // exactly the reference's operations (one float64 multiply by 1.02 / 1.002 / 0.98, the 1e-6 clamp, the two strict
     // compares), but arranged so the dependent chain per frame is  multiply -> select -> max : both candidate
-    // products are formed before the above/below compare resolves.  indicator_sig is a wave-wide compare mask (bit =
-    // bin) dropped into lane i of a VGPR pair for frame i of the chunk: one coalesced 8-byte store per lane per chunk.
+    // products are formed before the above/below compare resolves.  indicator_sig is shifted into the lane's own
+    // 64-frame history word: one coalesced 8-byte store per lane per chunk.
     double fl = 0.0;
     int cd = 3;
     const double snr = kp.snr_ratio;
-    unsigned long long *vout = valid + (((long)b * nchunks) * ngroups + g) * TR_CH + lane; // [b][chunk][group][frame]
+    unsigned long long *vout = valid + (((long)b * nchunks) * ngroups + g) * TR_CH + h * BINS + col; // [b][chunk][group][bin]
     if (w == 0) __builtin_amdgcn_s_setprio(3);
     for (int c = 0; c < nchunks; c++) {
         const double *cur = ring[c & 1];
         if (w == 0) {
-            if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
-                const int n0 = Tn < 5 ? Tn : 5;
-                double acc = 0.0;
-                for (int t = 0; t < n0; t++) acc += cur[t * 64 + lane];
-                fl = 0.5 * (acc / (double)n0);
-                if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
-            }
-            int lo = 0, hi = 0;
-            const int nfr = __builtin_amdgcn_readfirstlane(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH); // scalar
-            if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
+            if (lane < BINS) { // the consumer: one lane per bin
+                if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
+                    const int n0 = Tn < 5 ? Tn : 5;
+                    double acc = 0.0;
+                    for (int t = 0; t < n0; t++) acc += cur[t * BINS + lane];
+                    fl = 0.5 * (acc / (double)n0);
+                    if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
+                }
+                unsigned lo = 0, hi = 0; // this bin's indicator bits, newest in bit 0 (reversed once at the end of the chunk)
+                const int nfr = __builtin_amdgcn_readfirstlane(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH); // scalar
+                if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
 #pragma unroll
-                for (int i0 = 0; i0 < TR_CH; i0 += 16) {
-                    double m[16]; // one LDS round trip per 16 frames, not per frame
+                    for (int i0 = 0; i0 < TR_CH; i0 += 16) {
+                        double m[16]; // one LDS round trip per 16 frames, not per frame
 #pragma unroll
-                    for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * 64 + lane];
+                        for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * BINS + lane];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const bool s1 = salsa::tracker_step(fl, cd, m[i], snr);           // :65-87
-                        const unsigned long long sig = __ballot(s1);                        // bit = lane = bin of this group
-                        lo = writelane_const<0>((int)(unsigned)sig, i0 + i, lo);
-                        hi = writelane_const<0>((int)(unsigned)(sig >> 32), i0 + i, hi);
+                        for (int i = 0; i < 16; i++) {
+                            const unsigned s1 = salsa::tracker_step(fl, cd, m[i], snr) ? 1u : 0u;   // :65-87
+                            if (i0 < 32) lo = (lo << 1) | s1;
+                            else hi = (hi << 1) | s1;
+                        }
                     }
+                    lo = __builtin_bitreverse32(lo);
+                    hi = __builtin_bitreverse32(hi);
+                } else {
+                    unsigned long long hw = 0;
+                    for (int i = 0; i < nfr; i++)
+                        hw |= (unsigned long long)(salsa::tracker_step(fl, cd, cur[i * BINS + lane], snr) ? 1u : 0u) << i;
+                    lo = (unsigned)hw;
+                    hi = (unsigned)(hw >> 32);
                 }
-            } else {
-                for (int i = 0; i < nfr; i++) {
-                    const bool s1 = salsa::tracker_step(fl, cd, cur[i * 64 + lane], snr);
-                    const unsigned long long sig = __ballot(s1);
-                    if (lane == i) { lo = (int)(unsigned)sig; hi = (int)(unsigned)(sig >> 32); }
-                }
+                vout[(long)c * ngroups * TR_CH] = ((unsigned long long)hi << 32) | lo;
             }
-            vout[(long)c * ngroups * TR_CH] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
         } else if (c + 1 < nchunks) {
             float2 xn[PER_PROD + 2];
             if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, xn);
-            tracker_mag<PER_PROD>(xr, pfirst, ring[(c + 1) & 1], lane, kp.flex != 0);
+            tracker_mag<PER_PROD, BINS>(xr, pfirst, ring[(c + 1) & 1], col, kp.flex != 0);
 #pragma unroll
             for (int i = 0; i < PER_PROD + 2; i++) xr[i] = xn[i];
         }
         __syncthreads();
     }
 }
+
+#ifndef TR_BINS_N
+#define TR_BINS_N 32
+#endif
+constexpr int TR_BINS = TR_BINS_N;
+static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + 63) / 64) * (64 / TR_BINS)); }
 
 // ------------------------------------------------------------------------------------------------------------ K3
 // Covariance + eigen-gate + eigenvector.  Only TF bins that pass the noise gate need the (float64, ~700 instruction)
@@ -482,23 +492,25 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     };
     const double zero3[3] = {0.0, 0.0, 0.0};
     {
-        // Compaction.  lane = bin; a wave covers exactly one 64-bin group, so the gate word of (frame, group) is a
-        // wave-uniform scalar whose bits ARE the lanes to keep.  Each wave counts its K3_FT words with scalar popcounts,
-        // reserves its slice of the work list with ONE LDS atomic, and every kept lane drops its (frame, bin) at
-        // slice + (bits below it): lane order survives, so neighbouring list entries are neighbouring bins.
+        // Compaction.  lane = bin; a wave covers exactly one 64-bin group, so the gate mask of (frame, group) -- one ballot
+        // over the lanes' history bits -- is a wave-uniform scalar whose bits ARE the lanes to keep.  Each wave counts its
+        // K3_FT masks with scalar popcounts, reserves its slice of the work list with ONE LDS atomic, and every kept lane
+        // drops its (frame, bin) at slice + (bits below it): lane order survives, so neighbouring list entries are
+        // neighbouring bins.
         const int bl = tid;
         const bool in = bl < nbc;
         const int nchunks = (Tn + TR_CH - 1) / TR_CH, ngroups = (kp.nd + 63) / 64;
         const int bin = bin0 + bl;
         const int lane = tid & 63;
         const int grp = __builtin_amdgcn_readfirstlane(bin >> 6) < ngroups ? __builtin_amdgcn_readfirstlane(bin >> 6) : ngroups - 1;
-        const unsigned long long *vw = valid + (((long)b * nchunks + t0 / TR_CH) * ngroups + grp) * TR_CH + t0 % TR_CH;
-        const unsigned long long inmask = __ballot(in);
+        // this bin's 64-frame history word of the tile's chunk (coalesced 8-byte loads); frame ft of the tile is bit sh + ft
+        const unsigned long long mine = (kp.tracking && in) ? valid[(((long)b * nchunks + t0 / TR_CH) * ngroups + grp) * TR_CH + lane] : ~0ull;
+        const int sh = t0 % TR_CH;
         unsigned long long words[K3_FT];
         int total = 0;
 #pragma unroll
         for (int ft = 0; ft < K3_FT; ft++) {
-            words[ft] = ft < nft ? ((kp.tracking ? vw[ft] : ~0ull) & inmask) : 0ull;
+            words[ft] = ft < nft ? __ballot(in && ((mine >> (sh + ft)) & 1)) : 0ull; // back to a mask over the wave's bins
             total += __popcll(words[ft]);
         }
         int base = 0;
@@ -972,6 +984,11 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         return fail(SALSA_EINVAL, "salsa_extract_batch: bad argument%s");
     if (n_samples <= pl->p.n_fft / 2)
         return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != pl->device)
+            return fail(SALSA_EINVAL, "the plan's tables live on the device that was current at salsa_plan_create; make it current%s");
+    }
     {   // kernels index inside one clip with 32-bit offsets
         const int64_t T64 = 1 + n_samples / pl->p.hop_len;
         if (n_samples * 4 >= INT32_MAX || T64 * 7 * pl->F >= INT32_MAX || T64 * 2 * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX)
@@ -1014,7 +1031,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         if (gp.tracking) {
             m = mark_begin(pl, s2, "noise_floor_tracker");
-            hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(gp.B * ((gp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
+            hipLaunchKernelGGL(tracker_kernel<TR_BINS>, dim3(tracker_grid(gp)), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
             mark_end(pl, s2, m);
             HIP_TRY(hipGetLastError());
         }
@@ -1093,7 +1110,7 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
     if (kp.tracking) {
-        hipLaunchKernelGGL(tracker_kernel, dim3((unsigned)(kp.B * ((kp.nd + 63) / 64))), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
+        hipLaunchKernelGGL(tracker_kernel<TR_BINS>, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
         HIP_TRY(hipGetLastError());
     }
     const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);

@@ -98,9 +98,8 @@ class SalsaExtractor:
             self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    @staticmethod
-    def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ hot path
     def extract(self, audio: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
@@ -111,6 +110,8 @@ class SalsaExtractor:
         else:
             B, N, ch = audio.shape
         assert ch == 4, 'SALSA features are defined for 4-channel clips'
+        if audio.device != self.device:
+            raise ValueError('plan is bound to %s, audio is on %s' % (self.device, audio.device))
         Cn, T, F = self.output_shape(N)
         if out is None:
             out = torch.empty((B, Cn, T, F), dtype=torch.float32, device=audio.device)

@@ -1,6 +1,7 @@
 // tests/hostemu/hostemu.cpp -- CPU unit-test harness for salsa_amd/csrc/salsa_math.h (the per-thread arithmetic of the
 // HIP kernels).  TEST INFRASTRUCTURE ONLY: it lets `pytest -m "not gpu"` exercise the kernels' butterflies, Stockham
 // addressing and eigen-gate on CPU (no GPU in the build container).  The product never loads it and has no CPU path.
+#include <string.h>
 #include "../../salsa_amd/csrc/salsa_math.h"
 #include <vector>
 using namespace salsa;

@@ -189,3 +189,4 @@ def test_solver_stress_controlled_spectra(emu):
                     q = Q[:, 0]
                     c = abs(np.vdot(q, uu)) / (np.linalg.norm(uu) + 1e-300)
                     assert c > 1 - 1e-9, (lam, scale, c)
+
