@@ -104,6 +104,13 @@ __device__ __forceinline__ void wave_lds_fence()
 // 4-byte row stores into full lines, which nt stores forgo -- so plain stores are used throughout.)
 __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
+// Addressing: a wave-uniform base pointer (SGPR pair) + a 32-bit unsigned BYTE offset per lane lets the compiler use the
+// "saddr" form of global loads/stores; `ptr[int_index]` instead costs two or three 64-bit VALU instructions per access
+// (sign extension, shift, 64-bit add), and K1 / K3 are VALU-issue bound.  The host checks that a clip's arrays stay
+// below 4 GiB.
+template <typename V> __device__ __forceinline__ void st_off(V *base, unsigned byte_off, const V v) { *(V *)((char *)base + byte_off) = v; }
+template <typename V> __device__ __forceinline__ V ld_off(const V *base, unsigned byte_off) { return *(const V *)((const char *)base + byte_off); }
+
 constexpr int K1_NF = 8;                                          // frames per wave
 constexpr int K1_FRAMES_PER_BLOCK = 4 * K1_NF;
 
@@ -147,18 +154,30 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     // fold suffices because Ns > N/2, checked on the host).
     const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
     const int sstride = planar ? 1 : 4;
+    // Item order.  Full SALSA: PAIR-major (all the wave's frames of channels 0/1, then of channels 2/3), so consecutive
+    // items re-read the 41 % of samples that overlapping frames share while they are still in L2 (frame-major order
+    // puts another 4 KiB item and a whole CU's worth of traffic in between: measured 1.7x audio over-fetch).  SALSA-Lite
+    // needs channel 0 of the same frame when it processes pair 1, so it stays frame-major.
+#if defined(K1_FRAME_MAJOR)
+    constexpr bool PAIR_MAJOR = false;
+#else
+    constexpr bool PAIR_MAJOR = !LITE;
+#endif
+    const int nfr_ = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
+    auto item_frame = [&](int item) { return PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1; };
+    auto item_pair = [&](int item) { return PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1; };
     auto load_item = [&](int item, float *y0, float *y1) {
-        const int t = t_begin + (item >> 1);
-        const int c0 = 2 * (item & 1);
+        const int t = t_begin + item_frame(item);
+        const int c0 = 2 * item_pair(item);
         const int base = t * kp.hop - N / 2;
-        const float *p0 = clip + (planar ? c0 * Ns : c0);
-        const float *p1 = p0 + (planar ? Ns : 1);
+        const unsigned ch0 = 4u * (unsigned)(planar ? c0 * Ns : c0), ch1 = ch0 + 4u * (unsigned)(planar ? Ns : 1); // byte offsets
+        const unsigned step = 4u * (unsigned)sstride;
         if (base >= 0 && base + N <= Ns) {
-            const float *q0 = p0 + (base + lane) * sstride, *q1 = p1 + (base + lane) * sstride;
+            const unsigned q = (unsigned)(base + lane) * step;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                y0[r] = q0[r * (N / R) * sstride];
-                y1[r] = q1[r * (N / R) * sstride];
+                y0[r] = ld_off(clip, ch0 + q + (unsigned)(r * (N / R)) * step);
+                y1[r] = ld_off(clip, ch1 + q + (unsigned)(r * (N / R)) * step);
             }
         } else {
 #pragma unroll
@@ -166,13 +185,13 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 int s = base + salsa::stockham_in(lane, r, N, R);
                 s = s < 0 ? -s : s;
                 s = s >= Ns ? 2 * (Ns - 1) - s : s;
-                y0[r] = p0[s * sstride];
-                y1[r] = p1[s * sstride];
+                y0[r] = ld_off(clip, ch0 + (unsigned)s * step);
+                y1[r] = ld_off(clip, ch1 + (unsigned)s * step);
             }
         }
     };
 
-    const int nitems = (Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF) * 2;
+    const int nitems = nfr_ * 2;
     float y0[R], y1[R];
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
@@ -180,13 +199,15 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
         const float v = db10(p);
-        return kp.sc_mean ? (v - kp.sc_mean[c * kp.F + f]) / kp.sc_std[c * kp.F + f] : v;
+        const unsigned off = 4u * (unsigned)(c * kp.F + f);
+        return kp.sc_mean ? (v - ld_off(kp.sc_mean, off)) / ld_off(kp.sc_std, off) : v;
     };
+    const unsigned plane = 4u * (unsigned)(Tn * kp.F); // bytes of one output channel of a clip
     float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
 
     for (int item = 0; item < nitems; item++) {
-        const int t = t_begin + (item >> 1);
-        const int pr = item & 1;
+        const int t = t_begin + item_frame(item);
+        const int pr = item_pair(item);
         load_item(item, y0, y1);
         cplx<T> v[R];
 #pragma unroll
@@ -238,10 +259,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    xs[(t * 2 + pr) * kp.nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
+                    st_off(xs, 16u * (unsigned)((t * 2 + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
                 if (k >= kp.spec_lo && k < kp.spec_hi) {
-                    o[(c0 * Tn + t) * kp.F + (k - kp.spec_lo)] = spec(pa, c0, k - kp.spec_lo);
-                    o[((c0 + 1) * Tn + t) * kp.F + (k - kp.spec_lo)] = spec(pb, c0 + 1, k - kp.spec_lo);
+                    const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + (k - kp.spec_lo));
+                    st_off(o, off, spec(pa, c0, k - kp.spec_lo));
+                    st_off(o, off + plane, spec(pb, c0 + 1, k - kp.spec_lo));
                 } else if (kp.compress && k > kp.ident && k < N / 2) {
                     pw[w][0][k - kp.ident - 1] = pa;
                     pw[w][1][k - kp.ident - 1] = pb;
@@ -250,8 +272,9 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 if (pr == 0) x0k = xa;
                 if (k >= kp.lower && k < kp.cutoff) {
                     const int f = k - kp.lower;
-                    o[(c0 * Tn + t) * kp.F + f] = spec(pa, c0, f);
-                    o[((c0 + 1) * Tn + t) * kp.F + f] = spec(pb, c0 + 1, f);
+                    const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + f);
+                    st_off(o, off, spec(pa, c0, f));
+                    st_off(o, off + plane, spec(pb, c0 + 1, f));
                     const float2 x0 = x0k;
                     // angle(X_c conj(X_0)) / (delta*k) (lite :111-115) or / pi (ipd :113).  float32 throughout: the
                     // product's rounding moves the angle by <= 1e-7 rad and 1/(delta*k) is the float64 quotient rounded
@@ -272,8 +295,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                         }
                         return atan2f(wi, wr) * inv_scale;
                     };
-                    if (pr == 1) o[((3 + c0) * Tn + t) * kp.F + f] = phase(xa);
-                    o[((4 + c0) * Tn + t) * kp.F + f] = phase(xb);
+                    if (pr == 1) st_off(o, off + 3u * plane, phase(xa));
+                    st_off(o, off + 4u * plane, phase(xb));
                 }
             }
         };
@@ -296,7 +319,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                 const int cnt = gi < ng - 1 ? 8 : 7;
                 float acc = 0.f;
                 for (int q = 0; q < cnt; q++) acc += 0.125f * pw[w][h][8 * gi + q];
-                o[((c0 + h) * Tn + t) * kp.F + kp.ident + gi] = spec(acc, c0 + h, kp.ident + gi);
+                st_off(o, 4u * (unsigned)(((c0 + h) * Tn + t) * kp.F + kp.ident + gi), spec(acc, c0 + h, kp.ident + gi));
             }
         }
         wave_lds_fence(); // this item's LDS reads are done before the next item's first pass overwrites z / pw
@@ -482,8 +505,9 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     unsigned char *og = (!FEAT && gate) ? gate + (long)b * kp.nd * Tn : nullptr;
     auto emit = [&](int t, int bin, const double *e, unsigned char g) {
         if (FEAT) {
+            const unsigned off = 4u * (unsigned)(t * kp.F + bin), plane = 4u * (unsigned)(Tn * kp.F);
 #pragma unroll
-            for (int i = 0; i < 3; i++) of[(i * Tn + t) * kp.F + bin] = (float)e[i];
+            for (int i = 0; i < 3; i++) st_off(of, off + (unsigned)i * plane, (float)e[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < 3; i++) oe[((long)i * kp.nd + bin) * Tn + t] = e[i];
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         for (int i = tid; i < nft * tail; i += 256) {
             const int ft = i / tail, f = kp.nd + (i - ft * tail);
 #pragma unroll
-            for (int c = 0; c < 3; c++) of[(c * Tn + t0 + ft) * kp.F + f] = 0.f;
+            for (int c = 0; c < 3; c++) st_off(of, 4u * (unsigned)((c * Tn + t0 + ft) * kp.F + f), 0.f);
         }
     }
     __syncthreads();
@@ -545,6 +569,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         const int bin = bin0 + (i & 255);
         salsa::herm4<double> R = {};
         const float4 *xb = xclip + bin;
+        const unsigned row = 16u * (unsigned)stride, boff = 16u * (unsigned)bin, half = 16u * (unsigned)kp.nd; // bytes
         if (NHOP >= 0) {
             // all 2*NHOP+1 frames as independent 16-B loads issued together (splitting them into batches to save VGPRs
             // was measured slower: the loads' latency is what this kernel hides)
@@ -555,8 +580,8 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                 int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
                 while (tt < 0) tt += Tn;
                 while (tt >= Tn) tt -= Tn;
-                xa[k] = xb[tt * stride];
-                xc[k] = xb[tt * stride + kp.nd];
+                xa[k] = ld_off(xclip, (unsigned)tt * row + boff);
+                xc[k] = ld_off(xclip, (unsigned)tt * row + boff + half);
             }
 #pragma unroll
             for (int k = 0; k < NW; k++) {
@@ -991,7 +1016,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
     }
     {   // kernels index inside one clip with 32-bit offsets
         const int64_t T64 = 1 + n_samples / pl->p.hop_len;
-        if (n_samples * 4 >= INT32_MAX || T64 * 7 * pl->F >= INT32_MAX || T64 * 2 * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX)
+        if (n_samples * 16 >= INT32_MAX || T64 * 7 * pl->F >= INT32_MAX / 2 || T64 * 2 * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX / 8)
             return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
         if ((T64 + K3_FT - 1) / K3_FT > 65535) return fail(SALSA_EINVAL, "clip too long for one launch (split it)%s");
     }
@@ -1072,7 +1097,7 @@ int salsa_logspec_batch(salsa_plan *pl, const float *d_audio, int batch, int n_c
     if (!pl || !d_audio || !d_out || batch <= 0 || n_samples <= 0) return fail(SALSA_EINVAL, "salsa_logspec_batch: bad argument%s");
     if (n_channels != 4) return fail(SALSA_EINVAL, "salsa_logspec_batch: n_channels must be 4 (pad with silent channels)%s");
     if (n_samples <= pl->p.n_fft / 2) return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
-    if (n_samples * 4 >= INT32_MAX || (1 + n_samples / pl->p.hop_len) * 7 * 256 >= INT32_MAX)
+    if (n_samples * 16 >= INT32_MAX || (1 + n_samples / pl->p.hop_len) * 7 * 256 >= INT32_MAX / 2)
         return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
     KParams kp = make_kparams(pl, batch, n_samples);
     kp.feature = FEATURE_LOGSPEC_ONLY;
