@@ -458,6 +458,30 @@ def test_contrib_flexible_batch_against_oracle(dev, oracle):
             assert (out[:, 4:] != 0).any(), 'degenerate case: nothing passed the gates'
 
 
+def test_contrib_flexible_nfft256_and_long_clip_against_oracle(dev, oracle):
+    from flex_compare import compare_flexible
+    from salsa_amd.flexible import SalsaFeatures
+    ctor = dict(fs=24000, stft_winsize=256, hop_length=150, fmin_doa=50, fmax_doa=3000, fmax_spec=9000)
+    call = dict(clip_freqs=True, clip_spatial_alias=True)
+    n = 2 * 24000 + 31
+    y = synth_clip(411, n)
+    out = SalsaFeatures(**ctor)(y, **call)
+    kw = dict(ctor)
+    kw.update(call)
+    ref = oracle.flexible(y, kind='salsa', **kw)
+    compare_flexible(out, ref[:4].astype(np.float32), ref[4:], {'n_ch': 4, 'ctor': ctor, 'call': call}, n,
+                     spec_tol=(RTOL, ATOL_DB), spat_tol=ATOL_SP, spat_rtol=RTOL)
+
+
+def test_long_single_clip_against_oracle(dev, oracle):
+    """200 s in one clip (33x the chunks of the goldens): tracker hand-over across 250 chunks, 32-bit offsets."""
+    n = 200 * 24000 + 123
+    y = synth_clip(77, n)
+    out = _gpu_features(y, dev, audio_format='foa')
+    ref, aux = oracle.extract_salsa(y, audio_format='foa', return_aux=True)
+    _check(out, ref, margin=aux['margin'])
+
+
 def test_to_freq_major(dev):
     from salsa_amd.flexible import to_freq_major
     x = torch.randn(3, 7, 131, 77, device=dev)
