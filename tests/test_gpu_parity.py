@@ -492,3 +492,11 @@ def test_to_freq_major(dev):
     with pytest.raises(AssertionError):
         from salsa_amd.flexible import SalsaFeatures
         SalsaFeatures(fmax_doa=9500)                                            # contrib :183
+
+
+def test_torch_op_equals_the_extractor(dev):
+    import salsa_amd.torch_ops  # noqa: F401
+    a = torch.from_numpy(np.stack([synth_clip(500 + i, 30000) for i in range(2)])).to(dev)
+    assert torch.equal(torch.ops.salsa.extract(a), _extractor().extract(a))
+    assert torch.equal(torch.ops.salsa.extract(a, 'mic', 'salsa_lite', 24000, 512, 300, 50, 2000),
+                       _extractor(audio_format='mic', feature_type='salsa_lite', fmax_doa=2000).extract(a))

@@ -61,3 +61,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libsalsa_hip.so'))
     with pytest.raises(RuntimeError, match='hipcc'):
         _lib.load()
+
+
+def test_torch_op_is_registered_with_a_shape_function():
+    """torch.ops.salsa.extract: registered on import, FakeTensor shapes follow the reference's (7,T,F), and a
+    CPU tensor is refused (no CPU path)."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import salsa_amd.torch_ops  # noqa: F401
+    with FakeTensorMode():
+        a = torch.empty(3, 4, 48000)
+        assert tuple(torch.ops.salsa.extract(a).shape) == (3, 7, 161, 200)
+        assert tuple(torch.ops.salsa.extract(a, 'mic', 'salsa_lite', 24000, 512, 300, 50, 2000).shape) == (3, 7, 161, 191)
+        assert tuple(torch.ops.salsa.extract(a, 'foa', 'salsa', 24000, 256, 150, 50, 9000, 5.0, 3, True, False).shape) == (3, 7, 321, 128)
+    with pytest.raises(RuntimeError):
+        torch.ops.salsa.extract(torch.zeros(1, 4, 4000))
