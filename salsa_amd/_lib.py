@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libsalsa_hip.so')
 SRC_PATH = os.path.join(_HERE, 'csrc', 'salsa_kernels.hip')
 GRU_SRC_PATH = os.path.join(_HERE, 'csrc', 'gru_scan.hip')
+NN_SRC_PATH = os.path.join(_HERE, 'csrc', 'nn_ops.hip')
 
 FORMAT = {'foa': 0, 'mic': 1}
 FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
@@ -29,7 +30,7 @@ _lib = None
 
 
 def build_command():
-    return ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB_PATH, SRC_PATH, GRU_SRC_PATH]
+    return ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', LIB_PATH, SRC_PATH, GRU_SRC_PATH, NN_SRC_PATH]
 
 
 def load():
@@ -62,6 +63,8 @@ def load():
     L.salsa_plan_set_scaler.argtypes = [vp, vp, vp]
     L.salsa_gru_scan_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_gru_scan_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.salsa_nn_avgpool2x2_fwd.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp]
+    L.salsa_nn_avgpool2x2_bwd.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
     L.salsa_normalize_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp]
     L.salsa_to_freq_major.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, vp]
@@ -79,3 +82,4 @@ EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_c
            'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
            'salsa_to_freq_major']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_bwd']
+NN_EXPORTS = ['salsa_nn_avgpool2x2_fwd', 'salsa_nn_avgpool2x2_bwd']

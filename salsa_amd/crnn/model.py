@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .nn_ops import avg_pool2x2
+
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
 FUSED_GRU = os.environ.get('SALSA_FUSED_GRU', '1') == '1'
@@ -39,7 +41,7 @@ class Stem(nn.Module):
     def forward(self, x):
         x = F.relu(self.bn1(self.conv1(x)), inplace=True)
         x = F.relu(self.bn2(self.conv2(x)), inplace=True)
-        return F.avg_pool2d(x, 2)
+        return avg_pool2x2(x)
 
 
 class ResBlock(nn.Module):
@@ -57,7 +59,7 @@ class ResBlock(nn.Module):
             self.short_conv, self.short_bn = _conv(cin, cout, 1), nn.BatchNorm2d(cout)
 
     def forward(self, x):
-        y = F.avg_pool2d(x, 2) if self.stride == 2 else x
+        y = avg_pool2x2(x) if self.stride == 2 else x
         out = F.relu(self.bn1(self.conv1(y)), inplace=True)
         out = F.dropout(out, p=0.1, training=self.training)
         out = self.bn2(self.conv2(out))

@@ -33,6 +33,9 @@ def test_every_declared_symbol_is_exported(lib):
     gru = re.sub(r'/\*.*?\*/', '', gru, flags=re.S)
     gnames = set(re.findall(r'\b(salsa_gru_[a-z_]+)\s*\(', gru))
     assert gnames == set(_lib.GRU_EXPORTS) and all(hasattr(lib, n) for n in gnames)
+    nn = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'salsa_nn.h')).read(), flags=re.S)
+    nnames = set(re.findall(r'\b(salsa_nn_[a-z0-9_]+)\s*\(', nn))
+    assert nnames == set(_lib.NN_EXPORTS) and all(hasattr(lib, n) for n in nnames)
 
 
 def test_host_helpers_match_reference(lib):

@@ -66,3 +66,23 @@ def test_fused_gru_scan_matches_torch_gru_forward_and_backward():
         assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5), float((out - ref).abs().max())
         for a, b in zip(got_grads, ref_grads):
             assert torch.allclose(a, b, rtol=2e-3, atol=2e-4), float((a - b).abs().max())
+
+
+def test_hip_avgpool_matches_torch_forward_and_backward():
+    """salsa_nn_avgpool2x2 (channels-last, bf16 and float32, odd sizes) against F.avg_pool2d: values and gradients."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import _AvgPool2x2, avg_pool2x2
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(0)
+    for dtype, (n, c, h, w) in ((torch.bfloat16, (3, 64, 40, 25)), (torch.float32, (2, 8, 7, 6)), (torch.bfloat16, (2, 128, 80, 13))):
+        x = torch.randn((n, c, h, w), device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = avg_pool2x2(xa), F.avg_pool2d(xb, 2)
+        assert isinstance(ya.grad_fn, _AvgPool2x2._backward_cls) and ya.shape == yb.shape
+        assert torch.equal(ya, yb), dtype
+        gy = torch.randn(yb.shape, device=dev, generator=g).to(dtype)
+        ya.backward(gy)
+        yb.backward(gy)
+        assert torch.equal(xa.grad, xb.grad), dtype
+    x = torch.randn(2, 7, 8, 8, device=dev)                                     # 7 channels: falls through to torch
+    assert torch.equal(avg_pool2x2(x), F.avg_pool2d(x, 2))
