@@ -7,9 +7,20 @@
  *   the strided residual stages of the PANN ResNet22): y[n][h][w][c] = (x[2h][2w] + x[2h][2w+1] + x[2h+1][2w] +
  *   x[2h+1][2w+1]) / 4 accumulated in float32 in that order; odd trailing rows / columns are dropped (floor mode) and
  *   get zero gradient.  C must be a multiple of 8 (bf16) or 4 (float32).
+ *
+ *   salsa_nn_bn_*: nn.BatchNorm2d of the upstream blocks fused with what follows it there -- the residual add and the
+ *   ReLU (models/model_utils.py:187-228, :312-367): y = [relu]( ((x - mean) * invstd) * gamma + beta [+ residual] ).
+ *   x, y, residual, dy, dx: [M][C] (M = N*H*W) in `dtype`; gamma, beta, statistics: float32 [C].  Training statistics are
+ *   accumulated per block in float32 and across blocks in float64 (sums_ws: salsa_nn_bn_workspace_bytes of scratch) and the running statistics are updated like torch does
+ *   (momentum, unbiased variance).  Backward: with g = dy * (y > 0) (relu = 0: g = dy),
+ *   dbeta = sum g, dgamma = sum g * xhat, dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M), and dres = g when the
+ *   forward had a residual.  With relu != 0 and y_or_null = NULL (allowed when the forward had NO residual) the mask is
+ *   recomputed from x, which saves reading y.  coef_ws: 7*C floats of scratch.  salsa_nn_bn_supported: C/L must be a power of two <= 256
+ *   (L = 8 for bf16, 4 for float32).
  */
 #ifndef SALSA_NN_H
 #define SALSA_NN_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -17,6 +28,17 @@ extern "C" {
 
 int salsa_nn_avgpool2x2_fwd(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
 int salsa_nn_avgpool2x2_bwd(const void *grad_y, void *grad_x, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
+
+int salsa_nn_bn_supported(int dtype, int64_t M, int C);
+size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C); /* size of sums_ws (8-byte aligned) */
+int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                          float *save_mean, float *save_invstd, double *sums_ws, int relu, void *hip_stream);
+int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                         const float *beta, const float *mean, const float *invstd, int relu, void *hip_stream);
+int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *dx, void *dres_or_null, int dtype, int64_t M,
+                    int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream);
 
 #ifdef __cplusplus
 }

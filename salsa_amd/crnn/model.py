@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import avg_pool2x2
+from .nn_ops import BatchNormAct2d, avg_pool2x2
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -35,12 +35,12 @@ class Stem(nn.Module):
 
     def __init__(self, cin, cout):
         super().__init__()
-        self.conv1, self.bn1 = _conv(cin, cout, 3), nn.BatchNorm2d(cout)
-        self.conv2, self.bn2 = _conv(cout, cout, 3), nn.BatchNorm2d(cout)
+        self.conv1, self.bn1 = _conv(cin, cout, 3), BatchNormAct2d(cout)
+        self.conv2, self.bn2 = _conv(cout, cout, 3), BatchNormAct2d(cout)
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        x = F.relu(self.bn2(self.conv2(x)), inplace=True)
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
         return avg_pool2x2(x)
 
 
@@ -51,21 +51,20 @@ class ResBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
         self.stride = stride
-        self.conv1, self.bn1 = _conv(cin, cout, 3), nn.BatchNorm2d(cout)
-        self.conv2, self.bn2 = _conv(cout, cout, 3), nn.BatchNorm2d(cout)
+        self.conv1, self.bn1 = _conv(cin, cout, 3), BatchNormAct2d(cout)
+        self.conv2, self.bn2 = _conv(cout, cout, 3), BatchNormAct2d(cout)
         nn.init.zeros_(self.bn2.weight)
         self.short_conv, self.short_bn = None, None
         if stride != 1 or cin != cout:                      # 1x1 conv + BN shortcut (after the pool when strided)
-            self.short_conv, self.short_bn = _conv(cin, cout, 1), nn.BatchNorm2d(cout)
+            self.short_conv, self.short_bn = _conv(cin, cout, 1), BatchNormAct2d(cout)
 
     def forward(self, x):
         y = avg_pool2x2(x) if self.stride == 2 else x
-        out = F.relu(self.bn1(self.conv1(y)), inplace=True)
+        out = self.bn1(self.conv1(y), relu=True)
         out = F.dropout(out, p=0.1, training=self.training)
-        out = self.bn2(self.conv2(out))
         if self.short_conv is not None:
             x = self.short_bn(self.short_conv(y))
-        return F.relu(out + x, inplace=True)
+        return self.bn2(self.conv2(out), residual=x, relu=True)            # relu(bn2(conv2(out)) + shortcut)
 
 
 class Encoder(nn.Module):

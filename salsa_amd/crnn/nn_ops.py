@@ -11,6 +11,7 @@ from .. import _lib
 
 _DT = {torch.float32: (0, 4), torch.bfloat16: (1, 8)}
 USE_HIP_POOL = os.environ.get('SALSA_HIP_POOL', '1') != '0'
+USE_HIP_BN = os.environ.get('SALSA_HIP_BN', '1') != '0'
 
 
 def _stream(t):
@@ -49,3 +50,80 @@ def avg_pool2x2(x: torch.Tensor) -> torch.Tensor:
             and x.shape[2] >= 2 and x.shape[3] >= 2 and x.is_contiguous(memory_format=torch.channels_last)):
         return _AvgPool2x2.apply(x)
     return F.avg_pool2d(x, 2)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _BnAct(torch.autograd.Function):
+    """y = [relu]( batch_norm(x) [+ residual] ) in training mode (salsa_nn_bn_train_fwd / salsa_nn_bn_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu):
+        N, Cn, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_bn_train_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight),
+                                                   _ptr(bias), float(eps), float(momentum), _ptr(running_mean),
+                                                   _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu),
+                                                   _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
+        # the ReLU mask comes from y only when something was added before the ReLU; otherwise the backward recomputes it from x
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, save)
+        ctx.has_residual, ctx.relu = residual is not None, bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, bias, save = ctx.saved_tensors
+        N, Cn, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_residual else None
+        dwb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_bn_bwd(_ptr(gy), _ptr(y), _ptr(x), _ptr(dx), _ptr(dres), _DT[x.dtype][0], N * H * W, Cn,
+                                             _ptr(weight), _ptr(bias), _ptr(save[0]), _ptr(save[1]), int(ctx.relu), _ptr(dwb[0]),
+                                             _ptr(dwb[1]), _ptr(ws), _ptr(coef), _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_bwd failed (%d)' % rc)
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None
+
+
+class BatchNormAct2d(torch.nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose forward can take the residual add and the ReLU
+    that follow it in the upstream blocks: ``bn(x, residual=None, relu=False)``.  Channels-last CUDA bf16 / float32
+    inputs run the fused HIP kernels; anything else runs torch's batch_norm + add + relu."""
+
+    def forward(self, x, residual=None, relu=False):
+        fused = (USE_HIP_BN and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine and self.track_running_stats
+                 and self.momentum is not None and x.is_contiguous(memory_format=torch.channels_last)
+                 and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
+                                           and residual.is_contiguous(memory_format=torch.channels_last)))
+                 and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])
+                 and (self.training or not torch.is_grad_enabled() or not x.requires_grad))
+        if not fused:
+            y = super().forward(x)
+            if residual is not None:
+                y = y + residual
+            return F.relu(y, inplace=True) if relu else y
+        w, b = self.weight.float(), self.bias.float()
+        if self.training:
+            self.num_batches_tracked.add_(1)
+            return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu)
+        N, Cn, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        invstd = torch.rsqrt(self.running_var + self.eps)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_bn_eval_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], N * H * W, Cn, _ptr(w),
+                                                  _ptr(b), _ptr(self.running_mean), _ptr(invstd), int(relu), _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_eval_fwd failed (%d)' % rc)
+        return y

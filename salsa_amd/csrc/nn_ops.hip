@@ -104,6 +104,260 @@ __global__ __launch_bounds__(256) void avgpool2x2_bwd_kernel(const char *__restr
     vec_io<V, L>::store(gx + i * 16, g);
 }
 
+
+// ------------------------------------------------------------------------------------------------ BatchNorm2d (+ add) (+ ReLU)
+// x: [M][C] channels-last (M = N*H*W).  A thread owns one column group of L channels (16 bytes); a 256-thread block is
+// (256/cv) rows x cv column groups, cv = C / L, and walks BN_ROWS_PER_THREAD rows per thread.  Reductions: float32
+// per-thread partials -> LDS tree over the block's rows -> ONE float64 atomic per channel per block.
+#ifndef BN_RPT
+#define BN_RPT 32
+#endif
+constexpr int BN_ROWS_PER_THREAD = BN_RPT;
+
+template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], float (&b)[L], float *red /*[256][2L]*/, int cv,
+                                                                  float *part_a, float *part_b, int c0)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        red[tid * 2 * L + k] = a[k];
+        red[tid * 2 * L + L + k] = b[k];
+    }
+    __syncthreads();
+    for (int s = 128; s >= cv; s >>= 1) { // threads tid and tid + s own the same column group (s is a multiple of cv)
+        if (tid < s) {
+#pragma unroll
+            for (int k = 0; k < 2 * L; k++) red[tid * 2 * L + k] += red[(tid + s) * 2 * L + k];
+        }
+        __syncthreads();
+    }
+    if (tid < cv) { // this block's partial sums (no atomics: thousands of blocks would serialise on 2*C addresses)
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+            part_a[c0 + k] = red[tid * 2 * L + k];
+            part_b[c0 + k] = red[tid * 2 * L + L + k];
+        }
+    }
+}
+
+// sums[0..1][C] (float64) = sum over the blocks' partials [nblk][2][C].  A 256-thread block = 8 outputs x 32 threads
+// that each add every 32nd partial (coalesced over the 8 adjacent outputs), then an LDS tree over the 32.
+__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float *__restrict__ part, int nblk, int C,
+                                                              double *__restrict__ sums)
+{
+    __shared__ double red[256];
+    const int o = threadIdx.x & 7, seg = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + o;
+    double acc = 0.0;
+    if (i < 2 * C)
+        for (int b = seg; b < nblk; b += 32) acc += (double)part[(long)b * 2 * C + i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 8; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8 && i < 2 * C) sums[i] = red[threadIdx.x];
+}
+
+// part[block][0][C] = sum x, part[block][1][C] = sum x^2 over the block's rows
+template <typename V, int L>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ x, long M, int C, float *__restrict__ part)
+{
+    __shared__ float red[256 * 2 * L];
+    const int cv = C / L, rpi = 256 / cv;
+    const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
+    const long chunk = (long)rpi * BN_ROWS_PER_THREAD;
+    float s[L], ss[L];
+#pragma unroll
+    for (int k = 0; k < L; k++) s[k] = ss[k] = 0.f;
+    for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
+#pragma unroll 4
+        for (int it = 0; it < BN_ROWS_PER_THREAD; it++) {
+            const long r = row0 + (long)it * rpi + ry;
+            if (r < M) {
+                float v[L];
+                vec_io<V, L>::load(x + (r * cv + cx) * 16, v);
+#pragma unroll
+                for (int k = 0; k < L; k++) {
+                    s[k] += v[k];
+                    ss[k] += v[k] * v[k];
+                }
+            }
+        }
+    }
+    float *mine = part + (long)blockIdx.x * 2 * C;
+    bn_block_reduce<L>(s, ss, red, cv, mine, mine + C, cx * L);
+}
+
+// training: mean / invstd from the sums, running statistics (momentum, unbiased variance); one thread per channel
+__global__ void bn_finalize_kernel(const double *__restrict__ sums, long M, int C, float eps, float momentum,
+                                   float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = [relu]( ((x - mean) * invstd) * gamma + beta [+ residual] ).  Same thread geometry as the reductions: a thread keeps
+// its column group's constants in registers and walks BN_APPLY_ROWS rows (one thread per vector would re-load 4 x L
+// constants for every 16 bytes of payload and become instruction-bound).
+constexpr int BN_APPLY_ROWS = 16;
+template <typename V, int L>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ x, char *__restrict__ y,
+                                                       const char *__restrict__ residual, long M, int C,
+                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu)
+{
+    const int cv = C / L, rpi = 256 / cv;
+    const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
+    float mu[L], is[L], ga[L], be[L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        mu[k] = mean[cx * L + k];
+        is[k] = invstd[cx * L + k];
+        ga[k] = gamma[cx * L + k];
+        be[k] = beta[cx * L + k];
+    }
+    const long row0 = (long)blockIdx.x * rpi * BN_APPLY_ROWS;
+#pragma unroll 4
+    for (int it = 0; it < BN_APPLY_ROWS; it++) {
+        const long r = row0 + (long)it * rpi + ry;
+        if (r >= M) break;
+        const long off = (r * cv + cx) * 16;
+        float v[L], rs[L];
+        vec_io<V, L>::load(x + off, v);
+        if (residual) vec_io<V, L>::load(residual + off, rs);
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+            float o = ((v[k] - mu[k]) * is[k]) * ga[k] + be[k];
+            if (residual) o += rs[k];
+            v[k] = relu ? fmaxf(o, 0.f) : o;
+        }
+        vec_io<V, L>::store(y + off, v);
+    }
+}
+
+// g = dy * (y > 0) ; sums[0][C] += sum g (= dbeta) ; sums[1][C] += sum g * xhat (= dgamma)
+template <typename V, int L>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restrict__ dy, const char *__restrict__ y,
+                                                            const char *__restrict__ x, long M, int C,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            int mask_from_x, float *__restrict__ part)
+{
+    __shared__ float red[256 * 2 * L];
+    const int cv = C / L, rpi = 256 / cv;
+    const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
+    const long chunk = (long)rpi * BN_ROWS_PER_THREAD;
+    float db[L], dg[L], mu[L], is[L], ga[L], be[L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        db[k] = dg[k] = 0.f;
+        mu[k] = mean[cx * L + k];
+        is[k] = invstd[cx * L + k];
+        ga[k] = gamma[cx * L + k];
+        be[k] = beta[cx * L + k];
+    }
+    for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
+#pragma unroll 4
+        for (int it = 0; it < BN_ROWS_PER_THREAD; it++) {
+            const long r = row0 + (long)it * rpi + ry;
+            if (r < M) {
+                float g[L], xv[L], yv[L];
+                vec_io<V, L>::load(dy + (r * cv + cx) * 16, g);
+                vec_io<V, L>::load(x + (r * cv + cx) * 16, xv);
+                if (y) vec_io<V, L>::load(y + (r * cv + cx) * 16, yv);
+#pragma unroll
+                for (int k = 0; k < L; k++) {
+                    const float xh = (xv[k] - mu[k]) * is[k];
+                    // ReLU mask: from the stored output, or -- when nothing was added before the ReLU -- recomputed from x
+                    // (the sign of the float32 pre-activation survives its rounding to the stored dtype), saving y's read
+                    const bool off = y ? !(yv[k] > 0.f) : (mask_from_x && !(xh * ga[k] + be[k] > 0.f));
+                    const float gk = off ? 0.f : g[k];
+                    db[k] += gk;
+                    dg[k] += gk * xh;
+                }
+            }
+        }
+    }
+    float *mine = part + (long)blockIdx.x * 2 * C;
+    bn_block_reduce<L>(db, dg, red, cv, mine, mine + C, cx * L);
+}
+
+// coefficients of dx = a * (g - b - (x - mean) * k): coef[0..3][C] = a = gamma*invstd, b = dbeta/M, mean, k = invstd*dgamma/M ;
+// coef[4..5][C] = invstd, beta (for the mask recomputation)
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ sums, long M, int C, const float *__restrict__ gamma,
+                                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                                       const float *__restrict__ beta, float *__restrict__ coef, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double db = sums[c], dg = sums[C + c];
+    dbeta[c] = (float)db;
+    dgamma[c] = (float)dg;
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(db / (double)M);
+    coef[2 * C + c] = mean[c];
+    coef[3 * C + c] = (float)((double)invstd[c] * dg / (double)M);
+    coef[4 * C + c] = invstd[c];
+    coef[5 * C + c] = beta[c];
+    coef[6 * C + c] = gamma[c];
+}
+
+template <typename V, int L>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restrict__ dy, const char *__restrict__ y,
+                                                           const char *__restrict__ x, char *__restrict__ dx,
+                                                           char *__restrict__ dres, long M, int C,
+                                                           const float *__restrict__ coef, int mask_from_x)
+{
+    const int cv = C / L, rpi = 256 / cv;
+    const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
+    float a[L], b[L], mu[L], kk[L], is[L], be[L], ga[L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const int c = cx * L + k;
+        a[k] = coef[c];
+        b[k] = coef[C + c];
+        mu[k] = coef[2 * C + c];
+        kk[k] = coef[3 * C + c];
+        is[k] = coef[4 * C + c];
+        be[k] = coef[5 * C + c];
+        ga[k] = coef[6 * C + c];
+    }
+    const long row0 = (long)blockIdx.x * rpi * BN_APPLY_ROWS;
+#pragma unroll 2
+    for (int it = 0; it < BN_APPLY_ROWS; it++) {
+        const long r = row0 + (long)it * rpi + ry;
+        if (r >= M) break;
+        const long off = (r * cv + cx) * 16;
+        float g[L], xv[L], yv[L];
+        vec_io<V, L>::load(dy + off, g);
+        vec_io<V, L>::load(x + off, xv);
+        if (y) vec_io<V, L>::load(y + off, yv);
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+            const float xc = xv[k] - mu[k];
+            const bool zero = y ? !(yv[k] > 0.f) : (mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f));
+            if (zero) g[k] = 0.f;
+            xv[k] = a[k] * (g[k] - b[k] - xc * kk[k]);
+        }
+        vec_io<V, L>::store(dx + off, xv);
+        if (dres) vec_io<V, L>::store(dres + off, g);
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -131,6 +385,91 @@ int salsa_nn_avgpool2x2_bwd(const void *grad_y, void *grad_x, int dtype, int64_t
         hipLaunchKernelGGL((avgpool2x2_bwd_kernel<bf16x8, 8>), grid, dim3(256), 0, (hipStream_t)hip_stream, (const char *)grad_y, (char *)grad_x, n_vec, H, W, C);
     else
         hipLaunchKernelGGL((avgpool2x2_bwd_kernel<f32x4, 4>), grid, dim3(256), 0, (hipStream_t)hip_stream, (const char *)grad_y, (char *)grad_x, n_vec, H, W, C);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+static int bn_geometry_ok(int dtype, int64_t M, int C)
+{
+    const int L = dtype == 1 ? 8 : 4;
+    if ((dtype != 0 && dtype != 1) || M <= 0 || C <= 0 || C % L) return 0;
+    const int cv = C / L;
+    return cv <= 256 && (cv & (cv - 1)) == 0; // a block is (256/cv) rows x cv column groups
+}
+#ifndef BN_MAX_BLOCKS
+#define BN_MAX_BLOCKS 2048
+#endif
+constexpr unsigned BN_MAX_REDUCE_BLOCKS = BN_MAX_BLOCKS; // 8 per CU; a block takes several row chunks when M is large
+static unsigned bn_reduce_blocks(int dtype, int64_t M, int C)
+{
+    const int rpi = 256 / (C / (dtype == 1 ? 8 : 4));
+    const long per = (long)rpi * BN_ROWS_PER_THREAD;
+    const long n = (M + per - 1) / per;
+    return (unsigned)(n < BN_MAX_REDUCE_BLOCKS ? n : BN_MAX_REDUCE_BLOCKS);
+}
+static unsigned bn_apply_blocks(int dtype, int64_t M, int C)
+{
+    const long per = (long)(256 / (C / (dtype == 1 ? 8 : 4))) * BN_APPLY_ROWS;
+    return (unsigned)((M + per - 1) / per);
+}
+#define NN_LAUNCH(KERNEL, grid, block, ...)                                                               \
+    do {                                                                                                  \
+        if (dtype == 1) hipLaunchKernelGGL((KERNEL<bf16x8, 8>), grid, block, 0, st, __VA_ARGS__);          \
+        else hipLaunchKernelGGL((KERNEL<f32x4, 4>), grid, block, 0, st, __VA_ARGS__);                      \
+    } while (0)
+
+int salsa_nn_bn_supported(int dtype, int64_t M, int C) { return bn_geometry_ok(dtype, M, C); }
+/* bytes of the sums_ws scratch: 2*C float64 sums + one float32 partial pair per reduction block */
+size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
+{
+    if (!bn_geometry_ok(dtype, M, C)) return 0;
+    return sizeof(double) * 2 * C + sizeof(float) * 2 * (size_t)C * bn_reduce_blocks(dtype, M, C);
+}
+
+int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                          float *save_mean, float *save_invstd, double *sums_ws, int relu, void *hip_stream)
+{
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C)) return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned nblk = bn_reduce_blocks(dtype, M, C);
+    float *part = (float *)(sums_ws + 2 * C);
+    NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
+    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st, part, (int)nblk, C, sums_ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, (long)M, C, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var);
+    NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
+              (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                         const float *beta, const float *mean, const float *invstd, int relu, void *hip_stream)
+{
+    if (!x || !y || !gamma || !beta || !mean || !invstd || !bn_geometry_ok(dtype, M, C)) return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
+              (const char *)residual, (long)M, C, mean, invstd, gamma, beta, relu);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *dx, void *dres_or_null, int dtype, int64_t M,
+                    int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
+{
+    const int mask_from_x = relu && !y_or_null;
+    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
+        !bn_geometry_ok(dtype, M, C))
+        return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned nblk = bn_reduce_blocks(dtype, M, C);
+    float *part = (float *)(sums_ws + 2 * C);
+    NN_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (const char *)dy, (const char *)y_or_null,
+              (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, mask_from_x, part);
+    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st, part, (int)nblk, C, sums_ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, (long)M, C, gamma, save_mean,
+                       save_invstd, beta, coef_ws, dgamma, dbeta);
+    NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
+              (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

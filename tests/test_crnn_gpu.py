@@ -86,3 +86,58 @@ def test_hip_avgpool_matches_torch_forward_and_backward():
         assert torch.equal(xa.grad, xb.grad), dtype
     x = torch.randn(2, 7, 8, 8, device=dev)                                     # 7 channels: falls through to torch
     assert torch.equal(avg_pool2x2(x), F.avg_pool2d(x, 2))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_batchnorm_add_relu_matches_torch(dtype):
+    """BatchNormAct2d (salsa_nn_bn_*) against nn.BatchNorm2d + add + ReLU: outputs, every gradient, running statistics,
+    training and eval mode.  float32: 1e-5; bf16 activations: one bf16 ulp on outputs, bf16-level on gradients."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import BatchNormAct2d, _BnAct
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(1)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)   # bf16: gradients are stored in bf16
+    for (n, c, h, w), use_res, relu in (((4, 64, 20, 12), False, True), ((3, 128, 9, 7), True, True), ((2, 512, 5, 3), True, False),
+                                        ((2, 64, 6, 4), False, False)):
+        ref, fus = nn.BatchNorm2d(c).to(dev), BatchNormAct2d(c).to(dev)
+        with torch.no_grad():
+            ref.weight.copy_(torch.rand(c, device=dev, generator=g) + 0.5)
+            ref.bias.copy_(torch.randn(c, device=dev, generator=g))
+        fus.load_state_dict(ref.state_dict())
+        for step in range(2):                                                    # two steps: running statistics accumulate
+            x = (torch.randn((n, c, h, w), device=dev, generator=g) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+            r = torch.randn((n, c, h, w), device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last) if use_res else None
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            ra, rb = (r.clone().requires_grad_(True), r.clone().requires_grad_(True)) if use_res else (None, None)
+            # reference: torch's batch_norm + add + relu evaluated in float32 on the same (bf16-valued) inputs -- the fused
+            # kernel keeps float32 until its single store, torch's bf16 chain rounds after the BN and again after the add
+            xb = x.float().clone().requires_grad_(True)
+            rb = r.float().clone().requires_grad_(True) if use_res else None
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                ya = fus(xa, residual=ra, relu=relu)
+            yb = ref(xb)
+            yb = yb + rb if use_res else yb
+            yb = F.relu(yb) if relu else yb
+            assert isinstance(ya.grad_fn, _BnAct._backward_cls) and ya.dtype == dtype
+            out_tol = tol if dtype == torch.float32 else dict(rtol=2.0 ** -8, atol=1e-3)   # one rounding to bf16
+            torch.testing.assert_close(ya.float(), yb, **out_tol)
+            gy = torch.randn(ya.shape, device=dev, generator=g).to(dtype)
+            ya.backward(gy)
+            yb.backward(gy.float())
+            torch.testing.assert_close(xa.grad.float(), xb.grad.float(), **tol)
+            torch.testing.assert_close(fus.weight.grad, ref.weight.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+            torch.testing.assert_close(fus.bias.grad, ref.bias.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+            if use_res:
+                torch.testing.assert_close(ra.grad.float(), rb.grad.float(), **tol)
+            torch.testing.assert_close(fus.running_mean, ref.running_mean, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(fus.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+            assert int(fus.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+            fus.zero_grad(); ref.zero_grad()
+        ref.eval(); fus.eval()
+        with torch.no_grad():
+            ya = fus(x, residual=r, relu=relu)
+            yb = ref(x.float())
+            yb = yb + r.float() if use_res else yb
+            yb = F.relu(yb) if relu else yb
+        torch.testing.assert_close(ya.float(), yb, **out_tol)

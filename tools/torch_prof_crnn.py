@@ -18,5 +18,5 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
 rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
 tot = sum(e.device_time_total for e in rows)
 print('total device ms per step: %.2f' % (tot / 3e3))
-for e in rows[:28]:
+for e in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 28]:
     print('%-80s n=%5d  %7.2f ms/step  %5.1f%%' % (e.key[:80], e.count // 3, e.device_time_total / 3e3, 100 * e.device_time_total / tot))
