@@ -16,6 +16,7 @@
  *   MagStftExtractor.W, dataset/salsa_feature_extraction.py:152-175               salsa_compress_matrix (host)
  *   compute_scaler, dataset/salsa_feature_extraction.py:204-262                   salsa_scaler_accumulate
  *   Database.load_chunk_data normalisation, dataset/database.py:197-202           salsa_normalize_batch
+ *   SeldDataset train transforms, utilities/transforms.py (datamodule.py:45-82)   salsa_augment_batch
  *   SalsaFeatures / SalsaLiteFeatures.__call__, contrib/salsa_flexible.py:237-265 (+ :286-400)   salsa_extract_batch with SALSA_FLAG_FLEX, salsa_to_freq_major
  *
  * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
@@ -134,6 +135,18 @@ int salsa_plan_set_scaler(salsa_plan *plan, const float *d_mean, const float *d_
 /* Feature rows [n_rows][n_frames][n_freq] float32 (time-major, what salsa_extract_batch writes; n_rows = batch * 7) ->
  * [n_rows][n_freq][n_frames] float64, the freq-major float64 array contrib/salsa_flexible.py returns (:264). */
 int salsa_to_freq_major(const float *d_feat, int64_t n_rows, int64_t n_frames, int n_freq, double *d_out, void *hip_stream);
+
+/* Training augmentation of a feature batch in one pass (utilities/transforms.py via dataset/datamodule.py:45-52, :73-82):
+ * channel swap (TfmapRandomSwapChannelFoa :365-437 / ...Mic :440-523), RandomShiftUpDownNp (:286-320), then the
+ * CompositeCutout rectangles (:58-283).  d_out: float32 [B][7][T][F]; d_in: the same block, possibly a view with its own
+ * batch / channel strides in elements (e.g. extractor output cropped in time; rows stay contiguous).  The random draws are the
+ * caller's: d_params int32 [B][40] = m0..m3 (swap bits; MIC uses three), shift (0 = none), up, 0, 0, top[8], h[8], left[8],
+ * w[8] (h or w = 0: no rectangle; later rectangles win); d_uval float32 [B][8] in [0,1) and d_minmax float32 [B][2] give the
+ * fill value min + (max - min) * u of the first 7 - n_zero_channels rows (the last n_zero_channels rows get 0). */
+#define SALSA_AUGMENT_NPAR 40
+int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_channel_stride, float *d_out, int batch,
+                        int64_t n_frames, int n_freq, int audio_format, int n_zero_channels, const int *d_params,
+                        const float *d_uval, const float *d_minmax, void *hip_stream);
 
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
  * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the

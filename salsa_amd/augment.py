@@ -219,10 +219,10 @@ def reference_train_transform(x, y_sed, y_doa, audio_format='foa', rng=np.random
     return xb[0], y_sed, yb[0]
 
 
-def random_composite_cutout(x, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0, n_zero_channels=3):
-    """Batched on-device CompositeCutout: per sample, with probability p, one of the three cutouts with the reference's
-    size distributions; fill values uniform between the sample's min and max."""
-    B, C, T, F = x.shape
+def draw_composite_cutout_batch(B, T, F, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0):
+    """Per-sample CompositeCutout draws for a batch (host, torch.Generator): with probability p one of the three cutouts
+    with the reference's size distributions.  -> top, h, left, w (B,8) int64 (h = w = 0: no rectangle) and u (B,8) in
+    [0,1): the fill value of rectangle r is min + (max - min) * u[r] of the sample."""
     u = lambda *shape: torch.rand(*shape, generator=gen, dtype=torch.float64)     # noqa: E731
     ri = lambda hi, n: torch.floor(u(n) * hi.double()).long()                   # noqa: E731  randint(0, hi) per element
     apply = u(B) < p
@@ -250,20 +250,103 @@ def random_composite_cutout(x, gen=None, p: float = 0.5, image_aspect_ratio: flo
     left[c2] = torch.floor(u(B, 8) * (F - 8)).long()[c2]
     top[c2] = torch.floor(u(B, 8) * (T - 8)).long()[c2]
     h[~apply], w[~apply] = 0, 0
-    lo = x.amin(dim=(1, 2, 3)).double().cpu()
-    hi = x.amax(dim=(1, 2, 3)).double().cpu()
-    value = lo[:, None] + (hi - lo)[:, None] * u(B, 8)
+    return top, h, left, w, u(B, 8).float()
+
+
+def random_composite_cutout(x, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0, n_zero_channels=3):
+    """Batched CompositeCutout with torch operators; fill values uniform between the sample's min and max."""
+    B, C, T, F = x.shape
+    top, h, left, w, u = draw_composite_cutout_batch(B, T, F, gen, p, image_aspect_ratio)
+    lo, hi = x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))
+    value = lo[:, None] + (hi - lo)[:, None] * u.to(x.device, x.dtype)
     return fill_rects(x, top, h, left, w, value, n_zero_channels=n_zero_channels)
 
 
-def augment_batch(x, y_sed, y_doa, audio_format='foa', gen=None, n_classes: int = 12):
-    """The reference's SALSA training recipe on a device batch: channel swap (format-specific, changes the targets), then
-    frequency shift, then -- MIC only -- CompositeCutout(n_zero_channels=3) (datamodule.py:45-52, :73-82)."""
-    if audio_format == 'foa':
-        x, y_sed, y_doa = random_swap_channels_foa(x, y_sed, y_doa, gen=gen, n_classes=n_classes)
+def swap_targets(y_doa, m, audio_format='foa', n_classes: int = 12):
+    """The xyz-target half of the channel swaps, branch-free (torch.where on the per-sample bits: no host
+    synchronisation when m lives on the device).  y_doa (B,T_lab,3*nc), m (B,>=3|4) -> new tensor; equals the y that
+    swap_channels_foa / swap_channels_mic return."""
+    nc = n_classes
+    b = m.to(device=y_doa.device, dtype=torch.bool)[:, :, None, None]            # (B, bits, 1, 1)
+    x, y, z = y_doa[:, :, :nc], y_doa[:, :, nc:2 * nc], y_doa[:, :, 2 * nc:]
+    x, y = torch.where(b[:, 0], y, x), torch.where(b[:, 0], x, y)                # bit 0: swap x and y (both formats)
+    if audio_format == 'foa':                                                     # bits 1..3: negate x, y, z
+        x, y, z = torch.where(b[:, 1], -x, x), torch.where(b[:, 2], -y, y), torch.where(b[:, 3], -z, z)
     else:
-        x, y_sed, y_doa = random_swap_channels_mic(x, y_sed, y_doa, gen=gen, n_classes=n_classes)
-    x = random_shift_up_down(x, gen=gen)
+        x, y = torch.where(b[:, 1], -y, x), torch.where(b[:, 1], -x, y)          # bit 1: swap x and y, negate both
+        y, z = torch.where(b[:, 2], -y, y), torch.where(b[:, 2], -z, z)          # bit 2: negate y and z
+    return torch.cat([x, y, z], dim=2)
+
+
+def draw_augment(B, T, F, audio_format='foa', gen=None, p: float = 0.5, freq_shift_range: int = 10):
+    """All per-sample draws of the SALSA training recipe (datamodule.py:45-52 FOA, :73-82 MIC) for a batch, on the host:
+    dict(m (B,4) swap bits -- MIC uses the first three --, shift (B,) 0 = none, up (B,), top/h/left/w (B,8), u (B,8))."""
+    nbits = 4 if audio_format == 'foa' else 3
+    m = torch.zeros((B, 4), dtype=torch.long)
+    m[:, :nbits] = torch.randint(0, 2, (B, nbits), generator=gen) * (torch.rand(B, generator=gen) < p)[:, None]
+    shift = torch.randint(1, freq_shift_range, (B,), generator=gen) * (torch.rand(B, generator=gen) < p)
+    up = torch.randint(0, 2, (B,), generator=gen).bool()
     if audio_format == 'mic':
-        x = random_composite_cutout(x, gen=gen, image_aspect_ratio=x.shape[2] / 200, n_zero_channels=3)
-    return x, y_sed, y_doa
+        top, h, left, w, u = draw_composite_cutout_batch(B, T, F, gen, p, T / 200)
+    else:
+        top, h, left, w, u = (torch.zeros((B, 8), dtype=torch.long),) * 4 + (torch.zeros((B, 8)),)
+    return dict(m=m, shift=shift, up=up, top=top, h=h, left=left, w=w, u=u)
+
+
+def apply_augment_torch(x, y_doa, d, audio_format='foa', n_classes: int = 12):
+    """The drawn augmentation with torch operators (any device): swap -> shift -> cutout; the cutout's fill range is the
+    min / max of the sample BEFORE augmentation.  Returns (x', y_doa')."""
+    lo, hi = x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))
+    if audio_format == 'foa':
+        xn, yn = swap_channels_foa(x, y_doa, d['m'].to(x.device), n_classes)
+    else:
+        xn, yn = swap_channels_mic(x, y_doa, d['m'][:, :3].to(x.device), n_classes)
+    xn = shift_up_down(xn, d['shift'], d['up'])
+    if audio_format == 'mic':
+        value = lo[:, None] + (hi - lo)[:, None] * d['u'].to(x.device, x.dtype)
+        xn = fill_rects(xn, d['top'], d['h'], d['left'], d['w'], value, n_zero_channels=3)
+    return xn, yn
+
+
+def _rows_contiguous(x):
+    """[B,7,T,F] whose (T,F) blocks are dense: contiguous tensors and time-cropped views of them."""
+    return x.stride(3) == 1 and x.stride(2) == x.shape[3] and x.stride(1) >= x.shape[2] * x.shape[3] and x.stride(0) >= 7 * x.stride(1)
+
+
+def apply_augment_hip(x, d, audio_format='foa'):
+    """The drawn augmentation of the FEATURES in one pass of libsalsa_hip.so (salsa_augment_batch): x float32 CUDA
+    [B,7,T,F] contiguous -> new tensor.  (The targets are a (B, T_lab, 36) sign / swap: apply_augment_torch's y.)"""
+    import ctypes as C
+    from . import _lib
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 7 and _rows_contiguous(x)
+    B, _, T, F = x.shape
+    par = torch.zeros((B, 40), dtype=torch.int32)
+    par[:, 0:4] = d['m']
+    par[:, 4], par[:, 5] = d['shift'], d['up']
+    par[:, 8:16], par[:, 16:24], par[:, 24:32], par[:, 32:40] = d['top'], d['h'], d['left'], d['w']
+    # pinned staging: a pageable host-to-device copy would make the host wait for the stream and serialise the step
+    par = par.pin_memory().to(x.device, non_blocking=True)
+    u = d['u'].float().contiguous().pin_memory().to(x.device, non_blocking=True)
+    minmax = torch.stack([x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))], dim=1).contiguous()
+    out = torch.empty((B, 7, T, F), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_augment_batch(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), C.c_void_p(out.data_ptr()), B, T, F,
+                                             _lib.FORMAT[audio_format], 3 if audio_format == 'mic' else 0,
+                                             C.c_void_p(par.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(minmax.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc:
+        raise RuntimeError('salsa_augment_batch failed: ' + _lib.last_error())
+    return out
+
+
+def augment_batch(x, y_sed, y_doa, audio_format='foa', gen=None, n_classes: int = 12):
+    """The reference's SALSA training recipe on a batch: channel swap (format-specific, changes the targets), frequency
+    shift, and -- MIC only -- CompositeCutout(n_zero_channels=3) (datamodule.py:45-52, :73-82).  CUDA float32 features go
+    through the one-pass HIP kernel; the (tiny) target transform and everything on CPU use the torch operators."""
+    B, _, T, F = x.shape
+    d = draw_augment(B, T, F, audio_format, gen)
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _rows_contiguous(x):
+        m_dev = d['m'].pin_memory().to(x.device, non_blocking=True)
+        return apply_augment_hip(x, d, audio_format), y_sed, swap_targets(y_doa, m_dev, audio_format, n_classes)
+    xn, yn = apply_augment_torch(x, y_doa, d, audio_format, n_classes)
+    return xn, y_sed, yn

@@ -717,6 +717,72 @@ __global__ __launch_bounds__(256) void to_freq_major_kernel(const float *__restr
         if (f0 + i < F && t0 + lx < T) dst[(long)(f0 + i) * T + t0 + lx] = (double)tile[lx][i];
 }
 
+// ------------------------------------------------------------------------------------------------------------ augmentation
+// The reference's SALSA training augmentation (utilities/transforms.py; recipe in dataset/datamodule.py:45-52, :73-82) as
+// ONE gather pass over a feature batch [B][7][T][F]: channel swap (FOA :394-437 / MIC :469-523, applied in the reference's
+// order with its float32 arithmetic: the MIC swap re-references the three phase rows by differences), frequency shift with
+// reflect padding (:298-320), then the cutout rectangles (:87-121, :149-194, :223-254; last rectangle wins; the spatial rows
+// get zeros).  One thread = all 7 channels of one (clip, frame, bin).  par: int32 [B][AUG_NPAR] = m0..m3, shift, up, 0, 0,
+// top[8], h[8], left[8], w[8] ; uval: float32 [B][8] in [0,1) ; minmax: float32 [B][2] -> fill = min + (max - min) * u.
+constexpr int AUG_NPAR = 40;
+__global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ in, long in_batch, long in_chan,
+                                                      float *__restrict__ out, int T, int F,
+                                                      int format, int n_zero, const int *__restrict__ par,
+                                                      const float *__restrict__ uval, const float *__restrict__ minmax)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * F) return;
+    const int t = i / F, f = i - t * F;
+    const int *p = par + b * AUG_NPAR;
+    const long plane = (long)T * F;
+    const float *src = in + (long)b * in_batch; // the input may be a time-cropped view: its own batch / channel strides
+    float *dst = out + (long)b * 7 * plane + i;
+    int hit = -1;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int top = p[8 + r], h = p[16 + r], left = p[24 + r], w = p[32 + r];
+        if (t >= top && t < top + h && f >= left && f < left + w) hit = r;
+    }
+    if (hit >= 0) {
+#pragma clang fp contract(off) // min + (max - min) * u as three rounded operations, like the host-side restatement (no FMA)
+        const float lo = minmax[2 * b], hi = minmax[2 * b + 1];
+        const float v = lo + (hi - lo) * uval[b * 8 + hit];
+#pragma unroll
+        for (int c = 0; c < 7; c++) dst[c * plane] = c < 7 - n_zero ? v : 0.f;
+        return;
+    }
+    const int s = p[4];
+    int fs = f;
+    if (s > 0) {
+        if (p[5]) fs = f - s < 0 ? s - f : f - s;                    // shifted up: pad s bins at the front (reflect at bin 0)
+        else fs = f + s > F - 1 ? 2 * (F - 1) - (f + s) : f + s;       // shifted down: pad at the back (reflect at bin F-1)
+    }
+    float x[7];
+#pragma unroll
+    for (int c = 0; c < 7; c++) x[c] = src[c * in_chan + (long)t * F + fs];
+    if (format == SALSA_FORMAT_FOA) { // W Y Z X | Iy Iz Ix : swap x<->y, negate x, y, z
+        if (p[0]) { float a = x[1]; x[1] = x[3]; x[3] = a; a = x[4]; x[4] = x[6]; x[6] = a; }
+        if (p[1]) x[6] = -x[6];
+        if (p[2]) x[4] = -x[4];
+        if (p[3]) x[5] = -x[5];
+    } else {                          // M1 M2 M3 M4 | p12 p13 p14
+        if (p[0]) { float a = x[1]; x[1] = x[2]; x[2] = a; a = x[4]; x[4] = x[5]; x[5] = a; }
+        if (p[1]) {
+            const float c0 = x[0], c3 = x[3], c4 = x[4], c5 = x[5], c6 = x[6];
+            x[0] = c3; x[3] = c0;
+            x[6] = -c6; x[5] = c5 - c6; x[4] = c4 - c6;
+        }
+        if (p[2]) {
+            const float c0 = x[0], c1 = x[1], c2 = x[2], c3 = x[3], c4 = x[4], c5 = x[5], c6 = x[6];
+            x[0] = c1; x[1] = c0; x[2] = c3; x[3] = c2;
+            x[4] = -c4; x[5] = c6 - c4; x[6] = c5 - c4;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 7; c++) dst[c * plane] = x[c];
+}
+
 } // namespace
 
 // ================================================================================================== plan + C ABI
@@ -1224,6 +1290,24 @@ int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
         if (rc) return rc;
     }
     pl->n_groups = n_groups > SALSA_MAX_GROUPS ? SALSA_MAX_GROUPS : n_groups;
+    return SALSA_OK;
+}
+
+int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_channel_stride, float *d_out, int batch,
+                        int64_t n_frames, int n_freq, int audio_format, int n_zero_channels, const int *d_params,
+                        const float *d_uval, const float *d_minmax, void *hip_stream)
+{
+    if (in_channel_stride < n_frames * n_freq || in_batch_stride < 7 * in_channel_stride)
+        return fail(SALSA_EINVAL, "salsa_augment_batch: input strides smaller than the [7][T][F] block%s");
+    if (!d_in || !d_out || d_in == d_out || !d_params || !d_uval || !d_minmax || batch <= 0 || batch > 65535 || n_frames <= 0 ||
+        n_freq <= 1 || n_frames * n_freq >= INT32_MAX || n_zero_channels < 0 || n_zero_channels > 7)
+        return fail(SALSA_EINVAL, "salsa_augment_batch: bad argument%s");
+    if (audio_format != SALSA_FORMAT_FOA && audio_format != SALSA_FORMAT_MIC) return fail(SALSA_EFORMAT, "Unknown audio format%s");
+    const long n = (long)n_frames * n_freq;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)hip_stream,
+                       d_in, (long)in_batch_stride, (long)in_channel_stride, d_out, (int)n_frames, n_freq, audio_format,
+                       n_zero_channels, d_params, d_uval, d_minmax);
+    HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }
 

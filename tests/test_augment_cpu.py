@@ -107,3 +107,14 @@ def test_batched_mic_swap_and_cutout():
     assert frac.max() <= 0.5 and frac.min() > 0
     same = fill_rects(x, *(torch.zeros(64, 2, dtype=torch.long),) * 4, torch.zeros(64, 2))
     assert torch.equal(same, x)
+
+
+def test_branch_free_target_swap_equals_the_swap_cores():
+    from salsa_amd.augment import swap_channels_foa, swap_channels_mic, swap_targets
+    rng = np.random.RandomState(3)
+    y = torch.from_numpy(rng.randn(16, 5, 36).astype(np.float32))
+    x = torch.zeros(16, 7, 1, 1)
+    m4 = torch.tensor([[(i >> b) & 1 for b in range(4)] for i in range(16)])
+    assert torch.equal(swap_targets(y, m4, 'foa'), swap_channels_foa(x, y, m4)[1])
+    m3 = m4[:, :3]
+    assert torch.equal(swap_targets(y, m3, 'mic'), swap_channels_mic(x, y, m3)[1])

@@ -500,3 +500,30 @@ def test_torch_op_equals_the_extractor(dev):
     assert torch.equal(torch.ops.salsa.extract(a), _extractor().extract(a))
     assert torch.equal(torch.ops.salsa.extract(a, 'mic', 'salsa_lite', 24000, 512, 300, 50, 2000),
                        _extractor(audio_format='mic', feature_type='salsa_lite', fmax_doa=2000).extract(a))
+
+
+@pytest.mark.parametrize('fmt', ['foa', 'mic'])
+def test_one_pass_augmentation_kernel_equals_the_torch_composite(dev, fmt):
+    """salsa_augment_batch against swap -> shift -> cutout done with torch operators (which golden g11 ties to the
+    reference's transforms): bit-identical features for the same draws, every swap combination covered."""
+    from salsa_amd.augment import apply_augment_hip, apply_augment_torch, augment_batch, draw_augment
+    g = torch.Generator().manual_seed(5)
+    B, T, F = 48, 80, 200
+    x = torch.randn((B, 7, T, F), generator=g).to(dev)
+    doa = torch.randn((B, 10, 36), generator=g).to(dev)
+    d = draw_augment(B, T, F, fmt, gen=g, p=0.8)
+    nb = 4 if fmt == 'foa' else 3
+    for i in range(2 ** nb):                                        # all swap-bit combinations on the first samples
+        d['m'][i, :nb] = torch.tensor([(i >> k) & 1 for k in range(nb)])
+    d['shift'][:4] = torch.tensor([0, 9, 9, 1])
+    d['up'][:4] = torch.tensor([True, True, False, False])
+    ref, _ = apply_augment_torch(x, doa, d, fmt)
+    out = apply_augment_hip(x, d, fmt)
+    assert torch.equal(out, ref)
+    assert not torch.equal(out, x)
+    big = torch.randn((B, 7, T + 1, F), generator=g).to(dev)            # a time-cropped view, like extract(...)[:, :, :640]
+    view = big[:, :, :T]
+    assert torch.equal(apply_augment_hip(view, d, fmt), apply_augment_torch(view, doa, d, fmt)[0])
+    xa, sed, ya = augment_batch(x, doa[:, :, :12], doa, fmt, gen=torch.Generator().manual_seed(9))
+    xb, yb = apply_augment_torch(x, doa, draw_augment(B, T, F, fmt, gen=torch.Generator().manual_seed(9)), fmt)
+    assert torch.equal(xa, xb) and torch.equal(ya, yb)
