@@ -17,6 +17,12 @@
  *   forward had a residual.  With relu != 0 and y_or_null = NULL (allowed when the forward had NO residual) the mask is
  *   recomputed from x, which saves reading y.  coef_ws: 7*C floats of scratch.  salsa_nn_bn_supported: C/L must be a power of two <= 256
  *   (L = 8 for bf16, 4 for float32).
+ *
+ *   salsa_nn_conv3x3_c64: the 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels (the stem's second
+ *   convolution and the four of the first residual stage: 42 % of the network's convolution FLOPs) on the matrix cores,
+ *   bf16 in / float32 accumulate / bf16 out.  x, y: [N][H][W][64]; w: [64 co][3][3][64 ci] (a channels-last
+ *   torch.nn.Conv2d weight).  The data gradient is the same call on dy with the filter flipped and transposed
+ *   (w'[ci][r][s][co] = w[co][2-r][2-s][ci]).  salsa_amd/csrc/conv_mfma.hip describes the kernel.
  */
 #ifndef SALSA_NN_H
 #define SALSA_NN_H
@@ -28,6 +34,8 @@ extern "C" {
 
 int salsa_nn_avgpool2x2_fwd(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
 int salsa_nn_avgpool2x2_bwd(const void *grad_y, void *grad_x, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
+
+int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H, int W, void *hip_stream);
 
 int salsa_nn_bn_supported(int dtype, int64_t M, int C);
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C); /* size of sums_ws (8-byte aligned) */

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, avg_pool2x2
+from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -27,7 +27,8 @@ def _xavier(layer):
 
 
 def _conv(cin, cout, k):
-    return _xavier(nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=k // 2, bias=False))
+    cls = Conv3x3 if k == 3 else nn.Conv2d                     # same parameters / state_dict; 64 -> 64 runs on the MFMA kernel
+    return _xavier(cls(cin, cout, kernel_size=k, stride=1, padding=k // 2, bias=False))
 
 
 class Stem(nn.Module):

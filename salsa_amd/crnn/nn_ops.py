@@ -12,6 +12,7 @@ from .. import _lib
 _DT = {torch.float32: (0, 4), torch.bfloat16: (1, 8)}
 USE_HIP_POOL = os.environ.get('SALSA_HIP_POOL', '1') != '0'
 USE_HIP_BN = os.environ.get('SALSA_HIP_BN', '1') != '0'
+USE_HIP_CONV = os.environ.get('SALSA_HIP_CONV', '1') != '0'
 
 
 def _stream(t):
@@ -127,3 +128,53 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         if rc:
             raise RuntimeError('salsa_nn_bn_eval_fwd failed (%d)' % rc)
         return y
+
+
+def _conv64(x, w):
+    """salsa_nn_conv3x3_c64: x (N,64,H,W) bf16 channels-last, w (64,64,3,3) bf16 channels-last -> (N,64,H,W)."""
+    N, _, H, W = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_nn_conv3x3_c64(_ptr(x), _ptr(w), _ptr(y), N, H, W, _stream(x))
+    if rc:
+        raise RuntimeError('salsa_nn_conv3x3_c64 failed (%d)' % rc)
+    return y
+
+
+class _Conv3x3C64(torch.autograd.Function):
+    """64 -> 64 channel 3x3 convolution on the matrix cores: forward and data gradient are the hand-written kernel (the
+    latter with the flipped / transposed filter), the weight gradient stays with MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _conv64(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv64(gy, w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        return gx, gw
+
+
+class Conv3x3(torch.nn.Conv2d):
+    """nn.Conv2d(cin, cout, 3, padding=1, bias=False) whose 64 -> 64 instances run the MFMA kernel for bf16 channels-last
+    CUDA inputs (i.e. under the trainer's autocast); everything else is F.conv2d."""
+
+    def forward(self, x):
+        bf16 = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        if (USE_HIP_CONV and x.is_cuda and bf16 and self.in_channels == 64 and self.out_channels == 64 and x.dim() == 4
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.bias is None
+                and self.dilation == (1, 1) and self.groups == 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64):
+            with torch.autocast('cuda', enabled=False):
+                xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                wb = self.weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                return _Conv3x3C64.apply(xb, wb)
+        return super().forward(x)

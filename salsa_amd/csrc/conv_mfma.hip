@@ -1,0 +1,156 @@
+// conv_mfma.hip -- 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, channels-last bf16, on the gfx950 matrix cores.
+// Implicit GEMM computed transposed, C^T[co][pixel] = sum_{tap,ci} W[tap][co][ci] * X[pixel+tap][ci], so that
+//   A (32 co x 16 ci)     = 16 contiguous bytes of the weight row [co][ci..ci+7]       per lane (lane&31 = co, lane>>5 = k half)
+//   B (16 ci x 32 pixels) = 16 contiguous bytes of the input pixel [pixel][ci..ci+7]    per lane (lane&31 = pixel)
+//   D (32 co x 32 pixels) = for ONE pixel per lane, 4 groups of 4 consecutive co        -> 8-byte bf16 stores
+// i.e. neither operand needs a transpose and the result is written pixel-major (NHWC) with vector stores.
+// A persistent workgroup (4 waves) keeps the whole filter (9 x 64 x 64 bf16) in LDS and walks output tiles of 4 rows x 32
+// columns; wave w owns row w of the tile.  LDS rows are padded 128 -> 144 bytes so the 16-byte operand reads of 32
+// consecutive pixels / filter rows spread over all banks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CH = 64;            // channels in = out
+constexpr int ROW = 72;           // padded channel stride in LDS (bf16 elements): 144 bytes
+#ifndef CONV_RPW
+#define CONV_RPW 2 // measured: 2 rows per wave at 2 waves per SIMD (0.44 ms for 32x640x200) beats 4 rows at 1 wave per SIMD (0.50)
+#endif
+#ifndef CONV_WPS
+#define CONV_WPS 2
+#endif
+constexpr int RPW = CONV_RPW;      // output rows per wave
+constexpr int TH = 2 * RPW, TW = 32; // output tile of a workgroup: waves = 2 row groups x 2 halves of the 64 output channels
+constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int HALO_PIECES = HALO_H * HALO_W * 8;              // 16-byte pieces of one input tile
+constexpr int PREF = (HALO_PIECES + 255) / 256;               // pieces per thread
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// x: [N][H][W][64] bf16, w: [64 co][3][3][64 ci] bf16 (torch's channels-last weight layout), y: [N][H][W][64] bf16.
+// The WHOLE filter lives in registers (72 A fragments per lane: a wave per SIMD may use all 512 VGPR+AGPR), so LDS only
+// serves the input tile: one 16-byte B read per two MFMAs.  The next tile's halo is prefetched into registers while the
+// current tile is multiplied.
+__global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const unsigned short *__restrict__ x,
+                                                              const unsigned short *__restrict__ w,
+                                                              unsigned short *__restrict__ y, int N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xl[HALO_H * HALO_W * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 31, kh = (lane >> 5) * 8;
+    const int mb = wv & 1, rg = wv >> 1; // this wave: output channels 32*mb .. +31, tile rows RPW*rg .. +RPW-1
+    bf16x8 af[9][4];    // [tap][16-channel step]: filter row co = 32*mb + (lane&31), input channels kc*16 + kh .. +7
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) af[tap][kc] = *(const bf16x8 *)(w + ((long)((mb * 32 + px) * 9 + tap) * CH + kc * 16 + kh));
+    const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH;
+    const long n_tiles = (long)N * tiles_h * tiles_w;
+    uint4 pre[PREF];
+    auto fetch = [&](long tile) {
+        const int tw = (int)(tile % tiles_w);
+        const int th = (int)((tile / tiles_w) % tiles_h);
+        const long n = tile / ((long)tiles_w * tiles_h);
+#pragma unroll
+        for (int j = 0; j < PREF; j++) {
+            const int i = tid + j * 256;
+            const int piece = i & 7, p = i >> 3;
+            const int hh = p / HALO_W, ww = p - hh * HALO_W;
+            const int h = th * TH + hh - 1, wcol = tw * TW + ww - 1;
+            pre[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < HALO_PIECES && h >= 0 && h < H && wcol >= 0 && wcol < W)
+                pre[j] = *(const uint4 *)(x + (((n * H + h) * W + wcol) * CH + piece * 8));
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads(); // the previous tile's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < PREF; j++) {
+            const int i = tid + j * 256;
+            if (i < HALO_PIECES) *(uint4 *)(xl + (long)(i >> 3) * ROW + (i & 7) * 8) = pre[j];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
+        const int tw = (int)(tile % tiles_w);
+        const int th = (int)((tile / tiles_w) % tiles_h);
+        const long n = tile / ((long)tiles_w * tiles_h);
+        f32x16 acc[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) acc[r] = f32x16{};
+        // 36 K-steps (9 taps x 4 channel blocks), software-pipelined BY HAND: the compiler sinks plain LDS loads down to their
+        // first use (ds_read ; s_waitcnt ; mfma), which leaves the matrix pipe idle for the LDS latency every step.  So the
+        // B reads are volatile asm with the step's constant byte offset as the instruction's immediate, and the wait is an
+        // asm that takes the fragments as operands: step q+1's fragments are requested, step q's four MFMAs issue, then wait.
+        const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xl +
+                               2u * (unsigned)((rg * RPW * HALO_W + px) * ROW + kh);
+#define LDS_B(dst, q, rr)                                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                       \
+                 : "=v"(dst)                                                                                           \
+                 : "v"(lbase), "n"(2 * ((((rr) + ((q) >> 2) / 3) * HALO_W + ((q) >> 2) % 3) * ROW + ((q) & 3) * 16)))
+#if CONV_RPW == 4
+#define LDS_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#else
+#define LDS_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]))
+#endif
+        bf16x8 bb[2][RPW]; // ping-pong: step q multiplies bb[q&1] while bb[(q+1)&1] is in flight
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) LDS_B(bb[0][rr], 0, rr);
+        LDS_WAIT(bb[0]);
+#pragma unroll
+        for (int q = 0; q < 36; q++) {
+            if (q + 1 < 36) {
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++) LDS_B(bb[(q + 1) & 1][rr], q + 1, rr);
+            }
+            __builtin_amdgcn_sched_barrier(0); // the four reads go out BEFORE this step's MFMAs (which then cover their latency)
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++) acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q >> 2][q & 3], bb[q & 1][rr], acc[rr], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < 36) LDS_WAIT(bb[(q + 1) & 1]);
+        }
+#undef LDS_B
+#undef LDS_WAIT
+        // D: column = lane&31 = pixel, row (= co within this wave's 32) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds, for ONE
+        // pixel, four groups of four consecutive output channels -> 8-byte stores.  (Transposing through LDS to get 16-byte
+        // stores of 64 contiguous bytes per pixel was measured no faster: the LDS round trip costs what the wider stores save.)
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) {
+            const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
+            if (h < H && wcol < W) {
+                unsigned short *o = y + ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    uint2 v;
+                    v.x = (unsigned)f2bf(acc[rr][4 * g]) | ((unsigned)f2bf(acc[rr][4 * g + 1]) << 16);
+                    v.y = (unsigned)f2bf(acc[rr][4 * g + 2]) | ((unsigned)f2bf(acc[rr][4 * g + 3]) << 16);
+                    *(uint2 *)(o + 8 * g) = v;
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H, int W, void *hip_stream)
+{
+    if (!x || !w || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
+    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}

@@ -141,3 +141,30 @@ def test_fused_batchnorm_add_relu_matches_torch(dtype):
             yb = yb + r.float() if use_res else yb
             yb = F.relu(yb) if relu else yb
         torch.testing.assert_close(ya.float(), yb, **out_tol)
+
+
+def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
+    """salsa_nn_conv3x3_c64 (64 -> 64, bf16 in / f32 accumulate / bf16 out) against F.conv2d: output, data gradient (the same
+    kernel with the flipped, transposed filter) and weight gradient (MIOpen's), incl. ragged tile edges."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import Conv3x3, _Conv3x3C64
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(2)
+    conv = Conv3x3(64, 64, 3, padding=1, bias=False).to(dev)
+    for (n, h, w) in ((2, 12, 40), (3, 9, 37), (1, 1, 1), (2, 70, 33)):
+        x = torch.randn((n, 64, h, w), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.float().clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            ya = conv(xa)
+        assert isinstance(ya.grad_fn, _Conv3x3C64._backward_cls) and ya.dtype == torch.bfloat16
+        wref = conv.weight.detach().bfloat16().float().requires_grad_(True)        # the bf16-rounded filter, float32 math
+        yb = F.conv2d(xb, wref, padding=1)
+        torch.testing.assert_close(ya.float(), yb, rtol=2.0 ** -7, atol=2e-2)       # one bf16 rounding of a K=576 dot product
+        gy = torch.randn(ya.shape, device=dev, generator=g).bfloat16()
+        ya.backward(gy)
+        yb.backward(gy.float())
+        torch.testing.assert_close(xa.grad.float(), xb.grad, rtol=2.0 ** -7, atol=3e-2)
+        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=2e-2, atol=2e-2 * float(wref.grad.abs().max()))
+        conv.zero_grad()
+    y32 = conv(torch.randn(1, 64, 8, 8, device=dev))                               # float32 without autocast: torch path
+    assert y32.dtype == torch.float32 and not isinstance(y32.grad_fn, _Conv3x3C64._backward_cls)
