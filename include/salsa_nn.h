@@ -36,6 +36,8 @@ int salsa_nn_avgpool2x2_fwd(const void *x, void *y, int dtype, int64_t N, int H,
 int salsa_nn_avgpool2x2_bwd(const void *grad_y, void *grad_x, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
 
 int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H, int W, void *hip_stream);
+/* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
+int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 
 int salsa_nn_bn_supported(int dtype, int64_t M, int C);
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C); /* size of sums_ws (8-byte aligned) */

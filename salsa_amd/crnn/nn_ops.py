@@ -142,24 +142,29 @@ def _conv64(x, w):
 
 
 class _Conv3x3C64(torch.autograd.Function):
-    """64 -> 64 channel 3x3 convolution on the matrix cores: forward and data gradient are the hand-written kernel (the
-    latter with the flipped / transposed filter), the weight gradient stays with MIOpen."""
+    """64 -> 64 channel 3x3 convolution on the matrix cores (salsa_amd/csrc/conv_mfma.hip): forward, data gradient (the same
+    kernel with the flipped / transposed filter) and weight gradient (float32, straight into the float32 parameter's grad)."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return _conv64(x, w)
+    def forward(ctx, x, weight):
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, wb)
+        return _conv64(x, wb)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, wb = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv64(gy, w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+            gx = _conv64(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1]
+            N, _, H, W = x.shape
+            gw = torch.zeros((64, 64, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+            with torch.cuda.device(x.device):
+                rc = _lib.load().salsa_nn_conv3x3_c64_wrw(_ptr(x), _ptr(gy), _ptr(gw), N, H, W, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_conv3x3_c64_wrw failed (%d)' % rc)
         return gx, gw
 
 
@@ -174,7 +179,5 @@ class Conv3x3(torch.nn.Conv2d):
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.bias is None
                 and self.dilation == (1, 1) and self.groups == 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64):
             with torch.autocast('cuda', enabled=False):
-                xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-                wb = self.weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-                return _Conv3x3C64.apply(xb, wb)
+                return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
         return super().forward(x)

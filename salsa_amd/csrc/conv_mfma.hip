@@ -154,3 +154,146 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
+
+// ------------------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci]: a GEMM whose reduction runs over PIXELS, so both MFMA
+// operands need 8 consecutive pixels of ONE channel per lane while memory (and the LDS tiles) are pixel-major.  gfx950's
+// transposing LDS read does exactly that: ds_read_b64_tr_b16 with source lane i of a 16-lane group pointing at 4
+// consecutive channels of pixel row i/4 (channel block i%4) returns to lane l channel l%16 of those 4 pixel rows
+// (tools/probes/ds_tr_probe.hip prints the mapping), so two reads build one operand fragment: A = dy^T (32 co x 16 pixels),
+// B = x (16 pixels x 32 ci).  A persistent workgroup keeps 64 x 576 float32 partial sums in registers (wave = one co half
+// x one ci half x 9 taps = 9 accumulator tiles) over all its pixel tiles and adds them to the float32 result at the end.
+namespace {
+
+constexpr int WT_H = 4, WT_W = 32;                       // pixel tile
+constexpr int WHALO_W = WT_W + 2, WHALO_H = WT_H + 2;
+
+// one operand fragment = two transposing reads (pixel rows +0..3 and +4..7); issued without waiting: LDS_TR_WAIT below
+struct tr_frag {
+    unsigned long long lo, hi;
+};
+#define LDS_TR_ISSUE(f, addr, imm)                                                                                         \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                              \
+                 : "=&v"((f).lo), "=&v"((f).hi)                                                                            \
+                 : "v"(addr), "n"(imm), "n"((imm) + 4 * ROW * 2))
+#define LDS_TR_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((f).lo), "+v"((f).hi))
+__device__ __forceinline__ bf16x8 tr_value(const tr_frag &f)
+{
+    union { unsigned long long q[2]; bf16x8 v; } u;
+    u.q[0] = f.lo;
+    u.q[1] = f.hi;
+    return u.v;
+}
+
+
+template <int Q>
+__device__ __forceinline__ void wrw_steps(tr_frag (&fr)[2], bf16x8 &a, f32x16 (&acc)[9], const unsigned ga, const unsigned xa)
+{
+    if constexpr (Q < 80) {
+        if constexpr (Q + 1 < 80) {
+            constexpr int q1 = Q + 1, ks_ = q1 / 10, j_ = q1 % 10, rr_ = ks_ >> 1, hw_ = ks_ & 1;
+            if constexpr (j_ == 0) LDS_TR_ISSUE(fr[q1 & 1], ga, 2 * ((rr_ * WT_W + 16 * hw_) * ROW));
+            else LDS_TR_ISSUE(fr[q1 & 1], xa, 2 * (((rr_ + (j_ - 1) / 3) * WHALO_W + 16 * hw_ + (j_ - 1) % 3) * ROW));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q % 10 == 0) a = tr_value(fr[Q & 1]);
+        else acc[Q % 10 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_value(fr[Q & 1]), acc[Q % 10 - 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q + 1 < 80) LDS_TR_WAIT(fr[(Q + 1) & 1]);
+        wrw_steps<Q + 1>(fr, a, acc, ga, xa);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned short *__restrict__ x,
+                                                                 const unsigned short *__restrict__ dy,
+                                                                 float *__restrict__ dw, int N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xl[WHALO_H * WHALO_W * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mb = wv & 1, nb = wv >> 1;                 // this wave: co 32*mb.., ci 32*nb..
+    const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
+    // per-lane source address inside a 16-pixel x 32-channel operand block (see the comment above)
+    const unsigned a_lane = 2u * (unsigned)((8 * kh + (i16 >> 2)) * ROW + 32 * mb + 16 * cb + 4 * (i16 & 3));
+    const unsigned b_lane = 2u * (unsigned)((8 * kh + (i16 >> 2)) * ROW + 32 * nb + 16 * cb + 4 * (i16 & 3));
+    const unsigned gbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)gl;
+    const unsigned xbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xl;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = f32x16{};
+    const int tiles_w = (W + WT_W - 1) / WT_W, tiles_h = (H + WT_H - 1) / WT_H;
+    const long n_tiles = (long)N * tiles_h * tiles_w;
+    constexpr int XP = (WHALO_H * WHALO_W * 8 + 255) / 256, GP = WT_H * WT_W * 8 / 256; // 16-byte pieces per thread
+    uint4 px_[XP], pg_[GP];
+    auto fetch = [&](long tile) { // one tile's x (with halo, zeros outside the image) and dy into registers
+        const int tw = (int)(tile % tiles_w);
+        const int th = (int)((tile / tiles_w) % tiles_h);
+        const long n = tile / ((long)tiles_w * tiles_h);
+        const int h0 = th * WT_H, w0 = tw * WT_W;
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const int i = tid + j * 256, piece = i & 7, p = i >> 3;
+            const int hh = p / WHALO_W, ww = p - hh * WHALO_W;
+            const int h = h0 + hh - 1, wc = w0 + ww - 1;
+            px_[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < WHALO_H * WHALO_W * 8 && h >= 0 && h < H && wc >= 0 && wc < W)
+                px_[j] = *(const uint4 *)(x + (((n * H + h) * W + wc) * CH + piece * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < GP; j++) {
+            const int i = tid + j * 256, piece = i & 7, p = i >> 3;
+            const int hh = p / WT_W, ww = p - hh * WT_W;
+            const int h = h0 + hh, wc = w0 + ww;
+            pg_[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (h < H && wc < W) pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads(); // the previous tile's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < XP; j++) {
+            const int i = tid + j * 256;
+            if (i < WHALO_H * WHALO_W * 8) *(uint4 *)(xl + (long)(i >> 3) * ROW + (i & 7) * 8) = px_[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GP; j++) {
+            const int i = tid + j * 256;
+            *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = pg_[j];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
+        // 8 K-steps (4 rows x 2 halves of 16 consecutive pixels) x 9 taps, software-pipelined by hand like the forward kernel:
+        // the fragment of step q+1 is requested before step q's MFMA issues.  Step q = ks * 10 + j: j = 0 is the dy
+        // fragment of K-step ks, j = 1..9 the x fragment of tap j-1.
+        const unsigned ga = gbase + a_lane, xa = xbase + b_lane;
+        tr_frag fr[2];
+        bf16x8 a;
+        LDS_TR_ISSUE(fr[0], ga, 0);
+        LDS_TR_WAIT(fr[0]);
+        wrw_steps<0>(fr, a, acc, ga, xa);
+    }
+    // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the block
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), ci = 32 * nb + (lane & 31);
+            atomicAdd(dw + ((long)(co * 9 + tap) * CH + ci), acc[tap][reg]);
+        }
+}
+
+} // namespace
+
+// dw: float32 [64 co][3][3][64 ci], ADDED to (zero it first); x, dy: [N][H][W][64] bf16
+extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream)
+{
+    if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
+    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    // persistent workgroups, two per CU; fewer when there are few tiles (every workgroup ends with 36 864 float atomics)
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 256 : tiles >= 128 ? 128 : tiles);
+    hipLaunchKernelGGL(conv3x3_c64_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+                       (const unsigned short *)dy, dw, (int)N, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}

@@ -145,7 +145,8 @@ def test_fused_batchnorm_add_relu_matches_torch(dtype):
 
 def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
     """salsa_nn_conv3x3_c64 (64 -> 64, bf16 in / f32 accumulate / bf16 out) against F.conv2d: output, data gradient (the same
-    kernel with the flipped, transposed filter) and weight gradient (MIOpen's), incl. ragged tile edges."""
+    kernel with the flipped, transposed filter) and weight gradient (salsa_nn_conv3x3_c64_wrw, transposing LDS reads), incl.
+    ragged tile edges."""
     import torch.nn.functional as F
     from salsa_amd.crnn.nn_ops import Conv3x3, _Conv3x3C64
     dev = torch.device('cuda:0')
@@ -164,7 +165,8 @@ def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
         ya.backward(gy)
         yb.backward(gy.float())
         torch.testing.assert_close(xa.grad.float(), xb.grad, rtol=2.0 ** -7, atol=3e-2)
-        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=2e-2, atol=2e-2 * float(wref.grad.abs().max()))
+        assert conv.weight.grad.dtype == torch.float32                              # float32 sums of bf16 products: tight
+        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=1e-4, atol=1e-4 * float(wref.grad.abs().max()))
         conv.zero_grad()
     y32 = conv(torch.randn(1, 64, 8, 8, device=dev))                               # float32 without autocast: torch path
     assert y32.dtype == torch.float32 and not isinstance(y32.grad_fn, _Conv3x3C64._backward_cls)
