@@ -170,3 +170,71 @@ def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
         conv.zero_grad()
     y32 = conv(torch.randn(1, 64, 8, 8, device=dev))                               # float32 without autocast: torch path
     assert y32.dtype == torch.float32 and not isinstance(y32.grad_fn, _Conv3x3C64._backward_cls)
+
+
+def test_whole_model_hip_layers_on_vs_off():
+    """The CRNN with every hand-written layer (MFMA convolutions, pools, fused BatchNorm, GRU scan) against the same weights
+    with those layers switched to torch / MIOpen: bf16-autocast eval forward and one training step's loss and gradients."""
+    from salsa_amd.crnn import model as M, nn_ops
+    from salsa_amd.crnn.loss import seld_loss
+    from salsa_amd.crnn.train import synthetic_batch
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = M.SeldCRNN().to(dev).to(memory_format=torch.channels_last)
+    # no dropout: torch's nn.GRU draws its inter-layer dropout from MIOpen's own generator, so the two paths could not see
+    # the same masks
+    with torch.no_grad():                                                           # zero_init_residual would switch the
+        for mod in net.modules():                                                   # residual branches' gradients off
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    for mod in net.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.GRU):
+            mod.dropout = 0.0
+    real_dropout = M.F.dropout
+    M.F.dropout = lambda t, p=0.5, training=True, inplace=False: t
+    x, sed, doa = synthetic_batch(4, dev, seed=3)
+    x = x.contiguous(memory_format=torch.channels_last)
+
+    def run(on, amp=True):
+        nn_ops.USE_HIP_POOL = nn_ops.USE_HIP_BN = nn_ops.USE_HIP_CONV = on
+        M.FUSED_GRU = on
+        net.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            out_eval = [v.float() for _, v in sorted(net(x).items())]
+        net.train()
+        net.zero_grad()
+        torch.manual_seed(1)                                                        # same dropout masks
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            out = net(x)
+        loss = seld_loss(out, sed, doa)[0]
+        loss.backward()
+        g = {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}
+        return out_eval, float(loss.detach()), g
+
+    try:
+        bufs = {n: b.clone() for n, b in net.named_buffers()}
+        ev_on, loss_on, g_on = run(True)
+        for n, b in net.named_buffers():
+            b.copy_(bufs[n])
+        ev_off, loss_off, g_off = run(False)
+        for n, b in net.named_buffers():
+            b.copy_(bufs[n])
+        ev_ref, loss_ref, g_ref = run(False, amp=False)                             # float32 everywhere: the yardstick
+    finally:
+        nn_ops.USE_HIP_POOL = nn_ops.USE_HIP_BN = nn_ops.USE_HIP_CONV = True
+        M.FUSED_GRU = True
+        M.F.dropout = real_dropout
+    print('loss hip / torch-bf16 / float32', loss_on, loss_off, loss_ref)
+    for a, b in zip(ev_on, ev_off):
+        torch.testing.assert_close(a, b, rtol=5e-2, atol=5e-2)                      # bf16 activations through 22 layers
+    assert abs(loss_on - loss_ref) < 1e-2 * max(1.0, abs(loss_ref)) and abs(loss_off - loss_ref) < 1e-2 * max(1.0, abs(loss_ref))
+    # gradients: at random initialisation EVERY bf16 implementation is tens of percent away from float32 per tensor
+    # (and torch's own path is not reproducible run to run: atomics); ours must be no noisier than torch's
+    e_on = sorted((g_on[n] - g_ref[n]).norm().item() / (g_ref[n].norm().item() + 1e-12) for n in g_ref)
+    e_off = sorted((g_off[n] - g_ref[n]).norm().item() / (g_ref[n].norm().item() + 1e-12) for n in g_ref)
+    mid = len(e_on) // 2
+    print('gradient error vs float32, median / max: hip %.3f / %.3f   torch-bf16 %.3f / %.3f' % (e_on[mid], e_on[-1], e_off[mid], e_off[-1]))
+    assert e_on[mid] <= 1.25 * e_off[mid] + 2e-2 and e_on[-1] <= 1.5 * e_off[-1] + 5e-2
