@@ -1,8 +1,10 @@
 """Bidirectional GRU layer whose time recurrence is ONE hand-written HIP launch (salsa_amd/csrc/gru_scan.hip, C ABI in
 include/salsa_gru.h) instead of ~500 tiny library kernels per layer per step.  The dense parts stay GEMMs: the input
 projection W_ih x + b_ih for all timesteps before the scan, dW_hh / dW_ih after the backward scan.  Same float32
-arithmetic as torch.nn.GRU (gate order r, z, n); parameters are read from an nn.GRU so state dicts are unchanged."""
+arithmetic as torch.nn.GRU (gate order r, z, n); parameters are read from an nn.GRU so state dicts are unchanged.
+Without gradients (inference) the scan keeps W_hh in registers as float16 instead of streaming it from L2 every step."""
 import ctypes as C
+import os
 
 import torch
 
@@ -11,6 +13,22 @@ from .. import _lib
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+REGISTER_WEIGHTS = os.environ.get('SALSA_GRU_REGW', '1') != '0'
+
+
+def _scan_inference(gi, whh, bhh):
+    """salsa_gru_scan_fwd_regw: no-grad scan with the recurrent weights held in registers (float16), H = 256."""
+    T, B, D, H3 = gi.shape
+    H = H3 // 3
+    hs = torch.empty((T, B, D, H), dtype=torch.float32, device=gi.device)
+    rc = _lib.load().salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.detach().contiguous().data_ptr()),
+                                             C.c_void_p(bhh.detach().contiguous().data_ptr()), C.c_void_p(hs.data_ptr()),
+                                             T, B, D, H, _stream())
+    if rc:
+        raise RuntimeError('salsa_gru_scan_fwd_regw failed (%d)' % rc)
+    return hs
 
 
 class _GruScan(torch.autograd.Function):
@@ -69,6 +87,10 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool) -> torch.T
         if layer > 0 and training and gru.dropout > 0:
             out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
         gi = torch.einsum('bti,dgi->tbdg', out, wih) + bih                          # (T,B,D,3H)
-        hs = _GruScan.apply(gi.contiguous(), whh, bhh)                              # (T,B,D,H)
+        gi = gi.contiguous()
+        if REGISTER_WEIGHTS and whh.shape[2] == 256 and not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad)):
+            hs = _scan_inference(gi, whh, bhh)                                      # W_hh (float16) resident in registers
+        else:
+            hs = _GruScan.apply(gi, whh, bhh)                                       # (T,B,D,H)
         out = hs.permute(1, 0, 2, 3).reshape(x.shape[0], x.shape[1], -1)
     return out

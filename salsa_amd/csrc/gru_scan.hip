@@ -107,6 +107,83 @@ __global__ __launch_bounds__(H) void gru_bwd_kernel(const float *__restrict__ dh
     }
 }
 
+// Inference variant: W_hh RESIDENT IN REGISTERS.  With few sequences (8 clips x 2 directions = 16 workgroups) and many steps
+// (300 label-rate frames) the streaming kernel above spends ~10 us per step pulling 768 KB of weights through L2 into one
+// CU: 39 % of an inference sub-batch.  A 1024-thread workgroup's register file holds 512 KB, enough for the direction's
+// 3H x H matrix as float16 (384 KB): thread (q, part) keeps, for hidden unit q, the three gate rows' columns
+// part*64 .. +63 (192 weights = 96 registers), multiplies them with its 64-element slice of h (LDS, float32), and a
+// 4-lane butterfly completes the three dot products, so lane part 0 of every group has r, z, n of ITS unit.  float32 h,
+// gates and accumulation (v_fma_mix_f32 reads the float16 operand directly); only the recurrent weights are rounded, to
+// float16 (11 significant bits, finer than the bf16 activations the autocast encoder feeds it) -- hence inference only;
+// training keeps the float32 kernels.  One barrier per step (h is double-buffered).
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+template <int H>
+__global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restrict__ gi, const float *__restrict__ whh,
+                                                            const float *__restrict__ bhh, float *__restrict__ hs, int T, int B,
+                                                            int D)
+{
+    static_assert(H == 256, "1024 threads = 256 units x 4 column slices");
+    constexpr int KS = H / 4; // columns per thread
+    __shared__ __attribute__((aligned(16))) float h[2][H];
+    const int q = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int b = blockIdx.x, d = blockIdx.y;
+    half2_t wp[3][KS / 2];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float *row = whh + ((long)d * 3 * H + g * H + q) * H + part * KS;
+#pragma unroll
+        for (int i = 0; i < KS / 2; i++) wp[g][i] = half2_t{(_Float16)row[2 * i], (_Float16)row[2 * i + 1]};
+    }
+    const float br = bhh[d * 3 * H + q], bz = bhh[d * 3 * H + H + q], bn = bhh[d * 3 * H + 2 * H + q];
+    if (threadIdx.x < H) h[0][threadIdx.x] = 0.f;
+    float hq = 0.f;
+    __syncthreads();
+    for (int s = 0; s < T; s++) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const long base = ((long)t * B + b) * D + d;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (part == 0) { // this step's input projections, in flight during the dot products
+            const float *g = gi + base * 3 * H;
+            g0 = g[q];
+            g1 = g[H + q];
+            g2 = g[2 * H + q];
+        }
+        const float4 *hp = (const float4 *)&h[s & 1][part * KS];
+        float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+        for (int i = 0; i < KS / 4; i++) {
+            const float4 hv = hp[i];
+#pragma unroll
+            for (int g = 0; g < 3; g++) {
+                half2_t w01 = wp[g][2 * i], w23 = wp[g][2 * i + 1];
+                asm volatile("" : "+v"(w01), "+v"(w23)); // the half -> float conversions are loop-invariant: keep them from being
+                                                          // hoisted into 192 more registers (they fold into v_fma_mix_f32 here)
+                float acc = g == 0 ? ar : g == 1 ? az : an;
+                acc = fmaf((float)w01.x, hv.x, acc);
+                acc = fmaf((float)w01.y, hv.y, acc);
+                acc = fmaf((float)w23.x, hv.z, acc);
+                acc = fmaf((float)w23.y, hv.w, acc);
+                if (g == 0) ar = acc;
+                else if (g == 1) az = acc;
+                else an = acc;
+            }
+            __builtin_amdgcn_sched_barrier(0); // 96 of the 128 registers hold weights: one h vector in flight at a time
+        }
+        ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
+        ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
+        if (part == 0) {
+            const float r = sigmoidf_(g0 + ar + br);
+            const float z = sigmoidf_(g1 + az + bz);
+            const float n = tanhf(g2 + r * (an + bn));
+            hq = (1.f - z) * n + z * hq;
+            hs[base * H + q] = hq;
+            h[(s + 1) & 1][q] = hq;
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -120,6 +197,15 @@ int salsa_gru_scan_fwd(const float *gi, const float *whh_t, const float *bhh, fl
     if (H == 256) hipLaunchKernelGGL((gru_fwd_kernel<256>), grid, dim3(256), 0, s, gi, whh_t, bhh, hs, saved, T, B, D);
     else if (H == 128) hipLaunchKernelGGL((gru_fwd_kernel<128>), grid, dim3(128), 0, s, gi, whh_t, bhh, hs, saved, T, B, D);
     else hipLaunchKernelGGL((gru_fwd_kernel<64>), grid, dim3(64), 0, s, gi, whh_t, bhh, hs, saved, T, B, D);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_gru_scan_fwd_regw(const float *gi, const float *whh, const float *bhh, float *hs, int T, int B, int D, int H,
+                            void *hip_stream)
+{
+    if (!gi || !whh || !bhh || !hs || T <= 0 || B <= 0 || D <= 0 || H != 256) return -1;
+    hipLaunchKernelGGL((gru_fwd_regw_kernel<256>), dim3((unsigned)B, (unsigned)D), dim3(1024), 0, (hipStream_t)hip_stream, gi, whh,
+                       bhh, hs, T, B, D);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

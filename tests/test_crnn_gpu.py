@@ -238,3 +238,24 @@ def test_whole_model_hip_layers_on_vs_off():
     mid = len(e_on) // 2
     print('gradient error vs float32, median / max: hip %.3f / %.3f   torch-bf16 %.3f / %.3f' % (e_on[mid], e_on[-1], e_off[mid], e_off[-1]))
     assert e_on[mid] <= 1.25 * e_off[mid] + 2e-2 and e_on[-1] <= 1.5 * e_off[-1] + 5e-2
+
+
+def test_register_resident_gru_inference_scan():
+    """salsa_gru_scan_fwd_regw (no-grad path, W_hh as float16 in registers) against torch.nn.GRU in float32 and against the
+    float32 streaming scan: long sequences, both directions, two layers."""
+    from salsa_amd.crnn import fused_gru
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    gru = torch.nn.GRU(512, 256, num_layers=2, batch_first=True, bidirectional=True, dropout=0.3).to(dev).eval()
+    x = torch.randn(5, 300, 512, device=dev)
+    with torch.no_grad():
+        ref = gru(x)[0]
+        fast = fused_gru.bigru_forward(gru, x, training=False)
+        fused_gru.REGISTER_WEIGHTS = False
+        try:
+            slow = fused_gru.bigru_forward(gru, x, training=False)
+        finally:
+            fused_gru.REGISTER_WEIGHTS = True
+    torch.testing.assert_close(slow, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(fast, ref, rtol=2e-3, atol=2e-3)                     # float16 weights: 2^-11 per weight
+    assert not torch.equal(fast, slow)                                              # (the two kernels really are different)
