@@ -36,6 +36,10 @@ int salsa_nn_avgpool2x2_fwd(const void *x, void *y, int dtype, int64_t N, int H,
 int salsa_nn_avgpool2x2_bwd(const void *grad_y, void *grad_x, int dtype, int64_t N, int H, int W, int C, void *hip_stream);
 
 int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H, int W, void *hip_stream);
+/* inference: y = [relu](conv(x, w) + shift[co] [+ residual]) with the BatchNorm that follows folded in: w pre-scaled by
+ * gamma / sqrt(var + eps) per output channel, shift = beta - mean * gamma / sqrt(var + eps) (float32 [64]); residual bf16 or NULL */
+int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y, int relu,
+                                  int64_t N, int H, int W, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2
+from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2, conv_bn_act
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -40,8 +40,8 @@ class Stem(nn.Module):
         self.conv2, self.bn2 = _conv(cout, cout, 3), BatchNormAct2d(cout)
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
+        x = conv_bn_act(self.conv1, self.bn1, x)
+        x = conv_bn_act(self.conv2, self.bn2, x)
         return avg_pool2x2(x)
 
 
@@ -61,11 +61,11 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         y = avg_pool2x2(x) if self.stride == 2 else x
-        out = self.bn1(self.conv1(y), relu=True)
+        out = conv_bn_act(self.conv1, self.bn1, y)
         out = F.dropout(out, p=0.1, training=self.training)
         if self.short_conv is not None:
             x = self.short_bn(self.short_conv(y))
-        return self.bn2(self.conv2(out), residual=x, relu=True)            # relu(bn2(conv2(out)) + shortcut)
+        return conv_bn_act(self.conv2, self.bn2, out, residual=x)          # relu(bn2(conv2(out)) + shortcut)
 
 
 class Encoder(nn.Module):

@@ -172,12 +172,39 @@ class Conv3x3(torch.nn.Conv2d):
     """nn.Conv2d(cin, cout, 3, padding=1, bias=False) whose 64 -> 64 instances run the MFMA kernel for bf16 channels-last
     CUDA inputs (i.e. under the trainer's autocast); everything else is F.conv2d."""
 
-    def forward(self, x):
+    def _hip_eligible(self, x):
         bf16 = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)
-        if (USE_HIP_CONV and x.is_cuda and bf16 and self.in_channels == 64 and self.out_channels == 64 and x.dim() == 4
+        return (USE_HIP_CONV and x.is_cuda and bf16 and self.in_channels == 64 and self.out_channels == 64 and x.dim() == 4
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.bias is None
-                and self.dilation == (1, 1) and self.groups == 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64):
+                and self.dilation == (1, 1) and self.groups == 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64)
+
+    def forward(self, x):
+        if self._hip_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
         return super().forward(x)
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """relu(bn(conv(x)) + residual) of the reference blocks.  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
+    autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
+    residual add and the ReLU -- before its single rounding: the normalised activation never makes a round trip to HBM.
+    Every other case is conv -> BatchNormAct2d."""
+    if (isinstance(conv, Conv3x3) and conv._hip_eligible(x) and not bn.training and not torch.is_grad_enabled()
+            and bn.track_running_stats and bn.affine
+            and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == 64
+                                      and residual.is_contiguous(memory_format=torch.channels_last)))):
+        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
+        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        N, _, H, W = xb.shape
+        y = torch.empty_like(xb, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_conv3x3_c64_bias_act(_ptr(xb), _ptr(wf), _ptr(shift), _ptr(residual), _ptr(y), int(relu),
+                                                           N, H, W, _stream(xb))
+        if rc:
+            raise RuntimeError('salsa_nn_conv3x3_c64_bias_act failed (%d)' % rc)
+        return y
+    return bn(conv(x), residual=residual, relu=relu)

@@ -43,7 +43,9 @@ __device__ __forceinline__ unsigned short f2bf(float f)
 // current tile is multiplied.
 __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const unsigned short *__restrict__ x,
                                                               const unsigned short *__restrict__ w,
-                                                              unsigned short *__restrict__ y, int N, int H, int W)
+                                                              unsigned short *__restrict__ y, int N, int H, int W,
+                                                              const float *__restrict__ shift,
+                                                              const unsigned short *__restrict__ residual, int relu)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xl[HALO_H * HALO_W * ROW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -129,12 +131,27 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
         for (int rr = 0; rr < RPW; rr++) {
             const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
             if (h < H && wcol < W) {
-                unsigned short *o = y + ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
+                const long off = ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
+                unsigned short *o = y + off;
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
+                    float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
+                    if (shift) { // inference epilogue: folded BatchNorm shift (+ residual) (+ ReLU) before the single rounding
+                        const float4 sh = *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g);
+                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                        if (residual) {
+                            const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
+                            v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                            v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                        }
+                    }
                     uint2 v;
-                    v.x = (unsigned)f2bf(acc[rr][4 * g]) | ((unsigned)f2bf(acc[rr][4 * g + 1]) << 16);
-                    v.y = (unsigned)f2bf(acc[rr][4 * g + 2]) | ((unsigned)f2bf(acc[rr][4 * g + 3]) << 16);
+                    v.x = (unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16);
+                    v.y = (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16);
                     *(uint2 *)(o + 8 * g) = v;
                 }
             }
@@ -151,7 +168,20 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
     // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
+                       (const unsigned short *)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// inference: y = [relu](conv(x, w) + shift[co] [+ residual]) -- w pre-scaled by the folded BatchNorm factor gamma / sigma
+extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y,
+                                             int relu, int64_t N, int H, int W, void *hip_stream)
+{
+    if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
+    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -259,3 +259,30 @@ def test_register_resident_gru_inference_scan():
     torch.testing.assert_close(slow, ref, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(fast, ref, rtol=2e-3, atol=2e-3)                     # float16 weights: 2^-11 per weight
     assert not torch.equal(fast, slow)                                              # (the two kernels really are different)
+
+
+def test_eval_conv_with_folded_batchnorm_epilogue():
+    """conv_bn_act in eval mode (BatchNorm folded into the MFMA convolution's filter and epilogue, residual add and ReLU before
+    the single rounding) against the unfused float32 computation on the same bf16-valued inputs."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(6)
+    conv = nn_ops.Conv3x3(64, 64, 3, padding=1, bias=False).to(dev).eval()
+    bn = nn_ops.BatchNormAct2d(64).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, device=dev, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(64, device=dev, generator=g))
+        bn.running_mean.copy_(torch.randn(64, device=dev, generator=g))
+        bn.running_var.copy_(torch.rand(64, device=dev, generator=g) + 0.5)
+    for use_res, relu in ((False, True), (True, True), (True, False)):
+        x = torch.randn((2, 64, 21, 45), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        r = torch.randn((2, 64, 21, 45), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last) if use_res else None
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            y = nn_ops.conv_bn_act(conv, bn, x, residual=r, relu=relu)
+        assert y.dtype == torch.bfloat16
+        ref = F.batch_norm(F.conv2d(x.float(), conv.weight.float(), padding=1), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                           False, 0.0, bn.eps)
+        ref = ref + r.float() if use_res else ref
+        ref = F.relu(ref) if relu else ref
+        torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)            # bf16 filter (scaled) and output rounding
