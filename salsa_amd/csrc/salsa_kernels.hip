@@ -111,9 +111,11 @@ __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * _
 template <typename V> __device__ __forceinline__ void st_off(V *base, unsigned byte_off, const V v) { *(V *)((char *)base + byte_off) = v; }
 template <typename V> __device__ __forceinline__ V ld_off(const V *base, unsigned byte_off) { return *(const V *)((const char *)base + byte_off); }
 
-constexpr int K1_NF = 4;                                          // frames per wave (8 reuses more overlap per wave but leaves a
-                                                                  // 29 %-full last round of workgroups: measured 2 % slower)
-constexpr int K1_FRAMES_PER_BLOCK = 4 * K1_NF;
+// frames per wave.  Full SALSA: 4 (8 reuses more overlap per wave but leaves a 29 %-full last round of workgroups: measured
+// 2 % slower).  SALSA-Lite, whose items are frame-major and heavier (phase rows instead of the spill): 8 (4 measured 4 % slower)
+template <bool LITE> struct k1_cfg {
+    static constexpr int NF = LITE ? 8 : 4;
+};
 
 template <int N, typename T, bool LITE>
 __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int Ns = kp.N, Tn = kp.T;
+    constexpr int K1_NF = k1_cfg<LITE>::NF;
     const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
     cplx<T> *z = buf[w];
 
@@ -1055,9 +1058,10 @@ static void mark_end(salsa_plan *pl, hipStream_t s, int i)
 
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
-    const unsigned nblk = (unsigned)((kp.T + K1_FRAMES_PER_BLOCK - 1) / K1_FRAMES_PER_BLOCK);
-    dim3 grid(nblk, (unsigned)kp.B);
     const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
+    const int fpb = 4 * (lite ? k1_cfg<true>::NF : k1_cfg<false>::NF); // frames per workgroup
+    const unsigned nblk = (unsigned)((kp.T + fpb - 1) / fpb);
+    dim3 grid(nblk, (unsigned)kp.B);
     if (pl->p.n_fft == 512) {
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else hipLaunchKernelGGL((stft_kernel<512, double, false>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
