@@ -259,3 +259,77 @@ class StreamedExtractor:
         for e, o in pending:
             e.synchronize()
             yield o
+
+
+class HostPipeline:
+    """Host buffers in, host buffers out (what the reference-surface harness needs): ``depth`` slots, each with pinned
+    staging, device buffers, its own plan and its own copy-in / compute / copy-out streams, so the PCIe transfer of one batch
+    in each direction overlaps the kernels of another (MI355X moves data in both directions at once).  ``run`` takes an
+    iterable of float32 host arrays ``(B, 4, N)`` (or ``(B, N, 4)`` for interleaved plans) of ONE shape and yields float32
+    host feature arrays ``(B, 7, T, F)`` in order; a yielded array is a view of a pinned slot that is reused ``depth``
+    batches later -- copy it or finish with it before pulling that far ahead."""
+
+    def __init__(self, depth: int = 3, **extractor_kwargs):
+        self.depth = depth
+        self.exs = [SalsaExtractor(**extractor_kwargs) for _ in range(depth)]
+        dev = self.exs[0].device
+        self.s_in = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.s_run = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.s_out = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.slots = None
+
+    def _alloc(self, shape):
+        ex = self.exs[0]
+        n = shape[2] if ex.audio_layout == 'planar' else shape[1]
+        oshape = (shape[0],) + tuple(ex.output_shape(n))
+        dev = ex.device
+        self.slots = [dict(h_in=torch.empty(shape, dtype=torch.float32, pin_memory=True),
+                           d_in=torch.empty(shape, dtype=torch.float32, device=dev),
+                           d_out=torch.empty(oshape, dtype=torch.float32, device=dev),
+                           h_out=torch.empty(oshape, dtype=torch.float32, pin_memory=True),
+                           done=None) for _ in range(self.depth)]
+        self.shape = tuple(shape)
+
+    def run(self, batches=None, fill=None, n_batches=None, shape=None):
+        """Either ``batches``: an iterable of host arrays (each is copied into a pinned slot: one extra host copy), or
+        ``fill(buf, i)``: a callback that writes batch i straight into the pinned numpy array ``buf`` of ``shape`` (what a file
+        reader should do), called for i = 0 .. n_batches-1."""
+        if fill is not None:
+            if self.slots is None or tuple(shape) != self.shape:
+                self._alloc(tuple(shape))
+            source = range(n_batches)
+        else:
+            source = batches
+        pending = []
+        for i, a in enumerate(source):
+            if fill is None:
+                a = torch.as_tensor(a)
+                if self.slots is None or tuple(a.shape) != self.shape:
+                    assert not pending, 'all batches of one run must have the same shape'
+                    self._alloc(tuple(a.shape))
+            j = i % self.depth
+            sl = self.slots[j]
+            if sl['done'] is not None:
+                sl['done'].synchronize()                          # the slot's previous round trip has finished
+            if fill is None:
+                sl['h_in'].copy_(a)                               # host -> pinned staging
+            else:
+                fill(sl['h_in'].numpy(), i)
+            with torch.cuda.stream(self.s_in[j]):
+                sl['d_in'].copy_(sl['h_in'], non_blocking=True)
+            self.s_run[j].wait_stream(self.s_in[j])
+            with torch.cuda.stream(self.s_run[j]):
+                self.exs[j].extract(sl['d_in'], out=sl['d_out'])
+            self.s_out[j].wait_stream(self.s_run[j])
+            with torch.cuda.stream(self.s_out[j]):
+                sl['h_out'].copy_(sl['d_out'], non_blocking=True)
+                sl['done'] = torch.cuda.Event()
+                sl['done'].record(self.s_out[j])
+            pending.append(j)
+            if len(pending) == self.depth:
+                k = pending.pop(0)
+                self.slots[k]['done'].synchronize()
+                yield self.slots[k]['h_out'].numpy()
+        for k in pending:
+            self.slots[k]['done'].synchronize()
+            yield self.slots[k]['h_out'].numpy()

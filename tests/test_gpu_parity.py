@@ -527,3 +527,17 @@ def test_one_pass_augmentation_kernel_equals_the_torch_composite(dev, fmt):
     xa, sed, ya = augment_batch(x, doa[:, :, :12], doa, fmt, gen=torch.Generator().manual_seed(9))
     xb, yb = apply_augment_torch(x, doa, draw_augment(B, T, F, fmt, gen=torch.Generator().manual_seed(9)), fmt)
     assert torch.equal(xa, xb) and torch.equal(ya, yb)
+
+
+def test_host_pipeline_matches_direct_extraction(dev):
+    from salsa_amd.extractor import HostPipeline
+    ys = [np.stack([synth_clip(700 + 10 * k + i, 40000) for i in range(3)]) for k in range(7)]
+    ex = _extractor()
+    want = [ex.extract(torch.from_numpy(y).to(dev)).cpu().numpy() for y in ys]
+    pipe = HostPipeline(depth=3)
+    got = [o.copy() for o in pipe.run(ys)]
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    got2 = [o.copy() for o in pipe.run(ys[:2])]                                      # fewer batches than slots; reuse of the slots
+    assert all(np.array_equal(a, b) for a, b in zip(got2, want[:2]))
+    got3 = [o.copy() for o in pipe.run(fill=lambda buf, i: buf.__setitem__(Ellipsis, ys[i]), n_batches=5, shape=ys[0].shape)]
+    assert all(np.array_equal(a, b) for a, b in zip(got3, want[:5]))
