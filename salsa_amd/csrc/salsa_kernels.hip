@@ -8,9 +8,11 @@
 //                       complex64 STFT) to the workspace as Xs[b][t][channel pair][bin] (float4).
 //   K2 tracker_kernel   one lane per (clip, bin): 3-frame RMS of channel 0 and the sequential noise-floor tracker
 //                       in float64 -> valid[b][64-frame chunk][bin] (64-bit indicator history per bin).
-//   K3 cov_eig_kernel   one lane per TF bin (64 consecutive bins of one frame per wave, coalesced): 7-frame Hermitian
-//                       covariance accumulated in registers, eigen-gate + principal eigenvector (salsa_math.h),
-//                       FOA / MIC normalisation, writes channels 4-6 (zeros where gated).
+//   K3 cov_eig_kernel   per tile of 8 frames x 256 bins the gated (frame, bin) pairs are compacted into an LDS work list; one lane
+//                       per listed pair: 7-frame Hermitian covariance accumulated in registers, eigen-gate + principal
+//                       eigenvector (salsa_math.h), FOA / MIC normalisation, writes channels 4-6 (zeros where gated).
+// Further entry points: salsa_eigvec_batch (K2 + K3 on caller-supplied spectra), salsa_logspec_batch (K1 only), the scaler /
+// normalise kernels, the contrib-surface variants (SALSA_FLAG_FLEX), salsa_to_freq_major, salsa_augment_batch.
 // SALSA-Lite / IPD is K1 alone (log-spectrogram + inter-channel phase fused into the unpack).
 //
 // Arithmetic types follow the reference (see DESIGN.md "Precision"): STFT evaluated in float64 and rounded to
