@@ -20,11 +20,14 @@ extern "C" {
 int salsa_gru_scan_fwd(const float *gi, const float *whh_t, const float *bhh, float *hs, float *saved, int T, int B, int D,
                        int H, void *hip_stream);
 
-/* Inference variant for H = 256: the recurrent weights (PyTorch layout whh, rounded to float16) stay in the registers of a
- * 1024-thread workgroup for the whole scan instead of being streamed from L2 every step; float32 state, gates and
- * accumulation.  No `saved` output (no backward). */
-int salsa_gru_scan_fwd_regw(const float *gi, const float *whh, const float *bhh, float *hs, int T, int B, int D, int H,
-                            void *hip_stream);
+/* Register-resident variants for H = 256: the recurrent weights (PyTorch layout whh, rounded to float16) stay in the
+ * registers of a 1024-thread workgroup for the whole scan instead of being streamed from L2 every step; float32 state,
+ * gates and accumulation.  Used without gradients (saved = NULL) and for training under bf16 autocast, where the backward
+ * variant differentiates the same rounded weights (same arguments as salsa_gru_scan_bwd). */
+int salsa_gru_scan_fwd_regw(const float *gi, const float *whh, const float *bhh, float *hs, float *saved, int T, int B, int D,
+                            int H, void *hip_stream);
+int salsa_gru_scan_bwd_regw(const float *dhs, const float *whh, const float *hs, const float *saved, float *dgi, float *dgh,
+                            int T, int B, int D, int H, void *hip_stream);
 
 /* dhs [T][B][D][H] = gradient wrt every hs[t].  Outputs: dgi [T][B][D][3H] (gradient wrt gi) and dgh [T][B][D][3H]
  * (gradient wrt W_hh h_prev + b_hh; the caller forms dW_hh = sum_t,b dgh^T h_prev and db_hh with one GEMM). */

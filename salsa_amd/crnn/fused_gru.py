@@ -25,7 +25,7 @@ def _scan_inference(gi, whh, bhh):
     hs = torch.empty((T, B, D, H), dtype=torch.float32, device=gi.device)
     rc = _lib.load().salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.detach().contiguous().data_ptr()),
                                              C.c_void_p(bhh.detach().contiguous().data_ptr()), C.c_void_p(hs.data_ptr()),
-                                             T, B, D, H, _stream())
+                                             None, T, B, D, H, _stream())
     if rc:
         raise RuntimeError('salsa_gru_scan_fwd_regw failed (%d)' % rc)
     return hs
@@ -33,23 +33,29 @@ def _scan_inference(gi, whh, bhh):
 
 class _GruScan(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gi, whh, bhh):
-        """gi (T,B,D,3H) float32 contiguous; whh (D,3H,H); bhh (D,3H) -> hs (T,B,D,H)."""
+    def forward(ctx, gi, whh, bhh, half_weights=False):
+        """gi (T,B,D,3H) float32 contiguous; whh (D,3H,H); bhh (D,3H) -> hs (T,B,D,H).  half_weights: the register-resident
+        kernels (W_hh rounded to float16, forward and backward consistently) instead of the float32 streaming ones."""
         T, B, D, H3 = gi.shape
         H = H3 // 3
         L = _lib.load()
         whh = whh.contiguous()
-        whh_t = whh.transpose(1, 2).contiguous()
         hs = torch.empty((T, B, D, H), dtype=torch.float32, device=gi.device)
         need_grad = gi.requires_grad or whh.requires_grad or bhh.requires_grad
         saved = torch.empty((T, B, D, 4 * H), dtype=torch.float32, device=gi.device) if need_grad else None
-        rc = L.salsa_gru_scan_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh_t.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
-                                  C.c_void_p(hs.data_ptr()), C.c_void_p(saved.data_ptr() if saved is not None else 0),
-                                  T, B, D, H, _stream())
+        sv = C.c_void_p(saved.data_ptr() if saved is not None else 0)
+        if half_weights:
+            rc = L.salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
+                                           C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream())
+        else:
+            whh_t = whh.transpose(1, 2).contiguous()
+            rc = L.salsa_gru_scan_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh_t.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
+                                      C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream())
         if rc:
             raise RuntimeError('salsa_gru_scan_fwd failed (%d)' % rc)
         if need_grad:
             ctx.save_for_backward(whh, hs, saved)
+        ctx.half_weights = bool(half_weights)
         return hs
 
     @staticmethod
@@ -60,9 +66,9 @@ class _GruScan(torch.autograd.Function):
         dhs = dhs.contiguous()
         dgi = torch.empty((T, B, D, 3 * H), dtype=torch.float32, device=hs.device)
         dgh = torch.empty_like(dgi)
-        rc = L.salsa_gru_scan_bwd(C.c_void_p(dhs.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(hs.data_ptr()),
-                                  C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()),
-                                  T, B, D, H, _stream())
+        scan = L.salsa_gru_scan_bwd_regw if ctx.half_weights else L.salsa_gru_scan_bwd
+        rc = scan(C.c_void_p(dhs.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(hs.data_ptr()),
+                  C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()), T, B, D, H, _stream())
         if rc:
             raise RuntimeError('salsa_gru_scan_bwd failed (%d)' % rc)
         hprev = torch.zeros_like(hs)                       # h before each step, per direction's scan order
@@ -71,11 +77,13 @@ class _GruScan(torch.autograd.Function):
             hprev[:-1, :, 1] = hs[1:, :, 1]
         dwhh = torch.einsum('tbdr,tbdk->drk', dgh, hprev)  # one GEMM per direction
         dbhh = dgh.sum(dim=(0, 1))
-        return dgi, dwhh, dbhh
+        return dgi, dwhh, dbhh, None
 
 
-def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool) -> torch.Tensor:
-    """x (B,T,In) float32 CUDA -> (B,T,2H); equivalent to ``gru(x)[0]`` for a batch_first bidirectional nn.GRU."""
+def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weights: bool = False) -> torch.Tensor:
+    """x (B,T,In) float32 CUDA -> (B,T,2H); equivalent to ``gru(x)[0]`` for a batch_first bidirectional nn.GRU.
+    half_weights (the caller is under bf16 autocast): train through the register-resident kernels, i.e. with W_hh rounded to
+    float16 in the recurrence -- finer than the bf16 autocast would give nn.GRU; without gradients they are always used."""
     assert gru.batch_first and gru.bidirectional and gru.bias
     out = x
     for layer in range(gru.num_layers):
@@ -91,6 +99,6 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool) -> torch.T
         if REGISTER_WEIGHTS and whh.shape[2] == 256 and not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad)):
             hs = _scan_inference(gi, whh, bhh)                                      # W_hh (float16) resident in registers
         else:
-            hs = _GruScan.apply(gi, whh, bhh)                                       # (T,B,D,H)
+            hs = _GruScan.apply(gi, whh, bhh, bool(half_weights and REGISTER_WEIGHTS and whh.shape[2] == 256))   # (T,B,D,H)
         out = hs.permute(1, 0, 2, 3).reshape(x.shape[0], x.shape[1], -1)
     return out

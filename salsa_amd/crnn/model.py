@@ -136,10 +136,11 @@ class Decoder(nn.Module):
         if seq.is_cuda and GRU_FP32:
             # 0.4 % of the FLOPs but, under bf16 autocast, ~6000 per-timestep cell kernels per forward (torch's native
             # fallback); in float32 the whole sequence goes through MIOpen's fused RNN
+            amp = torch.is_autocast_enabled('cuda')
             with torch.autocast(device_type='cuda', enabled=False):
                 if FUSED_GRU:
                     from .fused_gru import bigru_forward
-                    seq = bigru_forward(self.gru, seq.float(), self.training)   # one HIP launch per layer for the scan
+                    seq = bigru_forward(self.gru, seq.float(), self.training, half_weights=amp)   # one HIP launch per layer
                 else:
                     seq, _ = self.gru(seq.float())
         else:

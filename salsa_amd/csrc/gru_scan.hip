@@ -114,14 +114,15 @@ __global__ __launch_bounds__(H) void gru_bwd_kernel(const float *__restrict__ dh
 // part*64 .. +63 (192 weights = 96 registers), multiplies them with its 64-element slice of h (LDS, float32), and a
 // 4-lane butterfly completes the three dot products, so lane part 0 of every group has r, z, n of ITS unit.  float32 h,
 // gates and accumulation (v_fma_mix_f32 reads the float16 operand directly); only the recurrent weights are rounded, to
-// float16 (11 significant bits, finer than the bf16 activations the autocast encoder feeds it) -- hence inference only;
-// training keeps the float32 kernels.  One barrier per step (h is double-buffered).
+// float16 (11 significant bits, finer than the bf16 that autocast would give an nn.GRU) -- used without gradients
+// (inference) and for training under bf16 autocast, with gru_bwd_regw_kernel differentiating the SAME rounded weights;
+// float32 training keeps the float32 kernels above.  One barrier per step (h is double-buffered).
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 template <int H>
 __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restrict__ gi, const float *__restrict__ whh,
-                                                            const float *__restrict__ bhh, float *__restrict__ hs, int T, int B,
-                                                            int D)
+                                                            const float *__restrict__ bhh, float *__restrict__ hs,
+                                                            float *__restrict__ saved, int T, int B, int D)
 {
     static_assert(H == 256, "1024 threads = 256 units x 4 column slices");
     constexpr int KS = H / 4; // columns per thread
@@ -179,8 +180,89 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
             hq = (1.f - z) * n + z * hq;
             hs[base * H + q] = hq;
             h[(s + 1) & 1][q] = hq;
+            if (saved) { // for the backward scan: r, z, n and W_hn h + b_hn
+                float *sv = saved + base * 4 * H;
+                sv[q] = r;
+                sv[H + q] = z;
+                sv[2 * H + q] = n;
+                sv[3 * H + q] = an + bn;
+            }
         }
         __syncthreads();
+    }
+}
+
+// Backward scan with W_hh resident in registers (float16), the counterpart of gru_fwd_regw_kernel: thread (q, part) keeps
+// COLUMN q of W_hh for the rows part*192 .. +191 (192 weights), i.e. its share of dh_prev[q] = sum_rows W_hh[row][q] * dgh[row].
+// Per step: the part-0 lane of unit q forms the gate derivatives of its unit and publishes (dr_pre, dz_pre, dhn) in LDS; after
+// a barrier every thread multiplies its 192 weights with its slice of that vector and a 4-lane butterfly completes dh_prev.
+template <int H>
+__global__ __launch_bounds__(1024) void gru_bwd_regw_kernel(const float *__restrict__ dhs, const float *__restrict__ whh,
+                                                            const float *__restrict__ hs, const float *__restrict__ saved,
+                                                            float *__restrict__ dgi, float *__restrict__ dgh, int T, int B, int D)
+{
+    static_assert(H == 256, "1024 threads = 256 units x 4 row slices");
+    constexpr int RS = 3 * H / 4; // rows per thread
+    __shared__ __attribute__((aligned(16))) float g[2][3 * H];
+    const int q = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int b = blockIdx.x, d = blockIdx.y;
+    half2_t wp[RS / 2];
+#pragma unroll
+    for (int i = 0; i < RS / 2; i++) {
+        const float *w0 = whh + ((long)d * 3 * H + part * RS + 2 * i) * H + q;
+        wp[i] = half2_t{(_Float16)w0[0], (_Float16)w0[H]};
+    }
+    float carry = 0.f;
+    for (int s = T - 1; s >= 0; s--) { // reverse of the forward scan order
+        const int t = d == 0 ? s : T - 1 - s;
+        const long base = ((long)t * B + b) * D + d;
+        float dhz = 0.f;
+        float *gs = g[s & 1];
+        if (part == 0) {
+            float hprev = 0.f;
+            if (s > 0) {
+                const int tp = d == 0 ? t - 1 : t + 1;
+                hprev = hs[(((long)tp * B + b) * D + d) * H + q];
+            }
+            const float *sv = saved + base * 4 * H;
+            const float r = sv[q], z = sv[H + q], n = sv[2 * H + q], hn = sv[3 * H + q];
+            const float dh = dhs[base * H + q] + carry;
+            const float dn = dh * (1.f - z);
+            const float dz = dh * (hprev - n);
+            const float dn_pre = dn * (1.f - n * n);
+            const float dr_pre = dn_pre * hn * r * (1.f - r);
+            const float dz_pre = dz * z * (1.f - z);
+            const float dhn = dn_pre * r;
+            float *o = dgi + base * 3 * H;
+            o[q] = dr_pre;
+            o[H + q] = dz_pre;
+            o[2 * H + q] = dn_pre;
+            float *qq = dgh + base * 3 * H;
+            qq[q] = dr_pre;
+            qq[H + q] = dz_pre;
+            qq[2 * H + q] = dhn;
+            gs[q] = dr_pre;
+            gs[H + q] = dz_pre;
+            gs[2 * H + q] = dhn;
+            dhz = dh * z;
+        }
+        __syncthreads(); // g of this step is complete (the other buffer may still be read by slower waves: double-buffered)
+        const float4 *gp = (const float4 *)&gs[part * RS];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < RS / 4; i++) {
+            const float4 gv = gp[i];
+            half2_t w01 = wp[2 * i], w23 = wp[2 * i + 1];
+            asm volatile("" : "+v"(w01), "+v"(w23)); // keep the loop-invariant half -> float conversions out of registers
+            acc = fmaf((float)w01.x, gv.x, acc);
+            acc = fmaf((float)w01.y, gv.y, acc);
+            acc = fmaf((float)w23.x, gv.z, acc);
+            acc = fmaf((float)w23.y, gv.w, acc);
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        carry = acc + dhz; // only read by the part-0 lane
     }
 }
 
@@ -200,12 +282,21 @@ int salsa_gru_scan_fwd(const float *gi, const float *whh_t, const float *bhh, fl
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
-int salsa_gru_scan_fwd_regw(const float *gi, const float *whh, const float *bhh, float *hs, int T, int B, int D, int H,
-                            void *hip_stream)
+int salsa_gru_scan_fwd_regw(const float *gi, const float *whh, const float *bhh, float *hs, float *saved, int T, int B, int D,
+                            int H, void *hip_stream)
 {
     if (!gi || !whh || !bhh || !hs || T <= 0 || B <= 0 || D <= 0 || H != 256) return -1;
     hipLaunchKernelGGL((gru_fwd_regw_kernel<256>), dim3((unsigned)B, (unsigned)D), dim3(1024), 0, (hipStream_t)hip_stream, gi, whh,
-                       bhh, hs, T, B, D);
+                       bhh, hs, saved, T, B, D);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_gru_scan_bwd_regw(const float *dhs, const float *whh, const float *hs, const float *saved, float *dgi, float *dgh,
+                            int T, int B, int D, int H, void *hip_stream)
+{
+    if (!dhs || !whh || !hs || !saved || !dgi || !dgh || T <= 0 || B <= 0 || D <= 0 || H != 256) return -1;
+    hipLaunchKernelGGL((gru_bwd_regw_kernel<256>), dim3((unsigned)B, (unsigned)D), dim3(1024), 0, (hipStream_t)hip_stream, dhs, whh,
+                       hs, saved, dgi, dgh, T, B, D);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -286,3 +286,25 @@ def test_eval_conv_with_folded_batchnorm_epilogue():
         ref = ref + r.float() if use_res else ref
         ref = F.relu(ref) if relu else ref
         torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)            # bf16 filter (scaled) and output rounding
+
+
+def test_register_resident_gru_training_scan_gradients():
+    """half_weights=True (what the model passes under bf16 autocast): forward + BPTT through the register-resident kernels,
+    against torch.nn.GRU in float32 -- outputs and every gradient within the float16 rounding of W_hh."""
+    from salsa_amd.crnn import fused_gru
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    gru = torch.nn.GRU(512, 256, num_layers=2, batch_first=True, bidirectional=True, dropout=0.0).to(dev).train()
+    ref = torch.nn.GRU(512, 256, num_layers=2, batch_first=True, bidirectional=True, dropout=0.0).to(dev).train()
+    ref.load_state_dict(gru.state_dict())
+    x = torch.randn(6, 80, 512, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = fused_gru.bigru_forward(gru, xa, training=True, half_weights=True)
+    yb = ref(xb)[0]
+    torch.testing.assert_close(ya, yb, rtol=2e-3, atol=2e-3)
+    gy = torch.randn_like(yb)
+    ya.backward(gy)
+    yb.backward(gy)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-2, atol=2e-3)
+    for (n, p), (_, q) in zip(gru.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-2, atol=1e-2 * float(q.grad.abs().max()), msg=n)
