@@ -140,24 +140,22 @@ template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], 
     }
 }
 
-// sums[0..1][C] (float64) = sum over the blocks' partials [nblk][2][C].  A 256-thread block = 8 outputs x 32 threads
-// that each add every 32nd partial (coalesced over the 8 adjacent outputs), then an LDS tree over the 32.
-__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float *__restrict__ part, int nblk, int C,
-                                                              double *__restrict__ sums)
+// Sum the blocks' partials [nblk][2][C] for FOUR channels (both sums) in float64: a 256-thread block = 8 outputs
+// (o = which * 4 + channel) x 32 threads that each add every 32nd partial, then an LDS tree over the 32.  On return
+// red[o] holds the totals; the statistics kernels below finish their per-channel arithmetic in the same launch.
+__device__ __forceinline__ void bn_sum_partials4(const float *__restrict__ part, int nblk, int C, int c0, double *red /*[256]*/)
 {
-    __shared__ double red[256];
     const int o = threadIdx.x & 7, seg = threadIdx.x >> 3;
-    const int i = blockIdx.x * 8 + o;
+    const int c = c0 + (o & 3), which = o >> 2;
     double acc = 0.0;
-    if (i < 2 * C)
-        for (int b = seg; b < nblk; b += 32) acc += (double)part[(long)b * 2 * C + i];
+    if (c < C)
+        for (int b = seg; b < nblk; b += 32) acc += (double)part[((long)b * 2 + which) * C + c];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s >= 8; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x < 8 && i < 2 * C) sums[i] = red[threadIdx.x];
 }
 
 // part[block][0][C] = sum x, part[block][1][C] = sum x^2 over the block's rows
@@ -190,15 +188,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
     bn_block_reduce<L>(s, ss, red, cv, mine, mine + C, cx * L);
 }
 
-// training: mean / invstd from the sums, running statistics (momentum, unbiased variance); one thread per channel
-__global__ void bn_finalize_kernel(const double *__restrict__ sums, long M, int C, float eps, float momentum,
-                                   float *__restrict__ save_mean, float *__restrict__ save_invstd,
-                                   float *__restrict__ running_mean, float *__restrict__ running_var)
+// training: mean / invstd from the blocks' partial sums, running statistics (momentum, unbiased variance); 4 channels per block
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, float eps,
+                                                          float momentum, float *__restrict__ save_mean,
+                                                          float *__restrict__ save_invstd, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = sums[c] / (double)M;
-    double var = sums[C + c] / (double)M - mean * mean;
+    __shared__ double red[256];
+    bn_sum_partials4(part, nblk, C, blockIdx.x * 4, red);
+    const int c = blockIdx.x * 4 + threadIdx.x;
+    if (threadIdx.x >= 4 || c >= C) return;
+    const double mean = red[threadIdx.x] / (double)M;
+    double var = red[4 + threadIdx.x] / (double)M - mean * mean;
     if (var < 0) var = 0;
     save_mean[c] = (float)mean;
     save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -297,14 +298,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
 
 // coefficients of dx = a * (g - b - (x - mean) * k): coef[0..3][C] = a = gamma*invstd, b = dbeta/M, mean, k = invstd*dgamma/M ;
 // coef[4..5][C] = invstd, beta (for the mask recomputation)
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ sums, long M, int C, const float *__restrict__ gamma,
-                                       const float *__restrict__ mean, const float *__restrict__ invstd,
-                                       const float *__restrict__ beta, float *__restrict__ coef, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C,
+                                                              const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd, const float *__restrict__ beta,
+                                                              float *__restrict__ coef, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double db = sums[c], dg = sums[C + c];
+    __shared__ double red[256];
+    bn_sum_partials4(part, nblk, C, blockIdx.x * 4, red);
+    const int c = blockIdx.x * 4 + threadIdx.x;
+    if (threadIdx.x >= 4 || c >= C) return;
+    const double db = red[threadIdx.x], dg = red[4 + threadIdx.x];
     dbeta[c] = (float)db;
     dgamma[c] = (float)dg;
     coef[c] = gamma[c] * invstd[c];
@@ -434,8 +438,7 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
     float *part = (float *)(sums_ws + 2 * C);
     NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
-    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st, part, (int)nblk, C, sums_ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, (long)M, C, eps, momentum, save_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
               (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu);
@@ -465,8 +468,7 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
     float *part = (float *)(sums_ws + 2 * C);
     NN_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (const char *)dy, (const char *)y_or_null,
               (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, mask_from_x, part);
-    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 7) / 8), dim3(256), 0, st, part, (int)nblk, C, sums_ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, (long)M, C, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
               (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x);
