@@ -43,16 +43,21 @@ int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const float *shi
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 
+/* drop_p > 0 fuses the dropout that follows the ReLU in the upstream residual block (models/resnet.py:78): an element is kept
+ * when a counter-based hash of (its index, drop_seed) says so and scaled by 1/(1-p), p quantised to 1/65536; the backward takes
+ * the same (drop_p, drop_seed) and regenerates the mask, so none is stored.  M*C must be below 2^32. */
 int salsa_nn_bn_supported(int dtype, int64_t M, int C);
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C); /* size of sums_ws (8-byte aligned) */
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                          float *save_mean, float *save_invstd, double *sums_ws, int relu, void *hip_stream);
+                          float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                          void *hip_stream);
 int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                          const float *beta, const float *mean, const float *invstd, int relu, void *hip_stream);
 int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *dx, void *dres_or_null, int dtype, int64_t M,
                     int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream);
+                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, float drop_p, uint32_t drop_seed,
+                    void *hip_stream);
 
 #ifdef __cplusplus
 }

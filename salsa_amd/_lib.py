@@ -75,9 +75,10 @@ def load():
     L.salsa_nn_bn_workspace_bytes.restype = C.c_size_t
     L.salsa_nn_bn_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int]
     L.salsa_nn_bn_train_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp,
-                                        vp, C.c_int, vp]
+                                        vp, C.c_int, C.c_float, C.c_uint32, vp]
     L.salsa_nn_bn_eval_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, C.c_int, vp]
-    L.salsa_nn_bn_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]
+    L.salsa_nn_bn_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp,
+                                  C.c_float, C.c_uint32, vp]
     L.salsa_scaler_accumulate.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp]
     L.salsa_normalize_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp]
     L.salsa_augment_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]

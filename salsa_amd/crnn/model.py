@@ -51,7 +51,7 @@ class ResBlock(nn.Module):
 
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.stride = stride
+        self.stride, self.dropout_p = stride, 0.1
         self.conv1, self.bn1 = _conv(cin, cout, 3), BatchNormAct2d(cout)
         self.conv2, self.bn2 = _conv(cout, cout, 3), BatchNormAct2d(cout)
         nn.init.zeros_(self.bn2.weight)
@@ -61,8 +61,7 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         y = avg_pool2x2(x) if self.stride == 2 else x
-        out = conv_bn_act(self.conv1, self.bn1, y)
-        out = F.dropout(out, p=0.1, training=self.training)
+        out = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p)   # dropout(relu(bn1(conv1(y)))), training only
         if self.short_conv is not None:
             x = self.short_bn(self.short_conv(y))
         return conv_bn_act(self.conv2, self.bn2, out, residual=x)          # relu(bn2(conv2(out)) + shortcut)

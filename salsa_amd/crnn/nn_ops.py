@@ -58,25 +58,27 @@ def _ptr(t):
 
 
 class _BnAct(torch.autograd.Function):
-    """y = [relu]( batch_norm(x) [+ residual] ) in training mode (salsa_nn_bn_train_fwd / salsa_nn_bn_bwd)."""
+    """y = [dropout]( [relu]( batch_norm(x) [+ residual] ) ) in training mode (salsa_nn_bn_train_fwd / salsa_nn_bn_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, drop_p=0.0):
         N, Cn, H, W = x.shape
         M = N * H * W
         y = torch.empty_like(x, memory_format=torch.channels_last)
         save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        # the mask seed comes from torch's CPU generator (torch.manual_seed makes it reproducible; no device sync)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0
         with torch.cuda.device(x.device):
             rc = _lib.load().salsa_nn_bn_train_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight),
                                                    _ptr(bias), float(eps), float(momentum), _ptr(running_mean),
                                                    _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu),
-                                                   _stream(x))
+                                                   float(drop_p), seed, _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
         # the ReLU mask comes from y only when something was added before the ReLU; otherwise the backward recomputes it from x
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, save)
-        ctx.has_residual, ctx.relu = residual is not None, bool(relu)
+        ctx.has_residual, ctx.relu, ctx.drop = residual is not None, bool(relu), (float(drop_p), seed)
         return y
 
     @staticmethod
@@ -92,18 +94,21 @@ class _BnAct(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = _lib.load().salsa_nn_bn_bwd(_ptr(gy), _ptr(y), _ptr(x), _ptr(dx), _ptr(dres), _DT[x.dtype][0], N * H * W, Cn,
                                              _ptr(weight), _ptr(bias), _ptr(save[0]), _ptr(save[1]), int(ctx.relu), _ptr(dwb[0]),
-                                             _ptr(dwb[1]), _ptr(ws), _ptr(coef), _stream(x))
+                                             _ptr(dwb[1]), _ptr(ws), _ptr(coef), ctx.drop[0], ctx.drop[1], _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
     """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose forward can take the residual add and the ReLU
-    that follow it in the upstream blocks: ``bn(x, residual=None, relu=False)``.  Channels-last CUDA bf16 / float32
-    inputs run the fused HIP kernels; anything else runs torch's batch_norm + add + relu."""
+    that follow it in the upstream blocks, and in training the dropout behind that ReLU: ``bn(x, residual=None, relu=False,
+    dropout_p=0.0)``.  Channels-last CUDA bf16 / float32 inputs run the fused HIP kernels; anything else runs torch's
+    batch_norm + add + relu + dropout."""
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, dropout_p=0.0):
+        if not self.training:
+            dropout_p = 0.0
         fused = (USE_HIP_BN and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine and self.track_running_stats
                  and self.momentum is not None and x.is_contiguous(memory_format=torch.channels_last)
                  and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
@@ -114,11 +119,12 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             y = super().forward(x)
             if residual is not None:
                 y = y + residual
-            return F.relu(y, inplace=True) if relu else y
+            y = F.relu(y, inplace=True) if relu else y
+            return F.dropout(y, p=dropout_p, training=True) if dropout_p > 0 else y
         w, b = self.weight.float(), self.bias.float()
         if self.training:
             self.num_batches_tracked.add_(1)
-            return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu)
+            return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu, float(dropout_p))
         N, Cn, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
         invstd = torch.rsqrt(self.running_var + self.eps)
@@ -186,8 +192,8 @@ class Conv3x3(torch.nn.Conv2d):
         return super().forward(x)
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True):
-    """relu(bn(conv(x)) + residual) of the reference blocks.  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
+def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0):
+    """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
     residual add and the ReLU -- before its single rounding: the normalised activation never makes a round trip to HBM.
     Every other case is conv -> BatchNormAct2d."""
@@ -207,4 +213,4 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True):
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_c64_bias_act failed (%d)' % rc)
         return y
-    return bn(conv(x), residual=residual, relu=relu)
+    return bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)

@@ -213,12 +213,40 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
 // y = [relu]( ((x - mean) * invstd) * gamma + beta [+ residual] ).  Same thread geometry as the reductions: a thread keeps
 // its column group's constants in registers and walks BN_APPLY_ROWS rows (one thread per vector would re-load 4 x L
 // constants for every 16 bytes of payload and become instruction-bound).
+// Dropout fused behind the ReLU: a counter-based hash of the element index decides what is kept, so the backward regenerates
+// the mask instead of reading one.  One 32-bit hash serves two neighbouring elements (16 bits each).
+struct DropArgs {
+    unsigned thresh; // drop when the element's 16 bits < thresh ; 0 = no dropout
+    unsigned seed;
+    float scale;     // 65536 / (65536 - thresh)
+};
+__device__ inline unsigned drop_hash(unsigned pair, unsigned seed)
+{
+    unsigned h = pair * 0x9E3779B1u + seed;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+template <int L> __device__ inline void drop_keep(long first_elem, DropArgs d, bool keep[L])
+{
+#pragma unroll
+    for (int k = 0; k < L; k += 2) {
+        const unsigned h = drop_hash((unsigned)(first_elem >> 1) + k / 2, d.seed);
+        keep[k] = (h & 0xFFFFu) >= d.thresh;
+        keep[k + 1] = (h >> 16) >= d.thresh;
+    }
+}
+
 constexpr int BN_APPLY_ROWS = 16;
 template <typename V, int L>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ x, char *__restrict__ y,
                                                        const char *__restrict__ residual, long M, int C,
                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu)
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                                       DropArgs drop)
 {
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
@@ -245,6 +273,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
             if (residual) o += rs[k];
             v[k] = relu ? fmaxf(o, 0.f) : o;
         }
+        if (drop.thresh) {
+            bool keep[L];
+            drop_keep<L>((r * cv + cx) * L, drop, keep);
+#pragma unroll
+            for (int k = 0; k < L; k++) v[k] = keep[k] ? v[k] * drop.scale : 0.f;
+        }
         vec_io<V, L>::store(y + off, v);
     }
 }
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                                                             const char *__restrict__ x, long M, int C,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            int mask_from_x, float *__restrict__ part)
+                                                            int mask_from_x, DropArgs drop, float *__restrict__ part)
 {
     __shared__ float red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
@@ -279,6 +313,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                 vec_io<V, L>::load(dy + (r * cv + cx) * 16, g);
                 vec_io<V, L>::load(x + (r * cv + cx) * 16, xv);
                 if (y) vec_io<V, L>::load(y + (r * cv + cx) * 16, yv);
+                if (drop.thresh) { // a stored y already holds the dropped zeros; otherwise the mask is regenerated
+                    bool keep[L];
+                    if (!y) drop_keep<L>((r * cv + cx) * L, drop, keep);
+#pragma unroll
+                    for (int k = 0; k < L; k++) g[k] = (y || keep[k]) ? g[k] * drop.scale : 0.f;
+                }
 #pragma unroll
                 for (int k = 0; k < L; k++) {
                     const float xh = (xv[k] - mu[k]) * is[k];
@@ -324,7 +364,7 @@ template <typename V, int L>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                            const char *__restrict__ x, char *__restrict__ dx,
                                                            char *__restrict__ dres, long M, int C,
-                                                           const float *__restrict__ coef, int mask_from_x)
+                                                           const float *__restrict__ coef, int mask_from_x, DropArgs drop)
 {
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
@@ -350,6 +390,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         vec_io<V, L>::load(dy + off, g);
         vec_io<V, L>::load(x + off, xv);
         if (y) vec_io<V, L>::load(y + off, yv);
+        if (drop.thresh) {
+            bool keep[L];
+            if (!y) drop_keep<L>((r * cv + cx) * L, drop, keep);
+#pragma unroll
+            for (int k = 0; k < L; k++) g[k] = (y || keep[k]) ? g[k] * drop.scale : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < L; k++) {
             const float xc = xv[k] - mu[k];
@@ -421,6 +467,17 @@ static unsigned bn_apply_blocks(int dtype, int64_t M, int C)
         else hipLaunchKernelGGL((KERNEL<f32x4, 4>), grid, block, 0, st, __VA_ARGS__);                      \
     } while (0)
 
+static DropArgs drop_args(float p, unsigned seed)
+{
+    DropArgs d = {0u, seed, 1.f};
+    if (p > 0.f) {
+        d.thresh = (unsigned)(p * 65536.f + 0.5f);
+        if (d.thresh > 65535u) d.thresh = 65535u;
+        d.scale = 65536.f / (float)(65536u - d.thresh);
+    }
+    return d;
+}
+
 int salsa_nn_bn_supported(int dtype, int64_t M, int C) { return bn_geometry_ok(dtype, M, C); }
 /* bytes of the sums_ws scratch: 2*C float64 sums + one float32 partial pair per reduction block */
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
@@ -431,9 +488,12 @@ size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
 
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                          float *save_mean, float *save_invstd, double *sums_ws, int relu, void *hip_stream)
+                          float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                          void *hip_stream)
 {
-    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C)) return -1;
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C) || drop_p < 0.f ||
+        drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32))
+        return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
     float *part = (float *)(sums_ws + 2 * C);
@@ -441,7 +501,7 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
-              (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu);
+              (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed));
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -451,15 +511,17 @@ int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype
     if (!x || !y || !gamma || !beta || !mean || !invstd || !bn_geometry_ok(dtype, M, C)) return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
-              (const char *)residual, (long)M, C, mean, invstd, gamma, beta, relu);
+              (const char *)residual, (long)M, C, mean, invstd, gamma, beta, relu, drop_args(0.f, 0u));
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
 int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *dx, void *dres_or_null, int dtype, int64_t M,
                     int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
+                    float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, float drop_p, uint32_t drop_seed, void *hip_stream)
 {
     const int mask_from_x = relu && !y_or_null;
+    const DropArgs drop = drop_args(drop_p, drop_seed);
+    if (drop_p < 0.f || drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32)) return -1;
     if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
         !bn_geometry_ok(dtype, M, C))
         return -1;
@@ -467,11 +529,11 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
     float *part = (float *)(sums_ws + 2 * C);
     NN_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (const char *)dy, (const char *)y_or_null,
-              (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, mask_from_x, part);
+              (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, mask_from_x, drop, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
-              (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x);
+              (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x, drop);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -143,6 +143,68 @@ def test_fused_batchnorm_add_relu_matches_torch(dtype):
         torch.testing.assert_close(ya.float(), yb, **out_tol)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_batchnorm_relu_dropout(dtype):
+    """The dropout fused behind BatchNorm + ReLU (salsa_nn_bn_train_fwd drop_p): every output is either dropped or the
+    undropped output / (1 - p); the drop rate is p; the same seed gives the same mask; the backward -- which regenerates the
+    mask from the seed -- matches autograd through batch_norm + relu + (that mask); eval mode drops nothing."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import BatchNormAct2d
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(5)
+    p = 0.1
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    for (n, c, h, w), use_res in (((8, 64, 40, 25), False), ((4, 128, 20, 13), True)):
+        fus, ref = BatchNormAct2d(c).to(dev), nn.BatchNorm2d(c).to(dev)
+        with torch.no_grad():
+            fus.weight.copy_(torch.rand(c, device=dev, generator=g) + 0.5)
+            fus.bias.copy_(torch.rand(c, device=dev, generator=g) + 0.5)          # most pre-activations positive
+        ref.load_state_dict(fus.state_dict())
+        x = torch.randn((n, c, h, w), device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+        r = torch.randn((n, c, h, w), device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last) if use_res else None
+        xa = x.clone().requires_grad_(True)
+        ra = r.clone().requires_grad_(True) if use_res else None
+        torch.manual_seed(11)
+        ya = fus(xa, residual=ra, relu=True, dropout_p=p)
+        with torch.no_grad():
+            stats = {k: v.clone() for k, v in fus.named_buffers()}                 # (weights are saved for the backward)
+            plain = fus(x, residual=r, relu=True).float()                          # same batch statistics, no dropout
+            torch.manual_seed(11)
+            again = fus(x, residual=r, relu=True, dropout_p=p)
+            for k, v in fus.named_buffers():
+                v.copy_(stats[k])
+        assert torch.equal(ya, again)                                              # the seed decides the mask
+        scale = 65536.0 / (65536 - round(p * 65536))
+        live = plain > 0
+        kept = (ya != 0) & live
+        torch.testing.assert_close(ya.float()[kept], (plain * scale)[kept], rtol=2.0 ** -7 if dtype == torch.bfloat16 else 1e-5, atol=1e-6)
+        assert bool((ya[~live] == 0).all())
+        rate = 1.0 - kept.sum().item() / live.sum().item()
+        assert abs(rate - p) < 4 * (p * (1 - p) / live.sum().item()) ** 0.5 + 1e-4, rate
+        # no structure along channels or rows: the per-channel and per-row drop rates stay near p as well
+        n_live = live.sum((0, 2, 3)).float().clamp_min(1)
+        per_c = 1.0 - kept.sum((0, 2, 3)).float() / n_live
+        assert bool(((per_c - p).abs() < 5 * (p * (1 - p) / n_live).sqrt()).all())
+        # backward against autograd with the observed mask as a constant
+        mask = ((ya != 0) | ~live).float()
+        xb = x.float().clone().requires_grad_(True)
+        rb = r.float().clone().requires_grad_(True) if use_res else None
+        yb = ref(xb)
+        yb = F.relu(yb + rb if use_res else yb) * mask * scale
+        gy = torch.randn(ya.shape, device=dev, generator=g).to(dtype)
+        ya.backward(gy)
+        yb.backward(gy.float())
+        torch.testing.assert_close(xa.grad.float(), xb.grad, **tol)
+        torch.testing.assert_close(fus.weight.grad, ref.weight.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+        torch.testing.assert_close(fus.bias.grad, ref.bias.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+        if use_res:
+            torch.testing.assert_close(ra.grad.float(), rb.grad, **tol)
+        fus.eval()
+        with torch.no_grad():
+            assert torch.equal(fus(x, residual=r, relu=True, dropout_p=p), fus(x, residual=r, relu=True))
+
+
 def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
     """salsa_nn_conv3x3_c64 (64 -> 64, bf16 in / f32 accumulate / bf16 out) against F.conv2d: output, data gradient (the same
     kernel with the flipped, transposed filter) and weight gradient (salsa_nn_conv3x3_c64_wrw, transposing LDS reads), incl.
@@ -193,6 +255,8 @@ def test_whole_model_hip_layers_on_vs_off():
             mod.p = 0.0
         if isinstance(mod, torch.nn.GRU):
             mod.dropout = 0.0
+        if isinstance(mod, M.ResBlock):
+            mod.dropout_p = 0.0
     real_dropout = M.F.dropout
     M.F.dropout = lambda t, p=0.5, training=True, inplace=False: t
     x, sed, doa = synthetic_batch(4, dev, seed=3)
