@@ -8,8 +8,9 @@
 //                       complex64 STFT) to the workspace as Xs[b][t][channel pair][bin] (float4).
 //   K2 tracker_kernel   one lane per (clip, bin): 3-frame RMS of channel 0 and the sequential noise-floor tracker
 //                       in float64 -> valid[b][64-frame chunk][bin] (64-bit indicator history per bin).
-//   K3 cov_eig_kernel   per tile of 8 frames x 256 bins the gated (frame, bin) pairs are compacted into an LDS work list; one lane
-//                       per listed pair: 7-frame Hermitian covariance accumulated in registers, eigen-gate + principal
+//   K3 cov_eig_kernel   per tile of 8 frames x 256 bins the gated TF bins are compacted into an LDS work list (an item = two
+//                       neighbouring frames of one bin, at least one gated in: their 7-frame windows share 6 frames);
+//                       one lane per item: Hermitian covariances accumulated in registers, eigen-gate + principal
 //                       eigenvector (salsa_math.h), FOA / MIC normalisation, writes channels 4-6 (zeros where gated).
 // Further entry points: salsa_eigvec_batch (K2 + K3 on caller-supplied spectra), salsa_logspec_batch (K1 only), the scaler /
 // normalise kernels, the contrib-surface variants (SALSA_FLAG_FLEX), salsa_to_freq_major, salsa_augment_batch.
@@ -487,6 +488,9 @@ static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.
 #define K3_FT_N 8 // measured 2/4/8/16/32/64: 8 is fastest (tiles in bursts do ~10x the work of quiet ones: small tiles balance)
 #endif
 constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gate words sit in one chunk
+#ifndef K3_GROUP
+#define K3_GROUP 2
+#endif
 
 template <bool FEAT, int NHOP>
 __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
@@ -494,6 +498,9 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
 {
+    constexpr int G = NHOP >= 0 ? K3_GROUP : 1; // frames per work item (compile-time window only)
+    constexpr bool PAIRED = G > 1;
+    static_assert(K3_FT % G == 0 && G <= 4 && K3_FT / G <= 16, "work-list entry layout");
     __shared__ unsigned short list[K3_FT * 256];
     __shared__ int count;
     const int tid = threadIdx.x;
@@ -539,21 +546,33 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         unsigned long long words[K3_FT];
         int total = 0;
 #pragma unroll
-        for (int ft = 0; ft < K3_FT; ft++) {
+        for (int ft = 0; ft < K3_FT; ft++)
             words[ft] = ft < nft ? __ballot(in && ((mine >> (sh + ft)) & 1)) : 0ull; // back to a mask over the wave's bins
-            total += __popcll(words[ft]);
-        }
+        // A work item is a GROUP of G neighbouring frames of one bin with at least one of them gated in.
+        auto any_of = [&](int ft) {
+            unsigned long long wd = 0ull;
+#pragma unroll
+            for (int j = 0; j < G; j++) wd |= words[ft + j];
+            return wd;
+        };
+#pragma unroll
+        for (int ft = 0; ft < K3_FT; ft += G) total += __popcll(any_of(ft));
         int base = 0;
         if (lane == 0 && total) base = atomicAdd(&count, total);
         base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-        for (int ft = 0; ft < K3_FT; ft++) {
-            if (ft < nft && in) {
-                const unsigned long long wd = words[ft];
-                if ((wd >> lane) & 1) list[base + __popcll(wd & ((1ull << lane) - 1))] = (unsigned short)(ft * 256 + bl);
-                else emit(t0 + ft, bin, zero3, 0);
+        for (int ft = 0; ft < K3_FT; ft += G) {
+            const unsigned long long wd = any_of(ft);
+            if (in) {
+                unsigned v = 0; // which frames of the group are gated in
+#pragma unroll
+                for (int j = 0; j < G; j++) v |= ((unsigned)(words[ft + j] >> lane) & 1u) << j;
+                if (v) list[base + __popcll(wd & ((1ull << lane) - 1))] = (unsigned short)((v << 12) | ((ft / G) << 8) | bl);
+#pragma unroll
+                for (int j = 0; j < G; j++)
+                    if (ft + j < nft && !((v >> j) & 1)) emit(t0 + ft + j, bin, zero3, 0);
             }
-            base += __popcll(words[ft]);
+            base += __popcll(wd);
         }
     }
     if (FEAT && blockIdx.z == gridDim.z - 1) { // zero the feature bins above the DOA band (:373-374)
@@ -569,45 +588,9 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     const int stride = 2 * kp.nd;
     const int nhop = NHOP >= 0 ? NHOP : kp.n_hop;
     const float4 *xclip = Xs + (long)b * Tn * stride;
-    for (int s = tid; s < n; s += 256) {
-        const int i = list[s];
-        const int t = t0 + (i >> 8);
-        const int bin = bin0 + (i & 255);
-        salsa::herm4<double> R = {};
-        const float4 *xb = xclip + bin;
-        const unsigned row = 16u * (unsigned)stride, boff = 16u * (unsigned)bin, half = 16u * (unsigned)kp.nd; // bytes
-        if (NHOP >= 0) {
-            // all 2*NHOP+1 frames as independent 16-B loads issued together (splitting them into batches to save VGPRs
-            // was measured slower: the loads' latency is what this kernel hides)
-            constexpr int NW = NHOP >= 0 ? 2 * NHOP + 1 : 1;
-            float4 xa[NW], xc[NW];
-#pragma unroll
-            for (int k = 0; k < NW; k++) {
-                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
-                while (tt < 0) tt += Tn;
-                while (tt >= Tn) tt -= Tn;
-                xa[k] = ld_off(xclip, (unsigned)tt * row + boff);
-                xc[k] = ld_off(xclip, (unsigned)tt * row + boff + half);
-            }
-#pragma unroll
-            for (int k = 0; k < NW; k++) {
-                const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
-                                           {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
-                salsa::herm4_rank1_add(R, x);
-            }
-        } else {
-            for (int k = -nhop; k <= nhop; k++) {
-                int tt = t + k;
-                while (tt < 0) tt += Tn;
-                while (tt >= Tn) tt -= Tn;
-                const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
-                const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
-                                           {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
-                salsa::herm4_rank1_add(R, x);
-            }
-        }
-        // :111-112 the coherence test only gates when tracking -- except in contrib, whose test always gates (:352-354)
-        const bool ungated = !kp.tracking && !kp.flex;
+    // :111-112 the coherence test only gates when tracking -- except in contrib, whose test always gates (:352-354)
+    const bool ungated = !kp.tracking && !kp.flex;
+    auto solve_emit = [&](const salsa::herm4<double> &R, int t, int bin) {
         const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, ungated);
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
@@ -622,6 +605,60 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
             e[0] = __builtin_nan(""); // marks "failed the test" for flex_allpass_kernel (a passing bin can be exactly 0)
         }
         emit(t, bin, e, g);
+    };
+    for (int s = tid; s < n; s += 256) {
+        const int i = list[s];
+        const int t = t0 + G * ((i >> 8) & 15); // entry = validity of the group's frames << 12 | group << 8 | bin
+        const int bin = bin0 + (i & 255);
+        const float4 *xb = xclip + bin;
+        const unsigned row = 16u * (unsigned)stride, boff = 16u * (unsigned)bin, half = 16u * (unsigned)kp.nd; // bytes
+        if (PAIRED) {
+            // frames t-NHOP .. t+1+NHOP as independent 16-B loads issued together: the two windows share 2*NHOP frames, so a
+            // pair costs 2*NHOP+2 gathers instead of 2*(2*NHOP+1) (the gate mask is bursty in time: 1.8 of 2 frames of a
+            // listed pair are gated in on the bench clips).  Splitting the loads into batches to save VGPRs was measured
+            // slower: their latency is what this kernel hides.
+            constexpr int NW = NHOP >= 0 ? 2 * NHOP + G : G;
+            float4 xa[NW], xc[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                xa[k] = ld_off(xclip, (unsigned)tt * row + boff);
+                xc[k] = ld_off(xclip, (unsigned)tt * row + boff + half);
+            }
+            auto frame = [&](int k, salsa::herm4<double> &A) {
+                const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
+                                           {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
+                salsa::herm4_rank1_add(A, x);
+            };
+            salsa::herm4<double> Rc = {}; // the frames every window of the group contains
+#pragma unroll
+            for (int k = G - 1; k <= 2 * NHOP; k++) frame(k, Rc);
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if ((i >> (12 + j)) & 1) {
+                    salsa::herm4<double> R = Rc;
+#pragma unroll
+                    for (int k = j; k < G - 1; k++) frame(k, R);
+#pragma unroll
+                    for (int k = 2 * NHOP + 1; k <= 2 * NHOP + j; k++) frame(k, R);
+                    solve_emit(R, t + j, bin);
+                }
+            }
+        } else {
+            salsa::herm4<double> R = {};
+            for (int k = -nhop; k <= nhop; k++) {
+                int tt = t + k;
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
+                const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
+                                           {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
+                salsa::herm4_rank1_add(R, x);
+            }
+            solve_emit(R, t, bin);
+        }
     }
 }
 
