@@ -111,12 +111,14 @@ __global__ __launch_bounds__(H) void gru_bwd_kernel(const float *__restrict__ dh
 // (300 label-rate frames) the streaming kernel above spends ~10 us per step pulling 768 KB of weights through L2 into one
 // CU: 39 % of an inference sub-batch.  A 1024-thread workgroup's register file holds 512 KB, enough for the direction's
 // 3H x H matrix as float16 (384 KB): thread (q, part) keeps, for hidden unit q, the three gate rows' columns
-// part*64 .. +63 (192 weights = 96 registers), multiplies them with its 64-element slice of h (LDS, float32), and a
-// 4-lane butterfly completes the three dot products, so lane part 0 of every group has r, z, n of ITS unit.  float32 h,
-// gates and accumulation (v_fma_mix_f32 reads the float16 operand directly); only the recurrent weights are rounded, to
-// float16 (11 significant bits, finer than the bf16 that autocast would give an nn.GRU) -- used without gradients
-// (inference) and for training under bf16 autocast, with gru_bwd_regw_kernel differentiating the SAME rounded weights;
-// float32 training keeps the float32 kernels above.  One barrier per step (h is double-buffered).
+// part*64 .. +63 (192 weights = 96 registers), multiplies them with its 64-element slice of h (LDS, float16 copy: 8 reads
+// of 16 B) with v_dot2_f32_f16 -- two multiply-adds per instruction, float32 accumulation -- and a 4-lane butterfly
+// completes the three dot products, so lane part 0 of every group has r, z, n of ITS unit.  Gates, the carried h of each
+// unit (z * h), the outputs and the accumulation stay float32; only the matrix-vector operands are rounded, to float16
+// (11 significant bits, finer than the bf16 that autocast would give an nn.GRU) -- used without gradients (inference)
+// and for training under bf16 autocast, with gru_bwd_regw_kernel differentiating the SAME rounded weights; float32
+// training keeps the float32 kernels above.  One barrier per step (h is double-buffered); nothing but the weights lives
+// in registers across steps (biases are re-read with the step's input projections: kept, they were spilled).
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 template <int H>
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
 {
     static_assert(H == 256, "1024 threads = 256 units x 4 column slices");
     constexpr int KS = H / 4; // columns per thread
-    __shared__ __attribute__((aligned(16))) float h[2][H];
+    __shared__ __attribute__((aligned(16))) _Float16 h[2][H]; // the matrix-vector operand; each unit's own h stays float32 (hq)
     const int q = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int b = blockIdx.x, d = blockIdx.y;
     half2_t wp[3][KS / 2];
@@ -136,35 +138,42 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < KS / 2; i++) wp[g][i] = half2_t{(_Float16)row[2 * i], (_Float16)row[2 * i + 1]};
     }
-    const float br = bhh[d * 3 * H + q], bz = bhh[d * 3 * H + H + q], bn = bhh[d * 3 * H + 2 * H + q];
-    if (threadIdx.x < H) h[0][threadIdx.x] = 0.f;
+    if (threadIdx.x < H) h[0][threadIdx.x] = (_Float16)0.f;
     float hq = 0.f;
     __syncthreads();
     for (int s = 0; s < T; s++) {
         const int t = d == 0 ? s : T - 1 - s;
         const long base = ((long)t * B + b) * D + d;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, br = 0.f, bz = 0.f, bn = 0.f;
         if (part == 0) { // this step's input projections, in flight during the dot products
             const float *g = gi + base * 3 * H;
             g0 = g[q];
             g1 = g[H + q];
             g2 = g[2 * H + q];
+            // the biases too: 96 of the 128 registers hold weights, so values kept across steps were being spilled and
+            // reloaded from scratch one by one in the middle of the gate math; re-read (L1 hits) they ride with the loads above
+            const float *bp = bhh + d * 3 * H + q;
+            asm volatile("" : "+v"(bp)); // (not loop-invariant as far as the compiler can tell)
+            br = bp[0];
+            bz = bp[H];
+            bn = bp[2 * H];
         }
-        const float4 *hp = (const float4 *)&h[s & 1][part * KS];
+        typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2))); // the operand type of the dot-product builtin
+        const uint4 *hp = (const uint4 *)&h[s & 1][part * KS];
         float ar = 0.f, az = 0.f, an = 0.f;
 #pragma unroll
-        for (int i = 0; i < KS / 4; i++) {
-            const float4 hv = hp[i];
+        for (int i = 0; i < KS / 8; i++) {
+            const uint4 raw = hp[i]; // 8 consecutive elements of h
+            const unsigned hv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
             for (int g = 0; g < 3; g++) {
-                half2_t w01 = wp[g][2 * i], w23 = wp[g][2 * i + 1];
-                asm volatile("" : "+v"(w01), "+v"(w23)); // the half -> float conversions are loop-invariant: keep them from being
-                                                          // hoisted into 192 more registers (they fold into v_fma_mix_f32 here)
                 float acc = g == 0 ? ar : g == 1 ? az : an;
-                acc = fmaf((float)w01.x, hv.x, acc);
-                acc = fmaf((float)w01.y, hv.y, acc);
-                acc = fmaf((float)w23.x, hv.z, acc);
-                acc = fmaf((float)w23.y, hv.w, acc);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    half2_t w = wp[g][4 * i + j];
+                    asm volatile("" : "+v"(w)); // keeps each weight pair packed in its one register
+                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(fp16x2_t, w), __builtin_bit_cast(fp16x2_t, hv[j]), acc, false); // v_dot2_f32_f16
+                }
                 if (g == 0) ar = acc;
                 else if (g == 1) az = acc;
                 else an = acc;
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
             const float n = tanhf(g2 + r * (an + bn));
             hq = (1.f - z) * n + z * hq;
             hs[base * H + q] = hq;
-            h[(s + 1) & 1][q] = hq;
+            h[(s + 1) & 1][q] = (_Float16)hq;
             if (saved) { // for the backward scan: r, z, n and W_hn h + b_hn
                 float *sv = saved + base * 4 * H;
                 sv[q] = r;
