@@ -113,29 +113,34 @@ __global__ __launch_bounds__(256) void avgpool2x2_bwd_kernel(const char *__restr
 #define BN_RPT 32
 #endif
 constexpr int BN_ROWS_PER_THREAD = BN_RPT;
+#ifndef BN_BATCH_N
+#define BN_BATCH_N 4
+#endif
+constexpr int BN_BATCH = BN_BATCH_N; // rows whose loads are in flight together in the reduction kernels
+static_assert(BN_RPT % BN_BATCH_N == 0, "row batches");
 
-template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], float (&b)[L], float *red /*[256][2L]*/, int cv,
+template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], float (&b)[L], float *red /*[2L][256]*/, int cv,
                                                                   float *part_a, float *part_b, int c0)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x; // red[value][thread]: neighbouring lanes touch neighbouring banks
 #pragma unroll
     for (int k = 0; k < L; k++) {
-        red[tid * 2 * L + k] = a[k];
-        red[tid * 2 * L + L + k] = b[k];
+        red[k * 256 + tid] = a[k];
+        red[(L + k) * 256 + tid] = b[k];
     }
     __syncthreads();
     for (int s = 128; s >= cv; s >>= 1) { // threads tid and tid + s own the same column group (s is a multiple of cv)
         if (tid < s) {
 #pragma unroll
-            for (int k = 0; k < 2 * L; k++) red[tid * 2 * L + k] += red[(tid + s) * 2 * L + k];
+            for (int k = 0; k < 2 * L; k++) red[k * 256 + tid] += red[k * 256 + tid + s];
         }
         __syncthreads();
     }
     if (tid < cv) { // this block's partial sums (no atomics: thousands of blocks would serialise on 2*C addresses)
 #pragma unroll
         for (int k = 0; k < L; k++) {
-            part_a[c0 + k] = red[tid * 2 * L + k];
-            part_b[c0 + k] = red[tid * 2 * L + L + k];
+            part_a[c0 + k] = red[k * 256 + tid];
+            part_b[c0 + k] = red[(L + k) * 256 + tid];
         }
     }
 }
@@ -170,18 +175,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
 #pragma unroll
     for (int k = 0; k < L; k++) s[k] = ss[k] = 0.f;
     for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
-#pragma unroll 4
-        for (int it = 0; it < BN_ROWS_PER_THREAD; it++) {
-            const long r = row0 + (long)it * rpi + ry;
-            if (r < M) {
-                float v[L];
-                vec_io<V, L>::load(x + (r * cv + cx) * 16, v);
+        // BN_BATCH rows' loads are issued together, with no branch between them (a row past the end re-reads the last row
+        // and is weighted 0): row-at-a-time code with its bounds test waited for every load before issuing the next
+#pragma unroll 1
+        for (int it0 = 0; it0 < BN_ROWS_PER_THREAD; it0 += BN_BATCH) {
+            float v[BN_BATCH][L], wgt[BN_BATCH];
+#pragma unroll
+            for (int u = 0; u < BN_BATCH; u++) {
+                const long r = row0 + (long)(it0 + u) * rpi + ry;
+                wgt[u] = r < M ? 1.f : 0.f;
+                vec_io<V, L>::load(x + ((r < M ? r : M - 1) * cv + cx) * 16, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_BATCH; u++)
 #pragma unroll
                 for (int k = 0; k < L; k++) {
-                    s[k] += v[k];
-                    ss[k] += v[k] * v[k];
+                    const float vk = v[u][k] * wgt[u];
+                    s[k] += vk;
+                    ss[k] += vk * vk;
                 }
-            }
         }
     }
     float *mine = part + (long)blockIdx.x * 2 * C;
@@ -284,12 +296,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
 }
 
 // g = dy * (y > 0) ; sums[0][C] += sum g (= dbeta) ; sums[1][C] += sum g * xhat (= dgamma)
-template <typename V, int L>
+// MASK: 0 no ReLU, 1 ReLU mask from the stored output y, 2 recomputed from x; DROP: fused dropout (compile-time, so the
+// element loop has no branches)
+template <typename V, int L, int MASK, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                             const char *__restrict__ x, long M, int C,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            int mask_from_x, DropArgs drop, float *__restrict__ part)
+                                                            DropArgs drop, float *__restrict__ part)
 {
     __shared__ float red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
@@ -305,27 +319,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
         be[k] = beta[cx * L + k];
     }
     for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
-#pragma unroll 4
-        for (int it = 0; it < BN_ROWS_PER_THREAD; it++) {
-            const long r = row0 + (long)it * rpi + ry;
-            if (r < M) {
-                float g[L], xv[L], yv[L];
-                vec_io<V, L>::load(dy + (r * cv + cx) * 16, g);
-                vec_io<V, L>::load(x + (r * cv + cx) * 16, xv);
-                if (y) vec_io<V, L>::load(y + (r * cv + cx) * 16, yv);
-                if (drop.thresh) { // a stored y already holds the dropped zeros; otherwise the mask is regenerated
-                    bool keep[L];
-                    if (!y) drop_keep<L>((r * cv + cx) * L, drop, keep);
+#pragma unroll 1
+        for (int it0 = 0; it0 < BN_ROWS_PER_THREAD; it0 += BN_BATCH) {
+            float g[BN_BATCH][L], xv[BN_BATCH][L], yv[BN_BATCH][L];
+            long vec[BN_BATCH];
+            bool ok[BN_BATCH];
 #pragma unroll
-                    for (int k = 0; k < L; k++) g[k] = (y || keep[k]) ? g[k] * drop.scale : 0.f;
-                }
+            for (int u = 0; u < BN_BATCH; u++) { // all of the batch's loads first (see bn_stats_kernel)
+                const long r = row0 + (long)(it0 + u) * rpi + ry;
+                ok[u] = r < M;
+                vec[u] = (ok[u] ? r : M - 1) * cv + cx;
+                vec_io<V, L>::load(dy + vec[u] * 16, g[u]);
+                vec_io<V, L>::load(x + vec[u] * 16, xv[u]);
+                if (MASK == 1) vec_io<V, L>::load(y + vec[u] * 16, yv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_BATCH; u++) {
+                bool keep[L];
+                if (DROP && MASK != 1) drop_keep<L>(vec[u] * L, drop, keep); // a stored y already holds the dropped zeros
 #pragma unroll
                 for (int k = 0; k < L; k++) {
-                    const float xh = (xv[k] - mu[k]) * is[k];
+                    const float xh = (xv[u][k] - mu[k]) * is[k];
                     // ReLU mask: from the stored output, or -- when nothing was added before the ReLU -- recomputed from x
                     // (the sign of the float32 pre-activation survives its rounding to the stored dtype), saving y's read
-                    const bool off = y ? !(yv[k] > 0.f) : (mask_from_x && !(xh * ga[k] + be[k] > 0.f));
-                    const float gk = off ? 0.f : g[k];
+                    bool live = ok[u];
+                    if (MASK == 1) live = live && yv[u][k] > 0.f;
+                    if (MASK == 2) live = live && xh * ga[k] + be[k] > 0.f;
+                    if (DROP && MASK != 1) live = live && keep[k];
+                    const float gk = live ? (DROP ? g[u][k] * drop.scale : g[u][k]) : 0.f;
                     db[k] += gk;
                     dg[k] += gk * xh;
                 }
@@ -528,8 +549,28 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
     float *part = (float *)(sums_ws + 2 * C);
-    NN_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (const char *)dy, (const char *)y_or_null,
-              (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, mask_from_x, drop, part);
+#define BN_REDUCE(MASK, DROP)                                                                                                   \
+    do {                                                                                                                        \
+        if (dtype == 1)                                                                                                         \
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16x8, 8, MASK, DROP>), dim3(nblk), dim3(256), 0, st, (const char *)dy,   \
+                               (const char *)y_or_null, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, \
+                               part);                                                                                           \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<f32x4, 4, MASK, DROP>), dim3(nblk), dim3(256), 0, st, (const char *)dy,    \
+                               (const char *)y_or_null, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, \
+                               part);                                                                                           \
+    } while (0)
+    const int mask_mode = !relu ? 0 : (y_or_null ? 1 : 2);
+    if (drop.thresh) {
+        if (mask_mode == 0) BN_REDUCE(0, true);
+        else if (mask_mode == 1) BN_REDUCE(1, true);
+        else BN_REDUCE(2, true);
+    } else {
+        if (mask_mode == 0) BN_REDUCE(0, false);
+        else if (mask_mode == 1) BN_REDUCE(1, false);
+        else BN_REDUCE(2, false);
+    }
+#undef BN_REDUCE
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
