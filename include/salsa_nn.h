@@ -40,6 +40,12 @@ int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H
  * gamma / sqrt(var + eps) per output channel, shift = beta - mean * gamma / sqrt(var + eps) (float32 [64]); residual bf16 or NULL */
 int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y, int relu,
                                   int64_t N, int H, int W, void *hip_stream);
+/* the network's first layer, Cin <= 8 -> 64 channels, on the extractor's output layout: x float32 planar [N][Cin][H][W] with
+ * contiguous rows and the given batch / channel strides (elements; a time-cropped view needs no copy);
+ * wq bf16 [64 co][10 taps][8 ci] (taps row-major, tap 9 and ci >= Cin zero); y bf16 channels-last [N][H][W][64];
+ * shift NULL: plain convolution, else y = [relu](conv + shift[co]) with the BatchNorm folded as above */
+int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *wq, const float *shift,
+                          void *y, int relu, int64_t N, int Cin, int H, int W, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

@@ -174,9 +174,68 @@ class _Conv3x3C64(torch.autograd.Function):
         return gx, gw
 
 
+def _planar_rows(x):
+    """(N, C, H, W) view whose rows are contiguous and whose planes / batches do not overlap (e.g. a time crop of NCHW)."""
+    N, Cn, H, W = x.shape
+    return (x.stride(3) == 1 and x.stride(2) == W and x.stride(1) >= H * W and x.stride(0) >= Cn * x.stride(1)) or x.numel() == 0
+
+
+def _stem_filter(weight, scale=None):
+    """(64, Cin <= 8, 3, 3) -> the stem kernel's bf16 [64][10 taps][8 channels] (zero-padded), optionally scaled per output
+    channel (folded BatchNorm)."""
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale[:, None, None, None]
+    wq = torch.zeros((64, 10, 8), dtype=torch.float32, device=w.device)
+    wq[:, :9, :w.shape[1]] = w.permute(0, 2, 3, 1).reshape(64, 9, w.shape[1])
+    return wq.to(torch.bfloat16).contiguous()
+
+
+def _conv_stem(x, wq, shift=None, relu=False):
+    """salsa_nn_conv3x3_stem: x (N, Cin, H, W) float32, planar with contiguous rows -> (N, 64, H, W) bf16 channels-last."""
+    N, Cin, H, W = x.shape
+    y = torch.empty((N, 64, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_nn_conv3x3_stem(_ptr(x), x.stride(0), x.stride(1), _ptr(wq), _ptr(shift), _ptr(y), int(relu), N, Cin,
+                                               H, W, _stream(x))
+    if rc:
+        raise RuntimeError('salsa_nn_conv3x3_stem failed (%d)' % rc)
+    return y
+
+
+class _Conv3x3Stem(torch.autograd.Function):
+    """The first layer (7 -> 64) on the stem kernel; its weight gradient (the input needs none) stays with MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return _conv_stem(x, _stem_filter(weight))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('the stem convolution does not differentiate its input')
+        if ctx.needs_input_grad[1]:
+            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gw = torch.ops.aten.convolution_backward(gy.contiguous(memory_format=torch.channels_last), xb, wb, None, [1, 1], [1, 1],
+                                                     [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
+        return gx, gw
+
+
 class Conv3x3(torch.nn.Conv2d):
     """nn.Conv2d(cin, cout, 3, padding=1, bias=False) whose 64 -> 64 instances run the MFMA kernel for bf16 channels-last
-    CUDA inputs (i.e. under the trainer's autocast); everything else is F.conv2d."""
+    CUDA inputs (i.e. under the trainer's autocast) and whose (Cin <= 8) -> 64 instance -- the network's first layer -- runs
+    the stem kernel on float32 planar inputs under bf16 autocast; everything else is F.conv2d."""
+
+    def _stem_eligible(self, x):
+        return (USE_HIP_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _planar_rows(x)
+                and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+                and self.in_channels <= 8 and self.out_channels == 64 and self.kernel_size == (3, 3) and self.stride == (1, 1)
+                and self.padding == (1, 1) and self.bias is None and self.dilation == (1, 1) and self.groups == 1
+                and not x.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64)
 
     def _hip_eligible(self, x):
         bf16 = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
@@ -189,6 +248,9 @@ class Conv3x3(torch.nn.Conv2d):
         if self._hip_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
+        if self._stem_eligible(x):
+            with torch.autocast('cuda', enabled=False):
+                return _Conv3x3Stem.apply(x, self.weight)
         return super().forward(x)
 
 
@@ -213,4 +275,9 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0):
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_c64_bias_act failed (%d)' % rc)
         return y
+    if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
+            and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
+        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
+        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        return _conv_stem(x, _stem_filter(conv.weight, scale), shift, relu)
     return bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)

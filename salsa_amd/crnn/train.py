@@ -63,13 +63,23 @@ class Trainer:
         self.model = model
         self.opt = torch.optim.Adam(self.model.parameters(), lr=LRS[0])
 
+    def _input_layout(self, x):
+        """channels-last for MIOpen -- unless the first layer runs the stem kernel, which reads the extractor's planar
+        float32 layout (time crops included) as it is."""
+        from . import nn_ops
+        if not self.channels_last:
+            return x
+        if (nn_ops.USE_HIP_CONV and self.amp_dtype == torch.bfloat16 and x.dtype == torch.float32 and x.dim() == 4
+                and x.shape[1] <= 8 and nn_ops._planar_rows(x)):
+            return x
+        return x.contiguous(memory_format=torch.channels_last)
+
     def train_step(self, x, sed, doa):
         self.model.train()
         lr = lr_at(self.step_idx / max(1, self.total_steps))
         for gparam in self.opt.param_groups:
             gparam['lr'] = lr
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
+        x = self._input_layout(x)
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             pred = self.model(x)
@@ -83,8 +93,7 @@ class Trainer:
     def infer(self, x):
         """eval forward (bf16 autocast): sigmoid SED probabilities and xyz at label rate (inference path, config 5)."""
         self.model.eval()
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
+        x = self._input_layout(x)
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.raw_model(x)
         return torch.sigmoid(out['event_frame_logit'].float()), out['doa_frame_output'].float()

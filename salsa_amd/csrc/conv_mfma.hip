@@ -4,9 +4,12 @@
 //   B (16 ci x 32 pixels) = 16 contiguous bytes of the input pixel [pixel][ci..ci+7]    per lane (lane&31 = pixel)
 //   D (32 co x 32 pixels) = for ONE pixel per lane, 4 groups of 4 consecutive co        -> 8-byte bf16 stores
 // i.e. neither operand needs a transpose and the result is written pixel-major (NHWC) with vector stores.
-// A persistent workgroup (4 waves) keeps the whole filter (9 x 64 x 64 bf16) in LDS and walks output tiles of 4 rows x 32
-// columns; wave w owns row w of the tile.  LDS rows are padded 128 -> 144 bytes so the 16-byte operand reads of 32
-// consecutive pixels / filter rows spread over all banks.
+// A persistent workgroup (4 waves) walks output tiles of 4 rows x 32 pixels: wave = one half of the output channels x one
+// pair of rows, its slice of the filter (9 taps x 32 co x 64 ci bf16 = 36 fragments) held in REGISTERS for the whole launch;
+// only the input halo tile goes through LDS (rows padded 128 -> 144 bytes so the 16-byte operand reads of 32 consecutive
+// pixels spread over all banks), the next tile's loads in flight during the current tile's MFMAs.
+// Also here: the first layer's kernel (Cin <= 8 -> 64, reads the extractor's planar float32 output; "stem layer" below) and
+// the 64 -> 64 weight gradient (transposing LDS reads; "weight gradient" below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -182,6 +185,106 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// ------------------------------------------------------------------------------------------------------------ stem layer
+// The network's first convolution: Cin <= 8 feature channels (7 for SALSA) -> 64, reading the extractor's OWN output layout
+// (float32, planar [N][Cin][H][W]) -- no layout change, no cast pass.  One workgroup = one 8 x 32 pixel tile: the halo tile goes
+// to LDS as [pixel][8 channels] bf16 (16 B per pixel, channels Cin..7 zero), which makes a B fragment (one pixel, one tap, 8
+// channels = 8 consecutive K) a single ds_read_b128.  K = 10 taps x 8 (tap 9 has zero weights) = 5 MFMA steps; the filter
+// (64 x 80 bf16, prepared by the caller) sits in registers.  The layer is bound by its 64-channel output stream, so the
+// optional epilogue (folded BatchNorm shift + ReLU, inference) saves a whole read + write of that tensor.
+namespace {
+
+constexpr int STH = 8, SHALO_H = STH + 2; // stem tile: 8 rows x TW pixels, wave w owns rows 2w, 2w+1 and all 64 output channels
+
+__global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__restrict__ x, const unsigned short *__restrict__ wq,
+                                                               unsigned short *__restrict__ y, int N, int Cin, int H, int W, long x_batch_stride,
+                                                               long x_channel_stride, const float *__restrict__ shift, int relu)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xs[SHALO_H * HALO_W * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 31, khalf = lane >> 5;
+    bf16x8 af[5][2]; // [K step][co half]: filter row co = 32*mt + (lane&31), tap 2*step + khalf, its 8 channels
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) af[ks][mt] = *(const bf16x8 *)(wq + ((mt * 32 + px) * 10 + 2 * ks + khalf) * 8);
+    const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + STH - 1) / STH;
+    const long tile = blockIdx.x;
+    const int tw = (int)(tile % tiles_w);
+    const int th = (int)((tile / tiles_w) % tiles_h);
+    const long n = tile / ((long)tiles_w * tiles_h);
+    for (int i = tid; i < SHALO_H * HALO_W; i += 256) *(uint4 *)(xs + i * 8) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const float *xn = x + n * x_batch_stride;
+    for (int i = tid; i < Cin * SHALO_H * HALO_W; i += 256) { // pixel index fastest: rows of 34 contiguous floats
+        const int c = i / (SHALO_H * HALO_W), p = i - c * (SHALO_H * HALO_W);
+        const int hh = p / HALO_W, ww = p - hh * HALO_W;
+        const int h = th * STH + hh - 1, wcol = tw * TW + ww - 1;
+        if (h >= 0 && h < H && wcol >= 0 && wcol < W) xs[p * 8 + c] = f2bf(xn[c * x_channel_stride + (long)h * W + wcol]);
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) acc[rr][mt] = f32x16{};
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) {
+        const int tap = 2 * ks + khalf < 9 ? 2 * ks + khalf : 8; // tap 9: any address, its weights are zero
+        const int r = tap / 3, sx = tap - 3 * r;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const bf16x8 b = *(const bf16x8 *)(xs + ((wv * 2 + rr + r) * HALO_W + px + sx) * 8);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) acc[rr][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mt], b, acc[rr][mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int h = th * STH + wv * 2 + rr, wcol = tw * TW + px;
+        if (h < H && wcol < W) {
+            unsigned short *o = y + ((n * H + h) * W + wcol) * CH + 4 * khalf;
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) { // D rows (reg&3) + 8*(reg>>2) + 4*(lane>>5): four consecutive output channels
+                    float v4[4] = {acc[rr][mt][4 * g], acc[rr][mt][4 * g + 1], acc[rr][mt][4 * g + 2], acc[rr][mt][4 * g + 3]};
+                    if (shift) {
+                        const float4 sh = *(const float4 *)(shift + 32 * mt + 4 * khalf + 8 * g);
+                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                        }
+                    }
+                    uint2 v;
+                    v.x = (unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16);
+                    v.y = (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16);
+                    *(uint2 *)(o + 32 * mt + 8 * g) = v;
+                }
+        }
+    }
+}
+
+} // namespace
+
+// x float32 planar [N][Cin][H][W] (Cin <= 8; rows contiguous, batch / channel strides in elements, so a time-cropped view of
+// the extractor's output needs no copy), wq bf16 [64][10][8] = w[co][tap][ci] zero-padded (tap 9 and ci >= Cin zero),
+// y bf16 channels-last [N][H][W][64]; shift NULL: plain convolution, else y = [relu](conv + shift[co]) (folded BatchNorm)
+extern "C" int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *wq,
+                                     const float *shift, void *y, int relu, int64_t N, int Cin, int H, int W, void *hip_stream)
+{
+    if (!x || !wq || !y || N <= 0 || Cin <= 0 || Cin > 8 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        return -1;
+    const long tiles = (long)N * ((H + STH - 1) / STH) * ((W + TW - 1) / TW);
+    if (tiles >= INT32_MAX) return -1;
+    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)hip_stream, x,
+                       (const unsigned short *)wq, (unsigned short *)y, (int)N, Cin, H, W, (long)x_batch_stride, (long)x_channel_stride,
+                       shift, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -234,6 +234,44 @@ def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
     assert y32.dtype == torch.float32 and not isinstance(y32.grad_fn, _Conv3x3C64._backward_cls)
 
 
+def test_stem_conv_kernel_matches_torch():
+    """salsa_nn_conv3x3_stem (7 -> 64 on float32 planar input): plain forward and weight gradient through Conv3x3 under bf16
+    autocast against F.conv2d on the bf16-rounded operands in float32; the folded-BatchNorm + ReLU epilogue (eval) against
+    conv -> BatchNorm -> ReLU; ragged sizes (tile edges, one-row / one-column images)."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(9)
+    for (n, cin, h, w) in ((2, 7, 40, 70), (1, 7, 9, 33), (3, 4, 8, 32), (1, 8, 1, 5), (1, 7, 17, 1)):
+        conv = nn_ops.Conv3x3(cin, 64, kernel_size=3, stride=1, padding=1, bias=False).to(dev)
+        bn = nn_ops.BatchNormAct2d(64).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn((n, cin, h + 1, w), device=dev, generator=g)[:, :, :h]     # a time crop: strided batches / channels
+        assert not x.is_contiguous() or n * cin == 1
+        xr, wr = x.to(torch.bfloat16).float(), conv.weight.detach().to(torch.bfloat16).float()
+        ref = F.conv2d(xr, wr, padding=1)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            assert conv._stem_eligible(x)
+            y = conv(x)
+        assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+        assert isinstance(y.grad_fn, nn_ops._Conv3x3Stem._backward_cls)
+        torch.testing.assert_close(y.float(), ref, rtol=2.0 ** -8, atol=2e-3)
+        gy = torch.randn(y.shape, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y.backward(gy)
+        wref = conv.weight.detach().clone().requires_grad_(True)
+        F.conv2d(xr, wref.to(torch.bfloat16).float(), padding=1).backward(gy.float())
+        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=2e-2, atol=2e-2 * float(wref.grad.abs().max()))
+        bn.eval(); conv.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            fused = nn_ops.conv_bn_act(conv, bn, x)
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        wf = (conv.weight.detach() * scale[:, None, None, None]).to(torch.bfloat16).float()
+        want = F.relu(F.conv2d(xr, wf, padding=1) + (bn.bias - bn.running_mean * scale)[None, :, None, None])
+        torch.testing.assert_close(fused.float(), want, rtol=2.0 ** -8, atol=2e-3)
+
+
 def test_whole_model_hip_layers_on_vs_off():
     """The CRNN with every hand-written layer (MFMA convolutions, pools, fused BatchNorm, GRU scan) against the same weights
     with those layers switched to torch / MIOpen: bf16-autocast eval forward and one training step's loss and gradients."""
