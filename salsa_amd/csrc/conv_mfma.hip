@@ -32,12 +32,12 @@ constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 constexpr int HALO_PIECES = HALO_H * HALO_W * 8;              // 16-byte pieces of one input tile
 constexpr int PREF = (HALO_PIECES + 255) / 256;               // pieces per thread
 
-__device__ __forceinline__ unsigned short f2bf(float f)
+// two float32 -> packed bf16 (low half = a), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
 // x: [N][H][W][64] bf16, w: [64 co][3][3][64 ci] bf16 (torch's channels-last weight layout), y: [N][H][W][64] bf16.
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
                         }
                     }
                     uint2 v;
-                    v.x = (unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16);
-                    v.y = (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16);
+                    v.x = pack_bf16(v4[0], v4[1]);
+                    v.y = pack_bf16(v4[2], v4[3]);
                     *(uint2 *)(o + 8 * g) = v;
                 }
             }
@@ -197,6 +197,11 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
 // optional epilogue (folded BatchNorm shift + ReLU, inference) saves a whole read + write of that tensor.
 namespace {
 
+#ifdef STEM_NO_STORE // probe: every value computed, nothing written
+#define STEM_STORE_COND &&v.x == 0x12345678u && v.w == 0x9abcdef0u
+#else
+#define STEM_STORE_COND
+#endif
 constexpr int STH = 8, SHALO_H = STH + 2; // stem tile: 8 rows x TW pixels, wave w owns rows 2w, 2w+1 and all 64 output channels
 
 __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__restrict__ x, const unsigned short *__restrict__ wq,
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
                                                                long x_channel_stride, const float *__restrict__ shift, int relu)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xs[SHALO_H * HALO_W * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short ys[4 * TW * ROW]; // per wave: one output row, [pixel][ROW]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = lane & 31, khalf = lane >> 5;
     bf16x8 af[5][2]; // [K step][co half]: filter row co = 32*mt + (lane&31), tap 2*step + khalf, its 8 channels
@@ -216,14 +222,23 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
     const int tw = (int)(tile % tiles_w);
     const int th = (int)((tile / tiles_w) % tiles_h);
     const long n = tile / ((long)tiles_w * tiles_h);
-    for (int i = tid; i < SHALO_H * HALO_W; i += 256) *(uint4 *)(xs + i * 8) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
     const float *xn = x + n * x_batch_stride;
-    for (int i = tid; i < Cin * SHALO_H * HALO_W; i += 256) { // pixel index fastest: rows of 34 contiguous floats
-        const int c = i / (SHALO_H * HALO_W), p = i - c * (SHALO_H * HALO_W);
-        const int hh = p / HALO_W, ww = p - hh * HALO_W;
+    for (int p = tid; p < SHALO_H * HALO_W; p += 256) { // a thread = one halo pixel (neighbouring lanes, neighbouring columns):
+        const int hh = p / HALO_W, ww = p - hh * HALO_W; // its Cin loads go out together, one 16-byte LDS write packs them
         const int h = th * STH + hh - 1, wcol = tw * TW + ww - 1;
-        if (h >= 0 && h < H && wcol >= 0 && wcol < W) xs[p * 8 + c] = f2bf(xn[c * x_channel_stride + (long)h * W + wcol]);
+        const bool inside = h >= 0 && h < H && wcol >= 0 && wcol < W;
+        const float *src = xn + (inside ? (long)h * W + wcol : 0);
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = src[c < Cin ? c * x_channel_stride : 0]; // unconditional (valid) loads, no branches
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = (inside && c < Cin) ? v[c] : 0.f;
+        uint4 pk;
+        pk.x = pack_bf16(v[0], v[1]);
+        pk.y = pack_bf16(v[2], v[3]);
+        pk.z = pack_bf16(v[4], v[5]);
+        pk.w = pack_bf16(v[6], v[7]);
+        *(uint4 *)(xs + p * 8) = pk;
     }
     __syncthreads();
     f32x16 acc[2][2];
@@ -242,30 +257,41 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
             for (int mt = 0; mt < 2; mt++) acc[rr][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mt], b, acc[rr][mt], 0, 0, 0);
         }
     }
+    // Epilogue.  D gives a lane four groups of four consecutive output channels of ONE pixel: stored directly that is 8-byte
+    // pieces, 16 store instructions per 128-byte pixel.  Each wave turns its row around through a private LDS strip
+    // ([pixel][64 co], rows padded to 144 bytes) instead and writes 16 bytes per lane, 8 lanes per pixel: every store
+    // instruction covers 8 whole pixels = 1 KB of contiguous memory (0.62 -> 0.52 ms on an 8 x 4800 x 200 sub-batch).
+    unsigned short *strip = ys + wv * (TW * ROW);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
-        const int h = th * STH + wv * 2 + rr, wcol = tw * TW + px;
-        if (h < H && wcol < W) {
-            unsigned short *o = y + ((n * H + h) * W + wcol) * CH + 4 * khalf;
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) { // D rows (reg&3) + 8*(reg>>2) + 4*(lane>>5): four consecutive output channels
-                    float v4[4] = {acc[rr][mt][4 * g], acc[rr][mt][4 * g + 1], acc[rr][mt][4 * g + 2], acc[rr][mt][4 * g + 3]};
-                    if (shift) {
-                        const float4 sh = *(const float4 *)(shift + 32 * mt + 4 * khalf + 8 * g);
-                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-                        if (relu) {
+            for (int g = 0; g < 4; g++) { // D rows (reg&3) + 8*(reg>>2) + 4*(lane>>5): four consecutive output channels
+                float v4[4] = {acc[rr][mt][4 * g], acc[rr][mt][4 * g + 1], acc[rr][mt][4 * g + 2], acc[rr][mt][4 * g + 3]};
+                if (shift) {
+                    const float4 sh = *(const float4 *)(shift + 32 * mt + 4 * khalf + 8 * g);
+                    v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                    if (relu) {
 #pragma unroll
-                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
-                        }
+                        for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
                     }
-                    uint2 v;
-                    v.x = (unsigned)f2bf(v4[0]) | ((unsigned)f2bf(v4[1]) << 16);
-                    v.y = (unsigned)f2bf(v4[2]) | ((unsigned)f2bf(v4[3]) << 16);
-                    *(uint2 *)(o + 32 * mt + 8 * g) = v;
                 }
+                uint2 v;
+                v.x = pack_bf16(v4[0], v4[1]);
+                v.y = pack_bf16(v4[2], v4[3]);
+                *(uint2 *)(strip + px * ROW + 32 * mt + 8 * g + 4 * khalf) = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the strip is wave-private: no barrier, only LDS order
+        const int h = th * STH + wv * 2 + rr;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int p = it * 8 + (lane >> 3), piece = lane & 7;
+            const uint4 v = *(const uint4 *)(strip + p * ROW + piece * 8);
+            const int wcol = tw * TW + p;
+            if (h < H && wcol < W STEM_STORE_COND) *(uint4 *)(y + ((n * H + h) * W + wcol) * CH + piece * 8) = v;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next row overwrites the strip
     }
 }
 

@@ -15,12 +15,12 @@ struct bf16x8 {
 };
 
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) // round to nearest even (inputs are finite sums of bf16 values)
+// two float32 -> packed bf16 (low half = a), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40); // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
 template <typename V, int L> struct vec_io;
@@ -47,7 +47,7 @@ template <> struct vec_io<bf16x8, 8> {
     {
         unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; i++) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
         *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
