@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
 #undef LDS_B
 #undef LDS_WAIT
         // D: column = lane&31 = pixel, row (= co within this wave's 32) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds, for ONE
-        // pixel, four groups of four consecutive output channels -> 8-byte stores.  (Transposing through LDS to get 16-byte
-        // stores of 64 contiguous bytes per pixel was measured no faster: the LDS round trip costs what the wider stores save.)
+        // pixel, four groups of four consecutive output channels -> 8-byte stores.  (Transposing through a wave-private LDS
+        // strip to get 16-byte stores of 64 contiguous bytes per pixel was measured SLOWER here, 1.59 -> 2.03 ms per training
+        // step, twice: this kernel's epilogue competes with the next tile's MFMAs for LDS and registers.  The stem kernel
+        // below, which has next to no MFMA work, does gain from it.)
 #pragma unroll
         for (int rr = 0; rr < RPW; rr++) {
             const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
