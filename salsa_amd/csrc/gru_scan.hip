@@ -11,6 +11,10 @@
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// the register-resident kernels' gate math is the serial tail of every step: hardware reciprocal (1 ulp) instead of the IEEE
+// division sequence, tanh through the same exponential (absolute error ~1e-7, far below the float16 operands' rounding)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // whh_t: [D][H(k)][3H] (weight_hh transposed by the caller) so that for a fixed k consecutive threads read
 // consecutive addresses.
@@ -183,9 +187,9 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
         ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
         ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
         if (part == 0) {
-            const float r = sigmoidf_(g0 + ar + br);
-            const float z = sigmoidf_(g1 + az + bz);
-            const float n = tanhf(g2 + r * (an + bn));
+            const float r = sigmoid_fast(g0 + ar + br);
+            const float z = sigmoid_fast(g1 + az + bz);
+            const float n = tanh_fast(g2 + r * (an + bn));
             hq = (1.f - z) * n + z * hq;
             hs[base * H + q] = hq;
             h[(s + 1) & 1][q] = (_Float16)hq;
