@@ -40,6 +40,10 @@ int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H
  * gamma / sqrt(var + eps) per output channel, shift = beta - mean * gamma / sqrt(var + eps) (float32 [64]); residual bf16 or NULL */
 int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y, int relu,
                                   int64_t N, int H, int W, void *hip_stream);
+/* the same followed by the 2x2 average pool of the upstream stem (taken in float32 before the single rounding):
+ * y bf16 [N][H/2][W/2][64]; H and W even */
+int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, const float *shift, const void *residual, void *y, int relu,
+                                       int64_t N, int H, int W, void *hip_stream);
 /* the network's first layer, Cin <= 8 -> 64 channels, on the extractor's output layout: x float32 planar [N][Cin][H][W] with
  * contiguous rows and the given batch / channel strides (elements; a time-cropped view needs no copy);
  * wq bf16 [64 co][10 taps][8 ci] (taps row-major, tap 9 and ci >= Cin zero); y bf16 channels-last [N][H][W][64];

@@ -41,8 +41,7 @@ class Stem(nn.Module):
 
     def forward(self, x):
         x = conv_bn_act(self.conv1, self.bn1, x)
-        x = conv_bn_act(self.conv2, self.bn2, x)
-        return avg_pool2x2(x)
+        return conv_bn_act(self.conv2, self.bn2, x, pool=True)                # ... -> 2x2 average pool
 
 
 class ResBlock(nn.Module):

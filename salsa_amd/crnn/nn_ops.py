@@ -254,11 +254,12 @@ class Conv3x3(torch.nn.Conv2d):
         return super().forward(x)
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0):
+def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
     """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
     residual add and the ReLU -- before its single rounding: the normalised activation never makes a round trip to HBM.
-    Every other case is conv -> BatchNormAct2d."""
+    ``pool=True`` appends the 2x2 average pool of the upstream stem; on that eval path it is taken inside the kernel, so the
+    full-resolution activation is not written at all.  Every other case is conv -> BatchNormAct2d (-> avg_pool2x2)."""
     if (isinstance(conv, Conv3x3) and conv._hip_eligible(x) and not bn.training and not torch.is_grad_enabled()
             and bn.track_running_stats and bn.affine
             and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == 64
@@ -268,16 +269,20 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0):
         wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, _, H, W = xb.shape
-        y = torch.empty_like(xb, memory_format=torch.channels_last)
+        fuse_pool = pool and H % 2 == 0 and W % 2 == 0
+        y = (torch.empty((N, 64, H // 2, W // 2), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
+             if fuse_pool else torch.empty_like(xb, memory_format=torch.channels_last))
+        fn = _lib.load().salsa_nn_conv3x3_c64_bias_act_pool if fuse_pool else _lib.load().salsa_nn_conv3x3_c64_bias_act
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_conv3x3_c64_bias_act(_ptr(xb), _ptr(wf), _ptr(shift), _ptr(residual), _ptr(y), int(relu),
-                                                           N, H, W, _stream(xb))
+            rc = fn(_ptr(xb), _ptr(wf), _ptr(shift), _ptr(residual), _ptr(y), int(relu), N, H, W, _stream(xb))
         if rc:
-            raise RuntimeError('salsa_nn_conv3x3_c64_bias_act failed (%d)' % rc)
-        return y
+            raise RuntimeError('salsa_nn_conv3x3_c64_bias_act%s failed (%d)' % ('_pool' if fuse_pool else '', rc))
+        return y if fuse_pool or not pool else avg_pool2x2(y)
     if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
             and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
         scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
         shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-        return _conv_stem(x, _stem_filter(conv.weight, scale), shift, relu)
-    return bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)
+        y = _conv_stem(x, _stem_filter(conv.weight, scale), shift, relu)
+        return avg_pool2x2(y) if pool else y
+    y = bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)
+    return avg_pool2x2(y) if pool else y

@@ -44,6 +44,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 // The WHOLE filter lives in registers (72 A fragments per lane: a wave per SIMD may use all 512 VGPR+AGPR), so LDS only
 // serves the input tile: one 16-byte B read per two MFMAs.  The next tile's halo is prefetched into registers while the
 // current tile is multiplied.
+template <bool POOL>
 __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const unsigned short *__restrict__ x,
                                                               const unsigned short *__restrict__ w,
                                                               unsigned short *__restrict__ y, int N, int H, int W,
@@ -132,6 +133,38 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
         // strip to get 16-byte stores of 64 contiguous bytes per pixel was measured SLOWER here, 1.59 -> 2.03 ms per training
         // step, twice: this kernel's epilogue competes with the next tile's MFMAs for LDS and registers.  The stem kernel
         // below, which has next to no MFMA work, does gain from it.)
+        if (POOL) { // inference, RPW == 2: the 2x2 average pool that follows (stem, model_utils.py:224) taken on the float32 values
+            // before the single rounding -- the wave's two rows are the vertical pair, the neighbouring lane the horizontal one;
+            // the full-resolution activation is never written (H and W even: a tile holds whole 2x2 cells)
+            const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
+            const bool inside = h0 < H && wcol < W;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};
+                const float4 sh = *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g);
+#pragma unroll
+                for (int rr = 0; rr < RPW; rr++) {
+                    float v4[4] = {acc[rr][4 * g] + sh.x, acc[rr][4 * g + 1] + sh.y, acc[rr][4 * g + 2] + sh.z, acc[rr][4 * g + 3] + sh.w};
+                    if (residual) {
+                        const long roff = ((n * H + (inside ? h0 + rr : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
+                        const uint2 rv = *(const uint2 *)(residual + roff + 8 * g);
+                        v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s4[j] += relu ? fmaxf(v4[j], 0.f) : v4[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) s4[j] = 0.25f * (s4[j] + __shfl_xor(s4[j], 1));
+                if (inside && !(px & 1)) {
+                    uint2 v;
+                    v.x = pack_bf16(s4[0], s4[1]);
+                    v.y = pack_bf16(s4[2], s4[3]);
+                    *(uint2 *)(y + ((n * (H / 2) + h0 / 2) * (W / 2) + wcol / 2) * CH + 32 * mb + 4 * (lane >> 5) + 8 * g) = v;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int rr = 0; rr < RPW; rr++) {
             const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
@@ -172,7 +205,7 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
-    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
                        (const unsigned short *)nullptr, 0);
     return hipGetLastError() == hipSuccess ? 0 : -6;
@@ -185,7 +218,21 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
-    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// the same with the 2x2 average pool that follows fused in: y is [N][H/2][W/2][64]; H and W must be even
+extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, const float *shift, const void *residual, void *y,
+                                                  int relu, int64_t N, int H, int W, void *hip_stream)
+{
+    if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || RPW != 2 ||
+        N * H * W >= INT32_MAX / CH)
+        return -1;
+    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

@@ -388,6 +388,18 @@ def test_eval_conv_with_folded_batchnorm_epilogue():
         ref = ref + r.float() if use_res else ref
         ref = F.relu(ref) if relu else ref
         torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)            # bf16 filter (scaled) and output rounding
+    # pool=True: the stem's 2x2 average pool inside the kernel (even sizes; tile edges in both directions), and the unfused
+    # fall-back for odd sizes
+    for (h, w), use_res in (((22, 46), False), ((8, 64), True), ((4, 2), False), ((21, 45), False)):
+        x = torch.randn((2, 64, h, w), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        r = torch.randn((2, 64, h, w), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last) if use_res else None
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            y = nn_ops.conv_bn_act(conv, bn, x, residual=r, relu=True, pool=True)
+        assert y.shape == (2, 64, h // 2, w // 2) and y.dtype == torch.bfloat16
+        ref = F.batch_norm(F.conv2d(x.float(), conv.weight.float(), padding=1), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                           False, 0.0, bn.eps)
+        ref = F.avg_pool2d(F.relu(ref + r.float() if use_res else ref), 2)
+        torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)
 
 
 def test_register_resident_gru_training_scan_gradients():
