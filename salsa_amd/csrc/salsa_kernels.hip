@@ -491,6 +491,7 @@ constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gat
 #ifndef K3_GROUP
 #define K3_GROUP 2
 #endif
+constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins + the zero band above them when it fits
 
 template <bool FEAT, int NHOP>
 __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
@@ -503,6 +504,10 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     static_assert(K3_FT % G == 0 && G <= 4 && K3_FT / G <= 16, "work-list entry layout");
     __shared__ unsigned short list[K3_FT * 256];
     __shared__ int count;
+    // FEAT: the tile's channels 4-6 are assembled in LDS (zeros + the gated bins' results) and written out as whole rows with
+    // 16-byte stores at the end, instead of one 4-byte store per lane per (channel, frame) for the zeros plus three scattered
+    // 4-byte stores per result
+    __shared__ __attribute__((aligned(16))) float otile[FEAT ? 3 * K3_FT * K3_OW : 4];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int Tn = kp.T;
@@ -512,15 +517,17 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     const int bin0 = blockIdx.z * 256;
     const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
     if (tid == 0) count = 0;
+    if (FEAT) {
+        for (int i = tid; i < 3 * K3_FT * K3_OW / 4; i += 256) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
     float *of = FEAT ? out_feat + ((long)b * kp.OC + 4) * Tn * kp.F : nullptr; // channels 4-6 of this clip, [3][T][F]
     double *oe = FEAT ? nullptr : out_eig + (long)b * 3 * kp.nd * Tn;
     unsigned char *og = (!FEAT && gate) ? gate + (long)b * kp.nd * Tn : nullptr;
     auto emit = [&](int t, int bin, const double *e, unsigned char g) {
         if (FEAT) {
-            const unsigned off = 4u * (unsigned)(t * kp.F + bin), plane = 4u * (unsigned)(Tn * kp.F);
 #pragma unroll
-            for (int i = 0; i < 3; i++) st_off(of, off + (unsigned)i * plane, (float)e[i]);
+            for (int i = 0; i < 3; i++) otile[(i * K3_FT + (t - t0)) * K3_OW + (bin - bin0)] = (float)e[i];
         } else {
 #pragma unroll
             for (int i = 0; i < 3; i++) oe[((long)i * kp.nd + bin) * Tn + t] = e[i];
@@ -570,15 +577,17 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                 if (v) list[base + __popcll(wd & ((1ull << lane) - 1))] = (unsigned short)((v << 12) | ((ft / G) << 8) | bl);
 #pragma unroll
                 for (int j = 0; j < G; j++)
-                    if (ft + j < nft && !((v >> j) & 1)) emit(t0 + ft + j, bin, zero3, 0);
+                    if (!FEAT && ft + j < nft && !((v >> j) & 1)) emit(t0 + ft + j, bin, zero3, 0);
             }
             base += __popcll(wd);
         }
     }
-    if (FEAT && blockIdx.z == gridDim.z - 1) { // zero the feature bins above the DOA band (:373-374)
-        const int tail = kp.F - kp.nd;
+    // columns of this block's rows: its bins, plus -- in the last block -- the zeros above the DOA band up to F (:373-374)
+    const int seg = (FEAT && blockIdx.z == gridDim.z - 1) ? (kp.F - bin0 < K3_OW ? kp.F - bin0 : K3_OW) : nbc;
+    if (FEAT && blockIdx.z == gridDim.z - 1 && kp.F - bin0 > K3_OW) { // (wider than the LDS tile: the rest directly)
+        const int first = bin0 + K3_OW, tail = kp.F - first;
         for (int i = tid; i < nft * tail; i += 256) {
-            const int ft = i / tail, f = kp.nd + (i - ft * tail);
+            const int ft = i / tail, f = first + (i - ft * tail);
 #pragma unroll
             for (int c = 0; c < 3; c++) st_off(of, 4u * (unsigned)((c * Tn + t0 + ft) * kp.F + f), 0.f);
         }
@@ -658,6 +667,22 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                 salsa::herm4_rank1_add(R, x);
             }
             solve_emit(R, t, bin);
+        }
+    }
+    if (FEAT) { // write the tile out: 3 channels x nft frames, `seg` consecutive floats each
+        __syncthreads();
+        const bool vec = !(kp.F & 3) && !(seg & 3) && !(bin0 & 3); // rows start and end on 16-byte boundaries
+        if (vec) {
+            const int q = seg >> 2;
+            for (int i = tid; i < 3 * nft * q; i += 256) {
+                const int row = i / q, col = i - row * q, c = row / nft, ft = row - c * nft;
+                *(float4 *)(of + ((long)(c * Tn + t0 + ft) * kp.F + bin0 + 4 * col)) = *(const float4 *)(otile + (c * K3_FT + ft) * K3_OW + 4 * col);
+            }
+        } else {
+            for (int i = tid; i < 3 * nft * seg; i += 256) {
+                const int row = i / seg, col = i - row * seg, c = row / nft, ft = row - c * nft;
+                of[(long)(c * Tn + t0 + ft) * kp.F + bin0 + col] = otile[(c * K3_FT + ft) * K3_OW + col];
+            }
         }
     }
 }
