@@ -41,6 +41,78 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 }
 
 // x: [N][H][W][64] bf16, w: [64 co][3][3][64 ci] bf16 (torch's channels-last weight layout), y: [N][H][W][64] bf16.
+// Epilogue of one tile, shared by the two forward kernels: D -> (shift, residual, ReLU) -> bf16 stores, or the pooled variant.
+template <bool POOL>
+__device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsigned short *__restrict__ y, const float *__restrict__ shift,
+                                                const float4 (&shv)[4], const unsigned short *__restrict__ residual, int relu, long n,
+                                                int th, int tw, int H, int W, int lane, int px, int mb, int rg)
+{
+    if (POOL) { // inference, RPW == 2: the 2x2 average pool that follows (stem, model_utils.py:224) taken on the float32 values
+        // before the single rounding -- the wave's two rows are the vertical pair, the neighbouring lane the horizontal one;
+        // the full-resolution activation is never written (H and W even: a tile holds whole 2x2 cells)
+        const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
+        const bool inside = h0 < H && wcol < W;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4 sh = shv[g];
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++) {
+                float v4[4] = {acc[rr][4 * g] + sh.x, acc[rr][4 * g + 1] + sh.y, acc[rr][4 * g + 2] + sh.z, acc[rr][4 * g + 3] + sh.w};
+                if (residual) {
+                    const long roff = ((n * H + (inside ? h0 + rr : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
+                    const uint2 rv = *(const uint2 *)(residual + roff + 8 * g);
+                    v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) s4[j] += relu ? fmaxf(v4[j], 0.f) : v4[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) s4[j] = 0.25f * (s4[j] + __shfl_xor(s4[j], 1));
+            if (inside && !(px & 1)) {
+                uint2 v;
+                v.x = pack_bf16(s4[0], s4[1]);
+                v.y = pack_bf16(s4[2], s4[3]);
+                *(uint2 *)(y + ((n * (H / 2) + h0 / 2) * (W / 2) + wcol / 2) * CH + 32 * mb + 4 * (lane >> 5) + 8 * g) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+        const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
+        if (h < H && wcol < W) {
+            const long off = ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
+            unsigned short *o = y + off;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
+                if (shift) { // inference epilogue: folded BatchNorm shift (+ residual) (+ ReLU) before the single rounding
+                    const float4 sh = shv[g];
+                    v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                    if (residual) {
+                        const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
+                        v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                    }
+                }
+                uint2 v;
+                v.x = pack_bf16(v4[0], v4[1]);
+                v.y = pack_bf16(v4[2], v4[3]);
+#ifdef CONV_NO_STORE // probe: everything computed, nothing written
+                if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
+#endif
+                *(uint2 *)(o + 8 * g) = v;
+            }
+        }
+    }
+}
+
 // The WHOLE filter lives in registers (72 A fragments per lane: a wave per SIMD may use all 512 VGPR+AGPR), so LDS only
 // serves the input tile: one 16-byte B read per two MFMAs.  The next tile's halo is prefetched into registers while the
 // current tile is multiplied.
@@ -60,6 +132,10 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
     for (int tap = 0; tap < 9; tap++)
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) af[tap][kc] = *(const bf16x8 *)(w + ((long)((mb * 32 + px) * 9 + tap) * CH + kc * 16 + kh));
+    float4 shv[4]; // the lane's 16 folded-BatchNorm shifts (inference), loaded once: ordinary loads inside the tile loop would
+                   // make the compiler drain every load in flight, the next tiles' included
+#pragma unroll
+    for (int g = 0; g < 4; g++) shv[g] = shift ? *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH;
     const long n_tiles = (long)N * tiles_h * tiles_w;
     uint4 pre[PREF];
@@ -74,8 +150,10 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
             const int hh = p / HALO_W, ww = p - hh * HALO_W;
             const int h = th * TH + hh - 1, wcol = tw * TW + ww - 1;
             pre[j] = make_uint4(0u, 0u, 0u, 0u);
+#ifndef CONV_NO_FETCH // probe: what the kernel costs without its input stream
             if (i < HALO_PIECES && h >= 0 && h < H && wcol >= 0 && wcol < W)
                 pre[j] = *(const uint4 *)(x + (((n * H + h) * W + wcol) * CH + piece * 8));
+#endif
         }
     };
     long tile = blockIdx.x;
@@ -101,6 +179,40 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
         // asm that takes the fragments as operands: step q+1's fragments are requested, step q's four MFMAs issue, then wait.
         const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xl +
                                2u * (unsigned)((rg * RPW * HALO_W + px) * ROW + kh);
+#if CONV_RPW == 2 && !defined(CONV_NO_ROW_SHARE)
+        // Output rows 0 and 1 of the wave read input rows 0-2 and 1-3: a fragment of input row ir (tap column s, channel block
+        // kc) serves output row 0 with filter row ir and output row 1 with filter row ir-1.  Walking the 4 x 3 x 4 = 48 distinct
+        // fragments instead of the 2 x 36 (row, step) pairs cuts the LDS reads by a third for the same 72 MFMAs (the LDS pipe,
+        // shared by the CU's 8 waves, was as busy as the matrix pipe).
+#define LDS_B1(dst, u)                                                                                                 \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                       \
+                 : "=v"(dst)                                                                                           \
+                 : "v"(lbase), "n"(2 * ((((u) / 12) * HALO_W + ((u) / 4) % 3) * ROW + ((u) & 3) * 16)))
+#define LDS_WAIT1(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f))
+#ifndef CONV_DEPTH
+#define CONV_DEPTH 1 // fragments in flight ahead of the one being multiplied (1, 2, 3 measured the same)
+#endif
+        constexpr int DEPTH = CONV_DEPTH, RING = DEPTH + 1;
+        bf16x8 bb[RING]; // fragment u multiplies while u+1 .. u+DEPTH are in flight (one MFMA pair is shorter than the LDS latency)
+#pragma unroll
+        for (int u = 0; u < DEPTH; u++) LDS_B1(bb[u % RING], u);
+#pragma unroll
+        for (int u = 0; u < 48; u++) {
+            if (u + DEPTH < 48) LDS_B1(bb[(u + DEPTH) % RING], u + DEPTH);
+            // wait until fragment u has landed: at most min(DEPTH, 47 - u) younger reads may still be outstanding
+            if (u + DEPTH < 48) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bb[u % RING]) : "n"(DEPTH));
+            else if (47 - u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bb[u % RING]));
+            else if (47 - u == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bb[u % RING]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[u % RING]));
+            __builtin_amdgcn_sched_barrier(0);
+            const int ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
+            if (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[u % RING], acc[0], 0, 0, 0);
+            if (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[u % RING], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef LDS_B1
+#undef LDS_WAIT1
+#else
 #define LDS_B(dst, q, rr)                                                                                              \
     asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                       \
                  : "=v"(dst)                                                                                           \
@@ -128,74 +240,177 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
         }
 #undef LDS_B
 #undef LDS_WAIT
+#endif
         // D: column = lane&31 = pixel, row (= co within this wave's 32) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds, for ONE
         // pixel, four groups of four consecutive output channels -> 8-byte stores.  (Transposing through a wave-private LDS
         // strip to get 16-byte stores of 64 contiguous bytes per pixel was measured SLOWER here, 1.59 -> 2.03 ms per training
         // step, twice: this kernel's epilogue competes with the next tile's MFMAs for LDS and registers.  The stem kernel
         // below, which has next to no MFMA work, does gain from it.)
-        if (POOL) { // inference, RPW == 2: the 2x2 average pool that follows (stem, model_utils.py:224) taken on the float32 values
-            // before the single rounding -- the wave's two rows are the vertical pair, the neighbouring lane the horizontal one;
-            // the full-resolution activation is never written (H and W even: a tile holds whole 2x2 cells)
-            const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
-            const bool inside = h0 < H && wcol < W;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};
-                const float4 sh = *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g);
-#pragma unroll
-                for (int rr = 0; rr < RPW; rr++) {
-                    float v4[4] = {acc[rr][4 * g] + sh.x, acc[rr][4 * g + 1] + sh.y, acc[rr][4 * g + 2] + sh.z, acc[rr][4 * g + 3] + sh.w};
-                    if (residual) {
-                        const long roff = ((n * H + (inside ? h0 + rr : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
-                        const uint2 rv = *(const uint2 *)(residual + roff + 8 * g);
-                        v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
-                        v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) s4[j] += relu ? fmaxf(v4[j], 0.f) : v4[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) s4[j] = 0.25f * (s4[j] + __shfl_xor(s4[j], 1));
-                if (inside && !(px & 1)) {
-                    uint2 v;
-                    v.x = pack_bf16(s4[0], s4[1]);
-                    v.y = pack_bf16(s4[2], s4[3]);
-                    *(uint2 *)(y + ((n * (H / 2) + h0 / 2) * (W / 2) + wcol / 2) * CH + 32 * mb + 4 * (lane >> 5) + 8 * g) = v;
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPW; rr++) {
-            const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
-            if (h < H && wcol < W) {
-                const long off = ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
-                unsigned short *o = y + off;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
-                    if (shift) { // inference epilogue: folded BatchNorm shift (+ residual) (+ ReLU) before the single rounding
-                        const float4 sh = *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g);
-                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-                        if (residual) {
-                            const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
-                            v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
-                            v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
-                        }
-                    }
-                    uint2 v;
-                    v.x = pack_bf16(v4[0], v4[1]);
-                    v.y = pack_bf16(v4[2], v4[3]);
-                    *(uint2 *)(o + 8 * g) = v;
-                }
-            }
-        }
+        conv64_epilogue<POOL>(acc, y, shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
     }
 }
+
+// ---- variant with the input tiles loaded STRAIGHT INTO LDS (global_load_lds_dwordx4), two tiles ahead.
+// Probe builds of the kernel above: 0.242 ms for 8 x 2400 x 100, 0.143 ms without its input loads -- the next tile's halo,
+// prefetched into registers ONE tile ahead, arrives later than one tile's multiply takes, and 256 VGPRs leave no room for a
+// second staging set.  Direct-to-LDS loads need no staging registers: three LDS tiles (2 x 78 KB per CU) rotate, the loads
+// for tile i+2 are issued when tile i starts, and the LDS write pass and one of the two barriers per tile disappear.  A wave's
+// load instruction fills 64 consecutive 16-byte LDS slots, so the pixel stride in LDS is exactly 128 bytes; the bank
+// conflicts that the padded layout avoided are avoided here by a rotation: channel block c of pixel p sits in slot
+// (c + p) & 7, applied to the GLOBAL address when loading and to the LDS address when reading (where pixel and block offsets
+// of a fragment are compile-time constants: eight per-lane base registers, one per value of the constant part mod 8).  Halo pixels outside the
+// image load from a 16-byte zero constant.
+__device__ uint4 conv_zero16; // zero-initialised
+
+constexpr int APIX = 64;                             // bf16 per pixel in LDS (no padding)
+constexpr int ABUF = HALO_H * HALO_W * APIX;         // one tile
+constexpr int NBUF = 3;
+constexpr int AFETCH = (HALO_PIECES + 255) / 256;    // load instructions per thread per tile (the last one partial)
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const unsigned short *__restrict__ x,
+                                                                       const unsigned short *__restrict__ w,
+                                                                       unsigned short *__restrict__ y, int N, int H, int W,
+                                                                       const float *__restrict__ shift,
+                                                                       const unsigned short *__restrict__ residual, int relu)
+{
+    static_assert(RPW == 2, "row sharing below is written for two rows per wave");
+    __shared__ __attribute__((aligned(16))) unsigned short xl[NBUF * ABUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = lane & 31, khalf = lane >> 5, kh = khalf * 8;
+    const int mb = wv & 1, rg = wv >> 1;
+    bf16x8 af[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) af[tap][kc] = *(const bf16x8 *)(w + ((long)((mb * 32 + px) * 9 + tap) * CH + kc * 16 + kh));
+    float4 shv[4]; // the lane's 16 folded-BatchNorm shifts (inference), loaded once: ordinary loads inside the tile loop would
+                   // make the compiler drain every load in flight, the next tiles' included
+#pragma unroll
+    for (int g = 0; g < 4; g++) shv[g] = shift ? *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the filter has landed BEFORE the tile loop: left to its first use, the compiler's wait for these ordinary loads sits in
+    // front of the loop's first MFMA as vmcnt(0) and drains the LDS-direct loads in flight with it, every tile
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) asm volatile("" ::"v"(af[tap][kc]));
+#pragma unroll
+    for (int g = 0; g < 4; g++) asm volatile("" ::"v"(shv[g].x), "v"(shv[g].y), "v"(shv[g].z), "v"(shv[g].w));
+    const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH;
+    const int n_tiles = N * tiles_h * tiles_w; // (fits: the host checks N*H*W; 32-bit tile arithmetic, no 64-bit divisions)
+    // Tile cursors.  Probe builds with neither loads nor stores still ran at 2x the MFMA time: the per-tile integer work
+    // (two divisions per decode, a division by 34 and 64-bit address arithmetic per load) was the bound.  So a cursor keeps
+    // (tw, th, n) and steps by the grid size with carries, and a thread's halo pixel walks rows incrementally (its channel
+    // block never changes: the slot index advances by 256 = 0 mod 8 and the pixel by 32 = 0 mod 8 per load).
+    struct Cursor { int tw, th, n; };
+    const int stride = (int)gridDim.x;
+    const int d_tw = stride % tiles_w, d_th = (stride / tiles_w) % tiles_h, d_n = stride / (tiles_w * tiles_h);
+    auto advance = [&](Cursor &c) {
+        c.tw += d_tw;
+        int carry = c.tw >= tiles_w ? 1 : 0;
+        c.tw -= carry ? tiles_w : 0;
+        c.th += d_th + carry;
+        carry = c.th >= tiles_h ? 1 : 0;
+        c.th -= carry ? tiles_h : 0;
+        c.n += d_n + carry;
+    };
+    const int p0 = tid >> 3, hh0 = p0 / HALO_W, ww0 = p0 - hh0 * HALO_W;
+    const int blk8 = (((tid & 7) - p0) & 7) * 8; // channel offset of this thread's 16 bytes: slot (block + pixel) & 7
+    auto fetch = [&](const Cursor &c, int buf) {
+        const unsigned short *origin = x + (((long)c.n * H + c.th * TH) * W + c.tw * TW) * CH; // pixel (0, 0) of the tile
+        const int h_lo = -c.th * TH, h_hi = H - c.th * TH, w_lo = -c.tw * TW, w_hi = W - c.tw * TW; // valid (row, col) - origin
+        int hh = hh0 - 1, ww = ww0 - 1; // halo pixel relative to the tile origin
+#pragma unroll
+        for (int j = 0; j < AFETCH; j++) {
+            const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
+            const unsigned short *src = inside ? origin + ((hh * W + ww) * CH + blk8) : (const unsigned short *)&conv_zero16;
+            unsigned short *dst = xl + buf * ABUF + (j * 256 + wv * 64) * 8; // the wave's 64 slots (lane l -> + 16 l bytes)
+#ifndef CONV_NO_FETCH
+            if (tid + j * 256 < HALO_PIECES)
+#else
+            if (tid < 0)
+#endif
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            ww += 32; // the next load of this thread: 32 pixels on
+            const int wrap = ww >= HALO_W - 1 ? 1 : 0;
+            ww -= wrap ? HALO_W : 0;
+            hh += wrap;
+        }
+    };
+    // Loads of ONE wave return in order, but its stores retire independently, so a counted wait is only exact where nothing
+    // but loads is younger than the loads waited for.  Order per tile: barrier -> issue tile+2 -> multiply tile -> wait until
+    // only tile+2's loads are outstanding (tile+1 has landed; the stores of the tile before retired during the multiply)
+    // -> store tile.  The barrier then makes every wave's part of tile+1 visible and frees the buffer tile+3 goes into.
+#define WAIT_ALL_BUT_LAST_FETCH()                                                        \
+    do {                                                                                 \
+        if (wv < (HALO_PIECES % 256 + 63) / 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFETCH) : "memory");     \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFETCH - 1) : "memory");             \
+    } while (0)
+    static_assert(HALO_PIECES % 256 != 0, "the last fetch instruction is issued by the first (HALO_PIECES % 256 + 63) / 64 waves only");
+    int tile = (int)blockIdx.x;
+    Cursor cur = {tile % tiles_w, (tile / tiles_w) % tiles_h, tile / (tiles_w * tiles_h)}, ahead = cur;
+    if (tile < n_tiles) fetch(ahead, 0);
+    advance(ahead);
+    if (tile + stride < n_tiles) {
+        fetch(ahead, 1);
+        WAIT_ALL_BUT_LAST_FETCH();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    advance(ahead); // two tiles ahead of `cur` from here on
+    for (int it = 0; tile < n_tiles; tile += stride, it++, advance(cur), advance(ahead)) {
+        __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
+        if (tile + 2 * stride < n_tiles) fetch(ahead, (it + 2) % NBUF); // into the buffer of the tile before
+        const int tw = cur.tw, th = cur.th;
+        const long n = cur.n;
+        f32x16 acc[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) acc[r] = f32x16{};
+        // 48 distinct fragments (4 input rows x 3 tap columns x 4 channel blocks) for 72 MFMAs, as in the kernel above
+        // fragment u = (input row ir, tap column sx, channel block kc): pixel (rg*RPW + ir) * 34 + px + sx, block 2*kc + khalf ->
+        // slot (block + pixel) & 7 = (L + K) & 7 with L = the lane's part and K = 2*kc + sx + 2*ir (34 = 2 mod 8) compile-time
+        unsigned rb[8];
+        {
+            const unsigned bbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xl +
+                                   2u * (unsigned)((it % NBUF) * ABUF + (rg * RPW * HALO_W + px) * APIX);
+            const int L = 2 * RPW * rg + px + khalf;
+#pragma unroll
+            for (int m = 0; m < 8; m++) rb[m] = bbase + 16u * (unsigned)((L + m) & 7);
+        }
+#define LDS_BA(dst, u)                                                                                                 \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                       \
+                 : "=v"(dst)                                                                                           \
+                 : "v"(rb[(2 * ((u) & 3) + ((u) / 4) % 3 + 2 * ((u) / 12)) & 7]), "n"(2 * ((((u) / 12) * HALO_W + ((u) / 4) % 3) * APIX)))
+        bf16x8 bb[2];
+        LDS_BA(bb[0], 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[0]));
+#pragma unroll
+        for (int u = 0; u < 48; u++) {
+            if (u + 1 < 48) LDS_BA(bb[(u + 1) & 1], u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
+            if (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[u & 1], acc[0], 0, 0, 0);
+            if (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[u & 1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < 48) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[(u + 1) & 1]));
+        }
+#undef LDS_BA
+        if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        conv64_epilogue<POOL>(acc, y, shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
+    }
+#undef WAIT_ALL_BUT_LAST_FETCH
+}
+
+#ifndef CONV_ASYNC
+#define CONV_ASYNC 1
+#endif
+#if CONV_ASYNC
+#define CONV_FWD_KERNEL conv3x3_c64_fwd_async_kernel
+#else
+#define CONV_FWD_KERNEL conv3x3_c64_fwd_kernel
+#endif
 
 } // namespace
 
@@ -205,7 +420,7 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
-    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+    hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
                        (const unsigned short *)nullptr, 0);
     return hipGetLastError() == hipSuccess ? 0 : -6;
@@ -218,7 +433,7 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
-    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+    hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
@@ -232,7 +447,7 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, 
         return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
-    hipLaunchKernelGGL(conv3x3_c64_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+    hipLaunchKernelGGL(CONV_FWD_KERNEL<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
