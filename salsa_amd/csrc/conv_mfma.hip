@@ -382,18 +382,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     asm volatile("ds_read_b128 %0, %1 offset:%2"                                                                       \
                  : "=v"(dst)                                                                                           \
                  : "v"(rb[(2 * ((u) & 3) + ((u) / 4) % 3 + 2 * ((u) / 12)) & 7]), "n"(2 * ((((u) / 12) * HALO_W + ((u) / 4) % 3) * APIX)))
-        bf16x8 bb[2];
-        LDS_BA(bb[0], 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[0]));
+#ifndef CONV_ADEPTH
+#define CONV_ADEPTH 1 // 1 and 2 measured the same, 3 slower (spills): LDS latency is not what this loop waits for
+#endif
+        constexpr int AD = CONV_ADEPTH, RING = AD + 1; // fragments in flight ahead of the one being multiplied
+        bf16x8 bb[RING];
+#pragma unroll
+        for (int u = 0; u < AD; u++) LDS_BA(bb[u % RING], u);
 #pragma unroll
         for (int u = 0; u < 48; u++) {
-            if (u + 1 < 48) LDS_BA(bb[(u + 1) & 1], u + 1);
+            if (u + AD < 48) LDS_BA(bb[(u + AD) % RING], u + AD);
+            // fragment u has landed when at most the younger reads are outstanding
+            if (u + AD < 48) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bb[u % RING]) : "n"(AD));
+            else if (47 - u == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bb[u % RING]));
+            else if (47 - u == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bb[u % RING]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[u % RING]));
             __builtin_amdgcn_sched_barrier(0);
             const int ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
-            if (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[u & 1], acc[0], 0, 0, 0);
-            if (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[u & 1], acc[1], 0, 0, 0);
+            if (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[u % RING], acc[0], 0, 0, 0);
+            if (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[u % RING], acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < 48) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[(u + 1) & 1]));
         }
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
