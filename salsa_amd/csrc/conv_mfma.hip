@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #ifndef CONV_ASYNC
 #define CONV_ASYNC 1
 #endif
+#ifndef CONV_BIG_GRID
+#define CONV_BIG_GRID 1024 // persistent workgroups for large inputs (two resident per CU)
+#endif
 #if CONV_ASYNC
 #define CONV_FWD_KERNEL conv3x3_c64_fwd_async_kernel
 #else
@@ -427,7 +430,7 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
     if (!x || !w || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
                        (const unsigned short *)nullptr, 0);
@@ -440,7 +443,7 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
 {
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
@@ -454,7 +457,7 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, 
         N * H * W >= INT32_MAX / CH)
         return -1;
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 1024 : tiles >= 512 ? 512 : tiles);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
