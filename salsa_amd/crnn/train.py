@@ -61,7 +61,9 @@ class Trainer:
                 from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
                 model.register_comm_hook(None, default_hooks.bf16_compress_hook)       # halves the bytes on xGMI
         self.model = model
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=LRS[0])
+        # one fused kernel per parameter group on the GPU (same update rule; SALSA_FUSED_ADAM=0 -> torch's foreach path)
+        fused = self.device.type == 'cuda' and os.environ.get('SALSA_FUSED_ADAM', '1') == '1'
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=LRS[0], fused=fused)
 
     def _input_layout(self, x):
         """channels-last for MIOpen -- unless the first layer runs the stem kernel, which reads the extractor's planar
