@@ -234,6 +234,24 @@ def test_mfma_conv3x3_c64_matches_torch_forward_and_gradients():
     assert y32.dtype == torch.float32 and not isinstance(y32.grad_fn, _Conv3x3C64._backward_cls)
 
 
+def test_mfma_conv_many_tiles_per_workgroup_and_determinism():
+    """The persistent 64 -> 64 kernel rotates three LDS tiles with loads two tiles ahead: a shape that gives every workgroup ~20
+    tiles (and one that gives most of them a single tile), against float32 convolution of the same bf16 operands, and bit-equal
+    repeated launches (a race in the rotation would show as a sporadic difference)."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(12)
+    for n, h, w_ in ((16, 640, 100), (2, 40, 300), (1, 1, 1)):
+        x = torch.randn((n, 64, h, w_), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn((64, 64, 3, 3), device=dev, generator=g) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = nn_ops._conv64(x, w)
+        for _ in range(3):
+            assert torch.equal(nn_ops._conv64(x, w), y)
+        ref = F.conv2d(x.float(), w.float(), padding=1)
+        torch.testing.assert_close(y.float(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * float(ref.abs().max()))
+
+
 def test_stem_conv_kernel_matches_torch():
     """salsa_nn_conv3x3_stem (7 -> 64 on float32 planar input): plain forward and weight gradient through Conv3x3 under bf16
     autocast against F.conv2d on the bf16-rounded operands in float32; the folded-BatchNorm + ReLU epilogue (eval) against
