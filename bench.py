@@ -1,13 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- SALSA feature-extraction throughput on N MI355X (BASELINE.json config 2).
+"""bench.py -- BASELINE.json's two-part metric on N MI355X: SALSA feature-extraction audio-s/s (config 2, the headline
+`value`) and CRNN training clips/s (config 3, the `crnn` object of the same JSON line).
 
-A step = one pass of the hot path (STFT -> log-spectrogram + noise gate + 4x4 covariance -> principal eigenvector)
-over one batch of 32 synthetic 60-s 4-channel 24-kHz clips already resident in HBM, FOA parameters (fmax_doa 9000,
-cond 5, tracking on, high-frequency compression on), output [32][7][4801][200] float32 in HBM.  Clips shard across
-ranks with no collective on the data path (weak scaling: 32 clips per GPU).  Prints ONE JSON line on rank 0.
+Feature step = one pass of the hot path (STFT -> log-spectrogram + noise gate + 4x4 covariance -> principal
+eigenvector) over one batch of 32 synthetic 60-s 4-channel 24-kHz clips already resident in HBM, FOA parameters
+(fmax_doa 9000, cond 5, tracking on, high-frequency compression on), output [32][7][4801][200] float32 in HBM.  Clips
+shard across ranks with no collective on the data path (weak scaling: 32 clips per GPU).  The K-step timed block
+(barrier + synchronize on both sides, MAX over ranks) is repeated `--blocks` times and the MEDIAN block is reported
+(box-to-box and run-to-run spread of a 24-ms region is several percent); every block's time is in `blocks_ms`.
+
+CRNN step (after the feature path, its own timed region) = forward + loss + backward + Adam on 32 chunks (7,640,200) per
+GPU, bf16 autocast, torch DDP over RCCL for N > 1 (bench_crnn.train_bench).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 8            # no launcher needed: re-executes itself under torch.distributed.run, one rank per GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -21,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+F64_VALU_PEAK_TFLOPS = 78.6  # float64 vector peak, same guide (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
 
 def _clip(args):
@@ -50,7 +59,8 @@ def algorithmic_bytes(batch, n_samples, T, F):
 
 def cpu_baseline(feature, fmt, fmax, n_samples):
     """The oracle (CPU restatement of the reference) timed on this host's cores on a bounded sample of the same
-    workload (one 60-s clip per worker process, <= 32 workers).  Reported beside the GPU number, never the target."""
+    workload (one 60-s clip per single-threaded worker process; all cores, and 32 cores).  Reported beside the GPU
+    number, never the target."""
     from oracle import cpu_bench
     return cpu_bench.run(feature, fmt, fmax, n_samples)
 
@@ -60,16 +70,23 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps steps; the median block is reported')
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU per step')
     ap.add_argument('--seconds', type=float, default=60.0)
     ap.add_argument('--feature', default='salsa', choices=['salsa', 'salsa_lite', 'salsa_ipd'])
     ap.add_argument('--format', default=None, choices=['foa', 'mic'])
     ap.add_argument('--fmax-doa', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-crnn', action='store_true', help='skip the CRNN-training half of the metric')
+    ap.add_argument('--crnn-steps', type=int, default=20)
+    ap.add_argument('--crnn-warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=1, help='extra leg: K steps round-robin over this many HIP streams / plans (reported as pipelined, never `value`)')
     ap.add_argument('--pcie', action='store_true', help='also time host->device->extract->device->host (reported, never `value`)')
     ap.add_argument('--groups', type=int, default=0, help='clip-group pipelining depth (0 = library default)')
     args = ap.parse_args()
+
+    from bench_crnn import self_spawn, train_bench
+    self_spawn(args.gpus, __file__)           # `--gpus N` without a launcher: become N ranks (does not return then)
 
     fmt = args.format or ('foa' if args.feature == 'salsa' else 'mic')
     fmax = args.fmax_doa or (9000 if args.feature == 'salsa' and fmt == 'foa' else 4000 if args.feature == 'salsa' else 2000)
@@ -88,9 +105,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
+        rccl_ranks = dist.get_world_size()          # read back from the process group, not from the command line
 
     ex = SalsaExtractor(audio_format=fmt, feature_type=args.feature, fmax_doa=fmax, device=dev)
     if args.groups:
@@ -105,20 +124,24 @@ def main():
 
     for _ in range(args.warmup):
         ex.extract(audio, out=out)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ex.extract(audio, out=out)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ex.extract(audio, out=out)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        block_s.append(el)
+    elapsed = float(np.median(block_s))             # the median K-step block (max over ranks within each block)
 
     # per-kernel durations: HIP events recorded by the library on the launch stream, separate pass (not in `value`)
     kernels = []
@@ -127,7 +150,7 @@ def main():
     pcie = None
     pipelined = None
     if rank == 0:
-        ex.set_timing(True)
+        ex.set_timing(True)                          # (timing mode issues the kernels back to back on one stream)
         tot, cnt, n_t = {}, {}, max(3, min(args.steps, 10))
         for _ in range(n_t):
             ex.extract(audio, out=out)
@@ -139,23 +162,27 @@ def main():
         if args.feature != 'salsa':
             ab = {'stft_logspec': args.batch * (4 * n_samples * 4 + 7 * T * F * 4)}
         for name in tot:
-            launches = cnt[name] // n_t                      # launches per step (one per clip group)
+            launches = cnt[name] // n_t                      # launches per step
             ms = tot[name] / cnt[name]                       # average duration of ONE launch
             b = ab.get(name, 0) / launches                   # algorithmic bytes ONE launch moves
             kernels.append({'name': name, 'launches_per_step': launches, 'ms_per_launch': round(ms, 4),
                             'algorithmic_bytes_per_launch': int(b),
-                            'GBps': round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None})
-        # measured HBM bytes per launch (rocprofv3 PMC, collected offline by tools/pmc_round.sh + tools/pmc_traffic.py:
-        # counters cannot be sampled from inside this process); only valid for the batch size they were taken at
-        traffic = {}
+                            'GBps': round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                            'frac': round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None})
+        # measured HBM bytes and VALU utilisation per launch (rocprofv3 PMC, collected offline by tools/pmc_round.sh +
+        # tools/pmc_traffic.py: counters cannot be sampled from inside this process); only valid for the batch size and
+        # kernel version they were taken at (profiles/traffic.json names both)
+        traffic, valu = {}, {}
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
             if tj.get('batch_clips_per_launch') == args.batch and args.feature == 'salsa' and abs(args.seconds - 60) < 1e-9:
                 traffic = {k: v['hbm_bytes'] for k, v in tj['kernels'].items()}
+                valu = {k: v.get('valu_util') for k, v in tj['kernels'].items()}
         except Exception:
             pass
         for k in kernels:
             k['traffic'] = traffic.get(k['name'])
+            k['f64_valu_util'] = valu.get(k['name'])
         # the box's attainable HBM rate ("confirm with a device copy and use the measured peak as denominator too")
         a1 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         a2 = torch.empty_like(a1)
@@ -168,22 +195,25 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 10 * 2 * a1.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a1, a2
-        # dominant kernel = most time per step; kernels within 3 % of it are a tie (STFT and eigen kernels are, and would swap
-        # run to run), broken by algorithmic bytes so that the headline fraction names the same kernel every run
+        # headline fraction = the WHOLE path (49 925 600 B per clip x B / step time / 8 TB/s); every kernel's
+        # own figure is in `kernels`, and `dominant` names the kernel with the most time per step (no tie-breaking rule)
         t_of = lambda k: k['ms_per_launch'] * k['launches_per_step']
-        t_max = max(t_of(k) for k in kernels)
-        dom = max((k for k in kernels if t_of(k) >= 0.97 * t_max), key=lambda k: k['algorithmic_bytes_per_launch'])
+        dom = max(kernels, key=t_of)
         step_ms = 1e3 * elapsed / args.steps
         pipe_bytes = sum(ab.values())
-        roofline = {'bound': 'hbm', 'kernel': dom['name'], 'kernel_ms': dom['ms_per_launch'],
-                    'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(dom['GBps'] / HBM_PEAK_GBS, 4), 'traffic': dom.get('traffic'),
-                    'peak_measured': round(copy_gbs, 1), 'frac_of_measured': round(dom['GBps'] / copy_gbs, 4),
+        achieved = pipe_bytes / (step_ms * 1e-3) / 1e9
+        tr_known = [k['traffic'] * k['launches_per_step'] for k in kernels if k.get('traffic')]
+        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4),
+                    'traffic': int(sum(tr_known)) if len(tr_known) == len(kernels) and tr_known else None,
+                    'scope': 'whole step: algorithmic bytes of the path (%d) / median wall time per step' % pipe_bytes,
+                    'algorithmic_bytes': pipe_bytes, 'ms': round(step_ms, 4),
+                    'peak_measured': round(copy_gbs, 1), 'frac_of_measured': round(achieved / copy_gbs, 4),
                     'peak_measured_note': '1 GiB device-to-device copy, read + write bytes / time',
-                    'pipeline': {'ms': round(step_ms, 4), 'algorithmic_bytes': pipe_bytes,
-                                 'achieved': round(pipe_bytes / (step_ms * 1e-3) / 1e9, 1),
-                                 'frac': round(pipe_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 'note': 'whole step (all kernels, wall clock of the timed region)'},
+                    'dominant': {'kernel': dom['name'], 'ms_per_launch': dom['ms_per_launch'], 'achieved': dom['GBps'],
+                                 'frac': dom['frac'], 'traffic': dom.get('traffic')},
+                    'secondary_bound': {'unit': 'fraction of float64 VALU issue cycles (peak %.1f TFLOP/s)' % F64_VALU_PEAK_TFLOPS,
+                                        'per_kernel': {k['name']: k['f64_valu_util'] for k in kernels}},
                     'kernels': kernels}
         if args.streams > 1:
             # independent batches on separate streams: the latency-bound tracker of one step hides under the STFT /
@@ -237,8 +267,20 @@ def main():
             pcie['overlapped'] = {'ms_per_step': round(1e3 * tp, 3), 'audio_s_per_s': round(args.batch * args.seconds / tp, 1),
                                   'note': 'HostPipeline(depth=3): pinned host slot -> device -> features -> pinned host slot, the transfers of neighbouring batches overlapped on separate streams'}
             del pipe
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
+
+    # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the DDP run)
+    del ex, audio, out
+    torch.cuda.empty_cache()
+    crnn = None
+    if not args.no_crnn and args.feature == 'salsa':
+        try:
+            crnn = train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup)
+        except Exception as e:                                   # the feature line must survive a CRNN failure
+            if world > 1:
+                raise
+            crnn = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
 
     if world > 1:
         dist.barrier()
@@ -251,9 +293,12 @@ def main():
         'value': round(audio_s / elapsed, 1),
         'unit': 'audio-seconds/s',
         'n_gpus': world,
+        'rccl_ranks': rccl_ranks,
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+        'blocks_ms': [round(1e3 * b / args.steps, 4) for b in block_s],
+        'blocks_note': 'ms per step of each timed %d-step block (max over ranks); value / ms_per_step = the median block' % args.steps,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -268,6 +313,7 @@ def main():
                    'clip_groups': args.groups or 'default'},
         'roofline': roofline,
         'cpu_baseline': cpu,
+        'crnn': crnn,
     }
     if pcie:
         line['pcie_inclusive'] = pcie

@@ -18,6 +18,23 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def self_spawn(n_gpus: int, script: str) -> None:
+    """`python <script> --gpus N` with no torch.distributed environment: become N ranks (one process per GPU, RCCL) by
+    re-executing this command under torch.distributed.run on a free loopback port.  Does not return when it spawns."""
+    if n_gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(script)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARCH.md
 GFLOP_PER_CHUNK_FWD = 44.74 + 0.19       # conv + GRU forward per 8-s chunk (SURVEY.md section 3.3, probed)
 
@@ -82,6 +99,73 @@ def infer_bench(args, rank, world, dev, tr):
                                'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}}))
 
 
+def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False):
+    """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
+    `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 torch DDP = bucketed gradient all-reduce on RCCL
+    overlapped with the backward.  The process group must already be initialised for world > 1.  Every rank calls this;
+    rank 0 gets the result dict, the others None."""
+    import torch
+    import torch.distributed as dist
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+
+    tr = Trainer(dev, bf16_grad_allreduce=not fp32_grads)
+    x, sed, doa = synthetic_batch(batch, dev, seed=2021 + rank)
+    ex, audio = None, None
+    if on_the_fly:
+        from salsa_amd.extractor import SalsaExtractor
+        ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
+        audio = 0.1 * torch.randn(batch, 4, 8 * 24000, device=dev, generator=torch.Generator(dev).manual_seed(rank))
+    aug_gen = torch.Generator().manual_seed(2021 + rank)
+
+    def step():
+        xb, sb, db = x, sed, doa
+        if ex is not None:
+            xb = ex.extract(audio)[:, :, :640]                      # (B,7,641,200) -> 640 frames
+        if augment:
+            from salsa_amd.augment import augment_batch
+            xb, sb, db = augment_batch(xb, sb, db, 'mic' if ex is not None else 'foa', gen=aug_gen)
+        return tr.train_step(xb, sb, db)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ranks = 1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ranks = dist.get_world_size()
+    if rank != 0:
+        return None
+    from salsa_amd.crnn import nn_ops
+    clips = world * batch * steps
+    cps = clips / elapsed
+    tflops = 3 * GFLOP_PER_CHUNK_FWD * cps / 1e3                     # fwd + bwd ~ 3x forward
+    return {
+        'metric': 'CRNN train clips/s', 'value': round(cps, 1), 'unit': '8-s chunks/s', 'n_gpus': world,
+        'rccl_ranks': ranks, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,640,200), batch %d per GPU, Adam'
+                               % ('on-the-fly extracted MIC' if on_the_fly else 'precomputed-FOA-shaped', batch)
+                               + (' + device augmentation' if augment else ''),
+                   'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if fp32_grads else 'bf16'},
+        'roofline': {'bound': 'mfma', 'achieved': round(tflops / world, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(tflops / world / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                     'note': 'per GPU; 134.8 GFLOP per chunk (3x the 44.93 GFLOP forward); convolutions: %s' % nn_ops.conv_backend_note()},
+        'final_loss': float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -96,13 +180,13 @@ def main():
     ap.add_argument('--sub-batch', type=int, default=32,
                     help='--infer: clips per extraction + CRNN forward (config 5 says 32; 8 gives a third of the latency at 77 %% of the rate)')
     args = ap.parse_args()
+    self_spawn(args.gpus, __file__)                                  # --gpus N without a launcher: become N ranks
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
 
     import torch
     import torch.distributed as dist
-    from salsa_amd.crnn.train import Trainer, synthetic_batch
 
     assert torch.cuda.is_available(), 'bench_crnn.py needs an MI355X'
     torch.cuda.set_device(local_rank)
@@ -110,64 +194,14 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
-    tr = Trainer(dev, bf16_grad_allreduce=not args.fp32_grads)
-    x, sed, doa = synthetic_batch(args.batch, dev, seed=2021 + rank)
-    ex, audio = None, None
-    if args.on_the_fly:
-        from salsa_amd.extractor import SalsaExtractor
-        ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
-        audio = 0.1 * torch.randn(args.batch, 4, 8 * 24000, device=dev, generator=torch.Generator(dev).manual_seed(rank))
-
     if args.infer:
-        return infer_bench(args, rank, world, dev, tr)
-
-    aug_gen = torch.Generator().manual_seed(2021 + rank)
-
-    def step():
-        xb, sb, db = x, sed, doa
-        if ex is not None:
-            xb = ex.extract(audio)[:, :, :640]                      # (B,7,641,200) -> 640 frames
-        if args.augment:
-            from salsa_amd.augment import augment_batch
-            xb, sb, db = augment_batch(xb, sb, db, 'mic' if ex is not None else 'foa', gen=aug_gen)
-        return tr.train_step(xb, sb, db)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+        from salsa_amd.crnn.train import Trainer
+        return infer_bench(args, rank, world, dev, Trainer(dev))
+    line = train_bench(rank, world, dev, args.batch, args.steps, args.warmup, args.on_the_fly, args.augment, args.fp32_grads)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()[0]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         dist.destroy_process_group()
-    if rank != 0:
-        return
-    clips = world * args.batch * args.steps
-    cps = clips / elapsed
-    tflops = 3 * GFLOP_PER_CHUNK_FWD * cps / 1e3                     # fwd + bwd ~ 3x forward
-    print(json.dumps({
-        'metric': 'CRNN train clips/s', 'value': round(cps, 1), 'unit': '8-s chunks/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,640,200), batch %d per GPU, Adam'
-                               % ('on-the-fly extracted MIC' if args.on_the_fly else 'precomputed-FOA-shaped', args.batch)
-                               + (' + device augmentation' if args.augment else ''),
-                   'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if args.fp32_grads else 'bf16'},
-        'roofline': {'bound': 'mfma', 'achieved': round(tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                     'note': '134.8 GFLOP per chunk (3x the 44.93 GFLOP forward); 64-channel convs on our MFMA kernels, wider ones in MIOpen via torch'},
-        'final_loss': float(loss)}))
+    if line is not None:
+        print(json.dumps(line))
 
 
 if __name__ == '__main__':

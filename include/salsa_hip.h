@@ -161,6 +161,12 @@ int salsa_plan_read_timing(salsa_plan *plan, float *ms, const char **names, int 
  * the caller's stream only. */
 int salsa_plan_set_groups(salsa_plan *plan, int n_groups);
 
+/* Diagnostic: the kernels' float32 dB conversion 10*log10(max(1e-10, p)) (librosa.power_to_db(ref=1, amin=1e-10, top_db=None),
+ * salsa_feature_extraction.py:194-195) applied elementwise to d_power[n] -> d_db[n].  It is the SAME device function the STFT
+ * kernel inlines (hardware v_log_f32 times a constant); exported so a test can bound its error over the whole float32
+ * exponent range instead of over whatever dynamic range a test clip happens to have. */
+int salsa_selftest_decibel(const float *d_power, float *d_db, int64_t n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,10 @@ import torch
 from .. import _lib
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t):
+    """the current stream of the tensor's device (launches are also wrapped in torch.cuda.device(t.device): the kernels
+    must run on the GPU that owns the pointers even when another device is current)"""
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 REGISTER_WEIGHTS = os.environ.get('SALSA_GRU_REGW', '1') != '0'
@@ -23,9 +25,10 @@ def _scan_inference(gi, whh, bhh):
     T, B, D, H3 = gi.shape
     H = H3 // 3
     hs = torch.empty((T, B, D, H), dtype=torch.float32, device=gi.device)
-    rc = _lib.load().salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.detach().contiguous().data_ptr()),
-                                             C.c_void_p(bhh.detach().contiguous().data_ptr()), C.c_void_p(hs.data_ptr()),
-                                             None, T, B, D, H, _stream())
+    with torch.cuda.device(gi.device):
+        rc = _lib.load().salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.detach().contiguous().data_ptr()),
+                                                 C.c_void_p(bhh.detach().contiguous().data_ptr()), C.c_void_p(hs.data_ptr()),
+                                                 None, T, B, D, H, _stream(gi))
     if rc:
         raise RuntimeError('salsa_gru_scan_fwd_regw failed (%d)' % rc)
     return hs
@@ -44,13 +47,14 @@ class _GruScan(torch.autograd.Function):
         need_grad = gi.requires_grad or whh.requires_grad or bhh.requires_grad
         saved = torch.empty((T, B, D, 4 * H), dtype=torch.float32, device=gi.device) if need_grad else None
         sv = C.c_void_p(saved.data_ptr() if saved is not None else 0)
-        if half_weights:
-            rc = L.salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
-                                           C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream())
-        else:
-            whh_t = whh.transpose(1, 2).contiguous()
-            rc = L.salsa_gru_scan_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh_t.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
-                                      C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream())
+        with torch.cuda.device(gi.device):
+            if half_weights:
+                rc = L.salsa_gru_scan_fwd_regw(C.c_void_p(gi.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
+                                               C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream(gi))
+            else:
+                whh_t = whh.transpose(1, 2).contiguous()
+                rc = L.salsa_gru_scan_fwd(C.c_void_p(gi.data_ptr()), C.c_void_p(whh_t.data_ptr()), C.c_void_p(bhh.contiguous().data_ptr()),
+                                          C.c_void_p(hs.data_ptr()), sv, T, B, D, H, _stream(gi))
         if rc:
             raise RuntimeError('salsa_gru_scan_fwd failed (%d)' % rc)
         if need_grad:
@@ -67,8 +71,9 @@ class _GruScan(torch.autograd.Function):
         dgi = torch.empty((T, B, D, 3 * H), dtype=torch.float32, device=hs.device)
         dgh = torch.empty_like(dgi)
         scan = L.salsa_gru_scan_bwd_regw if ctx.half_weights else L.salsa_gru_scan_bwd
-        rc = scan(C.c_void_p(dhs.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(hs.data_ptr()),
-                  C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()), T, B, D, H, _stream())
+        with torch.cuda.device(hs.device):
+            rc = scan(C.c_void_p(dhs.data_ptr()), C.c_void_p(whh.data_ptr()), C.c_void_p(hs.data_ptr()),
+                      C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()), T, B, D, H, _stream(hs))
         if rc:
             raise RuntimeError('salsa_gru_scan_bwd failed (%d)' % rc)
         hprev = torch.zeros_like(hs)                       # h before each step, per direction's scan order
@@ -82,8 +87,10 @@ class _GruScan(torch.autograd.Function):
 
 def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weights: bool = False) -> torch.Tensor:
     """x (B,T,In) float32 CUDA -> (B,T,2H); equivalent to ``gru(x)[0]`` for a batch_first bidirectional nn.GRU.
-    half_weights (the caller is under bf16 autocast): train through the register-resident kernels, i.e. with W_hh rounded to
-    float16 in the recurrence -- finer than the bf16 autocast would give nn.GRU; without gradients they are always used."""
+    half_weights (the caller is under bf16 autocast): run the register-resident kernels, i.e. with W_hh rounded to float16
+    in the recurrence -- finer than the bf16 autocast would give nn.GRU -- for training and for the no-gradient forward
+    alike.  A float32 caller (half_weights=False) gets the float32 streaming kernels in both modes, so pure-float32
+    evaluation matches float32 training and the reference's nn.GRU."""
     assert gru.batch_first and gru.bidirectional and gru.bias
     out = x
     for layer in range(gru.num_layers):
@@ -96,7 +103,8 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weigh
             out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
         gi = torch.einsum('bti,dgi->tbdg', out, wih) + bih                          # (T,B,D,3H)
         gi = gi.contiguous()
-        if REGISTER_WEIGHTS and whh.shape[2] == 256 and not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad)):
+        no_grad = not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad))
+        if REGISTER_WEIGHTS and half_weights and whh.shape[2] == 256 and no_grad:
             hs = _scan_inference(gi, whh, bhh)                                      # W_hh (float16) resident in registers
         else:
             hs = _GruScan.apply(gi, whh, bhh, bool(half_weights and REGISTER_WEIGHTS and whh.shape[2] == 256))   # (T,B,D,H)

@@ -19,6 +19,13 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def conv_backend_note() -> str:
+    """Which convolution layers run on the hand-written MFMA kernels (for the bench lines)."""
+    if not USE_HIP_CONV:
+        return 'all on MIOpen through torch (SALSA_HIP_CONV=0)'
+    return 'stem 7->64 and the five 64->64 3x3 layers on the hand-written MFMA kernels (conv_mfma.hip), the 128/256/512-channel layers on MIOpen through torch'
+
+
 class _AvgPool2x2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

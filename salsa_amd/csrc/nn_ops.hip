@@ -464,6 +464,7 @@ static int bn_geometry_ok(int dtype, int64_t M, int C)
     const int L = dtype == 1 ? 8 : 4;
     if ((dtype != 0 && dtype != 1) || M <= 0 || C <= 0 || C % L) return 0;
     const int cv = C / L;
+    if ((int64_t)M * C >= ((int64_t)1 << 32)) return 0; // element offsets are 32-bit unsigned inside the kernels
     return cv <= 256 && (cv & (cv - 1)) == 0; // a block is (256/cv) rows x cv column groups
 }
 #ifndef BN_MAX_BLOCKS

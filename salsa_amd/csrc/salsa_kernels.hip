@@ -851,6 +851,12 @@ __global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ 
     for (int c = 0; c < 7; c++) dst[c * plane] = x[c];
 }
 
+__global__ __launch_bounds__(256) void db10_kernel(const float *__restrict__ p, float *__restrict__ o, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = db10(p[i]);
+}
+
 } // namespace
 
 // ================================================================================================== plan + C ABI
@@ -1376,6 +1382,14 @@ int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_c
     hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)hip_stream,
                        d_in, (long)in_batch_stride, (long)in_channel_stride, d_out, (int)n_frames, n_freq, audio_format,
                        n_zero_channels, d_params, d_uval, d_minmax);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_selftest_decibel(const float *d_power, float *d_db, int64_t n, void *hip_stream)
+{
+    if (!d_power || !d_db || n <= 0 || (n + 255) / 256 >= INT32_MAX) return fail(SALSA_EINVAL, "salsa_selftest_decibel: bad argument%s");
+    hipLaunchKernelGGL(db10_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, d_power, d_db, (long)n);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }

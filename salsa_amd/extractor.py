@@ -119,8 +119,9 @@ class SalsaExtractor:
             assert out.shape == (B, Cn, T, F) and out.dtype == torch.float32 and out.is_contiguous() and out.is_cuda
         nws = self.workspace_bytes(B, N)
         ws = self._workspace(nws)
-        rc = self.L.salsa_extract_batch(self._plan, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(out.data_ptr()),
-                                        C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        with torch.cuda.device(self.device):        # the plan's device must be current for the launches
+            rc = self.L.salsa_extract_batch(self._plan, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         if rc:
             _raise(rc)
         return out
@@ -136,8 +137,9 @@ class SalsaExtractor:
         F = ((200 if n_fft == 512 else 100) if self.params.is_compress_high_freq else n_fft // 2)
         T = 1 + N // self.params.hop_len
         out = torch.empty((B, 4, T, F), dtype=torch.float32, device=audio.device)
-        rc = self.L.salsa_logspec_batch(self._plan, C.c_void_p(audio.data_ptr()), B, 4, N,
-                                        C.c_void_p(out.data_ptr()), self._stream())
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_logspec_batch(self._plan, C.c_void_p(audio.data_ptr()), B, 4, N,
+                                            C.c_void_p(out.data_ptr()), self._stream())
         if rc:
             _raise(rc)
         return out
@@ -150,9 +152,10 @@ class SalsaExtractor:
         gate = torch.empty((B, nb, nt), dtype=torch.uint8, device=X.device)
         nws = int(self.L.salsa_eigvec_workspace_bytes(self._plan, B, nb, nt))
         ws = self._workspace(nws)
-        rc = self.L.salsa_eigvec_batch(self._plan, C.c_void_p(X.data_ptr()), B, nb, nt, int(lower_bin),
-                                       C.c_void_p(out.data_ptr()), C.c_void_p(gate.data_ptr()),
-                                       C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_eigvec_batch(self._plan, C.c_void_p(X.data_ptr()), B, nb, nt, int(lower_bin),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(gate.data_ptr()),
+                                           C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
         if rc:
             _raise(rc)
         return (out, gate) if return_gate else out
@@ -199,8 +202,10 @@ def scaler_accumulate(feat: torch.Tensor, sums: torch.Tensor = None, n_scaler_ch
     B, Cn, T, F = feat.shape
     if sums is None:
         sums = torch.zeros((2, n_scaler_channels, F), dtype=torch.float64, device=feat.device)
-    rc = _lib.load().salsa_scaler_accumulate(C.c_void_p(feat.data_ptr()), B, Cn, T, F, n_scaler_channels,
-                                             C.c_void_p(sums.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    with torch.cuda.device(feat.device):         # launch on the GPU that owns the pointers, whatever device is current
+        rc = _lib.load().salsa_scaler_accumulate(C.c_void_p(feat.data_ptr()), B, Cn, T, F, n_scaler_channels,
+                                                 C.c_void_p(sums.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream))
     if rc:
         _raise(rc)
     return sums
@@ -219,8 +224,10 @@ def normalize_(feat: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> tor
     B, Cn, T, F = feat.shape
     m = mean.reshape(-1, F).contiguous().float().to(feat.device)
     s = std.reshape(-1, F).contiguous().float().to(feat.device)
-    rc = _lib.load().salsa_normalize_batch(C.c_void_p(feat.data_ptr()), B, Cn, T, F, m.shape[0], C.c_void_p(m.data_ptr()),
-                                           C.c_void_p(s.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    with torch.cuda.device(feat.device):
+        rc = _lib.load().salsa_normalize_batch(C.c_void_p(feat.data_ptr()), B, Cn, T, F, m.shape[0], C.c_void_p(m.data_ptr()),
+                                               C.c_void_p(s.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream))
     if rc:
         _raise(rc)
     return feat
@@ -229,8 +236,9 @@ def normalize_(feat: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> tor
 class StreamedExtractor:
     """Bulk extraction of many independent batches: ``n_streams`` plans on their own HIP streams, fed round-robin, so
     the latency-bound noise-floor tracker of one batch overlaps the STFT / eigen kernels of its neighbours (+9 % on
-    MI355X with 2 streams).  ``extract_many`` yields the feature tensors in input order; each yielded tensor is only
-    valid until ``n_streams`` further batches have been produced (its buffer is then reused)."""
+    MI355X with 2 streams).  ``extract_many`` yields the feature tensors in input order.  A yielded tensor is valid ONLY
+    UNTIL THE GENERATOR IS ADVANCED AGAIN: the next pull launches a new batch into the same buffer.  Clone it (or finish
+    with it) before calling next()."""
 
     def __init__(self, n_streams: int = 2, **extractor_kwargs):
         self.exs = [SalsaExtractor(**extractor_kwargs) for _ in range(n_streams)]
@@ -266,8 +274,9 @@ class HostPipeline:
     staging, device buffers, its own plan and its own copy-in / compute / copy-out streams, so the PCIe transfer of one batch
     in each direction overlaps the kernels of another (MI355X moves data in both directions at once).  ``run`` takes an
     iterable of float32 host arrays ``(B, 4, N)`` (or ``(B, N, 4)`` for interleaved plans) of ONE shape and yields float32
-    host feature arrays ``(B, 7, T, F)`` in order; a yielded array is a view of a pinned slot that is reused ``depth``
-    batches later -- copy it or finish with it before pulling that far ahead."""
+    host feature arrays ``(B, 7, T, F)`` in order.  A yielded array is a view of a pinned slot and is valid ONLY UNTIL THE
+    GENERATOR IS ADVANCED AGAIN: the next pull starts the following batch's round trip through that very slot (its
+    device-to-host copy will overwrite the view).  Copy it or finish with it before calling next()."""
 
     def __init__(self, depth: int = 3, **extractor_kwargs):
         self.depth = depth

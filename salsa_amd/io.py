@@ -18,7 +18,8 @@ except Exception:  # pragma: no cover - depends on the image
 
 def load_audio(path: str, sr: int) -> np.ndarray:
     """-> (n_channels, n_samples) float32 in [-1, 1), like librosa.load(path, sr=sr, mono=False, dtype=float32) on a
-    file whose native rate is ``sr`` (the TNSSE2021 clips are 24 kHz; resampling is not implemented)."""
+    file whose native rate is ``sr`` (the TNSSE2021 clips are 24 kHz).  librosa.load would RESAMPLE a file of another
+    rate (salsa_feature_extraction.py:353); this loader raises instead -- resample such files beforehand."""
     if path.endswith('.npy'):
         a = np.load(path)
         return np.ascontiguousarray(a, dtype=np.float32)
@@ -56,15 +57,32 @@ def save_arrays(path_h5: str, **arrays) -> str:
     return out
 
 
-def load_arrays(path_h5: str) -> dict:
-    if os.path.exists(path_h5) and HAVE_H5PY:
+def load_arrays(path: str) -> dict:
+    """Read a feature / scaler file by the container its EXTENSION names: ``.npz`` -> numpy, ``.h5`` -> h5py; a ``.h5``
+    name whose file is absent (or unreadable without h5py) falls back to its ``.npz`` twin."""
+    if path.endswith('.npz'):
+        z = np.load(path)
+        return {k: z[k] for k in z.files}
+    if os.path.exists(path) and HAVE_H5PY:
         import h5py
-        with h5py.File(path_h5, 'r') as hf:
+        with h5py.File(path, 'r') as hf:
             return {k: hf[k][:] for k in hf.keys()}
-    z = np.load(_alt(path_h5))
+    if os.path.exists(path) and not os.path.exists(_alt(path)):
+        raise RuntimeError('{} is HDF5 and h5py is not installed here (no .npz twin next to it)'.format(path))
+    z = np.load(_alt(path))
     return {k: z[k] for k in z.files}
 
 
 def feature_files(feature_dir: str):
-    """Sorted feature files of a split directory (either container)."""
-    return sorted(f for f in os.listdir(feature_dir) if f.endswith('.h5') or f.endswith('.npz'))
+    """Sorted feature files of a split directory, ONE name per clip: when both containers of a clip are present the
+    ``.h5`` is listed if h5py can read it, else the ``.npz``."""
+    by_stem = {}
+    for f in os.listdir(feature_dir):
+        stem, ext = os.path.splitext(f)
+        if ext not in ('.h5', '.npz'):
+            continue
+        cur = by_stem.get(stem)
+        prefer_h5 = HAVE_H5PY
+        if cur is None or (ext == '.h5') == prefer_h5:
+            by_stem[stem] = f
+    return sorted(by_stem.values())

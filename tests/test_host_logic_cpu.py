@@ -1,10 +1,12 @@
 """CPU tests of the host-side logic around the hot path (file naming, WAV reading, feature containers, CLI flags,
 error behaviour without a GPU).  No compute calls."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from salsa_amd import io as sio
 
 
@@ -76,3 +78,40 @@ def test_torch_op_is_registered_with_a_shape_function():
         assert tuple(torch.ops.salsa.extract(a, 'foa', 'salsa', 24000, 256, 150, 50, 9000, 5.0, 3, True, False).shape) == (3, 7, 321, 128)
     with pytest.raises(RuntimeError):
         torch.ops.salsa.extract(torch.zeros(1, 4, 4000))
+
+
+def test_bench_self_spawn_becomes_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (N ranks on loopback);
+    with WORLD_SIZE already set, or N = 1, it stays in-process."""
+    import bench_crnn
+    calls = []
+    monkeypatch.setattr(os, 'execv', lambda exe, argv: calls.append((exe, list(argv))))
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench_crnn.self_spawn(1, os.path.join(ROOT, 'bench.py'))
+    assert calls == []
+    bench_crnn.self_spawn(4, os.path.join(ROOT, 'bench.py'))
+    (exe, argv), = calls
+    assert exe == sys.executable and argv[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert argv[argv.index('--nproc-per-node') + 1] == '4' and argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+    assert 0 < int(argv[argv.index('--master-port') + 1]) < 65536
+    assert argv[-5:] == [os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '7']
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    bench_crnn.self_spawn(4, os.path.join(ROOT, 'bench.py'))
+    assert len(calls) == 1                                            # already a rank of a launched job
+
+
+def test_feature_files_dispatch_on_extension_and_one_name_per_clip(tmp_path):
+    from salsa_amd import io as sio
+    a = np.arange(12, dtype=np.float32).reshape(1, 3, 4)
+    np.savez(tmp_path / 'clip_b.npz', feature=a)
+    np.savez(tmp_path / 'clip_a.npz', feature=a + 1)
+    (tmp_path / 'clip_a.h5').write_bytes(b'not really hdf5')              # both containers of one clip present
+    (tmp_path / 'notes.txt').write_text('x')
+    names = sio.feature_files(str(tmp_path))
+    assert [os.path.splitext(n)[0] for n in names] == ['clip_a', 'clip_b']            # one entry per clip, sorted
+    if not sio.HAVE_H5PY:
+        assert names == ['clip_a.npz', 'clip_b.npz']
+    got = sio.load_arrays(str(tmp_path / 'clip_b.npz'))                  # an .npz name is read as .npz whatever is installed
+    assert np.array_equal(got['feature'], a)
+    assert np.array_equal(sio.load_arrays(str(tmp_path / 'clip_b.h5'))['feature'], a)  # .h5 name, only the twin exists
