@@ -155,10 +155,17 @@ int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_c
 int salsa_plan_set_timing(salsa_plan *plan, int enable);
 int salsa_plan_read_timing(salsa_plan *plan, float *ms, const char **names, int *n_out);
 
-/* Clip-group pipelining of salsa_extract_batch (default 1 = off; at most 8, capped at the batch size): the batch is cut into
- * n_groups clip ranges whose kernels run on plan-owned streams forked from / joined to the caller's stream, so the
- * latency-bound noise-floor tracker of one group overlaps the STFT / eigen kernels of the others.  1 = one group on
- * the caller's stream only. */
+/* Pipelined schedule of salsa_extract_batch (default: n_groups 1, flags 0 = three kernels in order on the caller's stream).
+ * n_groups > 1 (at most 16, capped at the batch size): the batch is cut into clip ranges whose kernels run on plan-owned
+ * streams forked from / joined to the caller's stream, so the latency-bound noise-floor tracker of one group overlaps the
+ * STFT / eigen kernels of the others.  SALSA_PIPE_SPLIT_PAIRS: the STFT of a group is two launches (channels 0/1, then 2/3)
+ * and the tracker, which only needs channel 0, starts after the first.  SALSA_PIPE_GRAPH: the fork/join is captured once per
+ * (buffers, sizes) into a plan-owned hipGraph and every later call with the same arguments is ONE hipGraphLaunch on the
+ * caller's stream (a call made while the caller's stream is itself being captured issues the fork/join eagerly, so it
+ * becomes part of the caller's graph).  Results are bit-identical under every schedule.  salsa_plan_set_groups(n) keeps
+ * the current flags. */
+enum { SALSA_PIPE_SPLIT_PAIRS = 1, SALSA_PIPE_GRAPH = 2 };
+int salsa_plan_set_pipeline(salsa_plan *plan, int n_groups, int flags);
 int salsa_plan_set_groups(salsa_plan *plan, int n_groups);
 
 /* Diagnostic: the kernels' float32 dB conversion 10*log10(max(1e-10, p)) (librosa.power_to_db(ref=1, amin=1e-10, top_db=None),

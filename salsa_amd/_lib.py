@@ -14,6 +14,7 @@ FORMAT = {'foa': 0, 'mic': 1}
 FEATURE = {'salsa': 0, 'salsa_lite': 1, 'salsa_ipd': 2}
 LAYOUT = {'planar': 0, 'interleaved': 1}
 FLAG_FLEX, FLAG_NO_CLIP_FREQS, FLAG_CLIP_SPATIAL_ALIAS = 1, 2, 4
+PIPE_SPLIT_PAIRS, PIPE_GRAPH = 1, 2
 MAX_KERNELS = 32
 
 E_INVAL, E_NFFT, E_FORMAT, E_BINS, E_WORKSPACE, E_HIP = -1, -2, -3, -4, -5, -6
@@ -61,6 +62,7 @@ def load():
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
     L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
+    L.salsa_plan_set_pipeline.argtypes = [vp, C.c_int, C.c_int]
     L.salsa_plan_set_scaler.argtypes = [vp, vp, vp]
     L.salsa_gru_scan_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_gru_scan_fwd_regw.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -97,7 +99,7 @@ def last_error() -> str:
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_plan_set_timing',
-           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
+           'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_plan_set_pipeline', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
            'salsa_to_freq_major', 'salsa_augment_batch', 'salsa_selftest_decibel']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_fwd_regw', 'salsa_gru_scan_bwd', 'salsa_gru_scan_bwd_regw']
 NN_EXPORTS = ['salsa_nn_avgpool2x2_fwd', 'salsa_nn_avgpool2x2_bwd', 'salsa_nn_conv3x3_c64', 'salsa_nn_conv3x3_c64_bias_act', 'salsa_nn_conv3x3_c64_wrw', 'salsa_nn_conv3x3_stem', 'salsa_nn_conv3x3_c64_bias_act_pool', 'salsa_nn_bn_supported', 'salsa_nn_bn_workspace_bytes', 'salsa_nn_bn_train_fwd',

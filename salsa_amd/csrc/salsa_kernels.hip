@@ -64,6 +64,7 @@ struct KParams {
     int format;
     int tracking;
     int n_hop;
+    int pair_sel;         // K1: -1 = both channel pairs of every frame in one launch; 0 / 1 = only channels {0,1} / {2,3}
     double cond;
     double inv_cond;      // 1/cond (0 when cond == 0: unused, cond <= 1 short-circuits the gate)
     double delta;         // 2 pi fs / (n_fft * 343)
@@ -120,7 +121,7 @@ template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : 4;
 };
 
-template <int N, typename T, bool LITE>
+template <int N, typename T, bool LITE, int NF>
 __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int Ns = kp.N, Tn = kp.T;
-    constexpr int K1_NF = k1_cfg<LITE>::NF;
+    constexpr int K1_NF = NF;
     const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
     cplx<T> *z = buf[w];
 
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     constexpr bool PAIR_MAJOR = !LITE;
 #endif
     const int nfr_ = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
-    auto item_frame = [&](int item) { return PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1; };
-    auto item_pair = [&](int item) { return PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1; };
+    const int psel = LITE ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
+    auto item_frame = [&](int item) { return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1; };
+    auto item_pair = [&](int item) { return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1; };
     auto load_item = [&](int item, float *y0, float *y1) {
         const int t = t_begin + item_frame(item);
         const int c0 = 2 * item_pair(item);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
         }
     };
 
-    const int nitems = nfr_ * 2;
+    const int nitems = psel >= 0 ? nfr_ : nfr_ * 2;
     float y0[R], y1[R];
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
     float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(256) void db10_kernel(const float *__restrict__ p, 
 } // namespace
 
 // ================================================================================================== plan + C ABI
-constexpr int SALSA_MAX_GROUPS = 8;
+constexpr int SALSA_MAX_GROUPS = 16;
 
 struct salsa_plan {
     salsa_params p;
@@ -875,12 +877,25 @@ struct salsa_plan {
     int n_kernels;
     hipEvent_t ev0[SALSA_MAX_KERNELS], ev1[SALSA_MAX_KERNELS]; // start/stop of each launch (timing mode only)
     const char *names[SALSA_MAX_KERNELS];
-    // clip-group pipeline: stream 0 runs the STFT kernels of all groups back to back; group g's tracker and
-    // covariance/eigen kernels run on stream 1+g, so the latency-bound tracker of one group hides under the
-    // STFT / eigen work of its neighbours.
+    // clip-group pipeline (salsa_plan_set_pipeline): stream 0 runs the STFT kernels of all groups back to back; group g's
+    // tracker and covariance/eigen kernels run on stream 1+g, so the latency-bound tracker of one group hides under the
+    // STFT / eigen work of its neighbours.  With SALSA_PIPE_SPLIT_PAIRS the STFT of a group is two launches (channels 0/1,
+    // then 2/3) and the tracker -- which only needs channel 0 -- starts after the first.  With SALSA_PIPE_GRAPH the whole
+    // fork/join is captured ONCE per (buffers, sizes) into a hipGraph and replayed with a single hipGraphLaunch.
     int n_groups;
+    int pipe_flags;
     hipStream_t streams[SALSA_MAX_GROUPS + 1];
-    hipEvent_t ev_fork, ev_stft[SALSA_MAX_GROUPS], ev_join[SALSA_MAX_GROUPS + 1];
+    hipEvent_t ev_fork, ev_stft[SALSA_MAX_GROUPS], ev_stft2[SALSA_MAX_GROUPS], ev_join[SALSA_MAX_GROUPS + 1];
+    hipStream_t cap_stream;
+    hipGraphExec_t gexec;
+    struct {
+        const float *audio;
+        float *out;
+        void *ws;
+        const float *sc_mean, *sc_std;
+        int batch, n_groups, flags;
+        int64_t n_samples;
+    } gkey;
 };
 
 extern "C" {
@@ -1047,7 +1062,10 @@ int salsa_plan_destroy(salsa_plan *pl)
         if (pl->streams[i]) (void)hipStreamDestroy(pl->streams[i]);
         if (pl->ev_join[i]) (void)hipEventDestroy(pl->ev_join[i]);
         if (i < SALSA_MAX_GROUPS && pl->ev_stft[i]) (void)hipEventDestroy(pl->ev_stft[i]);
+        if (i < SALSA_MAX_GROUPS && pl->ev_stft2[i]) (void)hipEventDestroy(pl->ev_stft2[i]);
     }
+    if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
+    if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     delete pl;
     return SALSA_OK;
@@ -1102,6 +1120,7 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.format = pl->p.audio_format;
     kp.tracking = pl->p.is_tracking;
     kp.n_hop = pl->p.n_hopframes;
+    kp.pair_sel = -1;
     kp.cond = pl->p.cond_num;
     kp.inv_cond = pl->p.cond_num > 0 ? 1.0 / pl->p.cond_num : 0.0;
     kp.delta = pl->delta;
@@ -1129,15 +1148,19 @@ static void mark_end(salsa_plan *pl, hipStream_t s, int i)
 static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
 {
     const bool lite = kp.feature == SALSA_FEATURE_LITE || kp.feature == SALSA_FEATURE_IPD;
-    const int fpb = 4 * (lite ? k1_cfg<true>::NF : k1_cfg<false>::NF); // frames per workgroup
+    const bool single = !lite && kp.pair_sel >= 0; // one channel pair per launch: twice the frames per wave, same work per wave
+    constexpr int NF_FULL = k1_cfg<false>::NF, NF_LITE = k1_cfg<true>::NF, NF_PAIR = 2 * k1_cfg<false>::NF;
+    const int fpb = 4 * (lite ? NF_LITE : single ? NF_PAIR : NF_FULL); // frames per workgroup
     const unsigned nblk = (unsigned)((kp.T + fpb - 1) / fpb);
     dim3 grid(nblk, (unsigned)kp.B);
     if (pl->p.n_fft == 512) {
-        if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
-        else hipLaunchKernelGGL((stft_kernel<512, double, false>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else if (single) hipLaunchKernelGGL((stft_kernel<512, double, false, NF_PAIR>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
     } else {
-        if (lite) hipLaunchKernelGGL((stft_kernel<256, double, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
-        else hipLaunchKernelGGL((stft_kernel<256, double, false>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        if (lite) hipLaunchKernelGGL((stft_kernel<256, double, true, NF_LITE>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else if (single) hipLaunchKernelGGL((stft_kernel<256, double, false, NF_PAIR>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<256, double, false, NF_FULL>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
     }
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
@@ -1175,25 +1198,38 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
     pl->n_kernels = 0;
     const long T = kp.T;
     const size_t nchunks = (size_t)((T + TR_CH - 1) / TR_CH);
-    // group g = clips [g0, g1): every buffer is clip-major, so a group is just a pointer offset
-    auto run_group = [&](int g0, int g1, hipStream_t s1, hipStream_t s2, hipEvent_t between) -> int {
+    // group g = clips [g0, g1): every buffer is clip-major, so a group is just a pointer offset.  s1 runs the STFT launch(es);
+    // s2 the tracker and the covariance/eigen kernel (s1 == s2: plain in-order issue on one stream).
+    auto run_group = [&](int g0, int g1, hipStream_t s1, hipStream_t s2, hipEvent_t after_first, hipEvent_t after_second,
+                         bool split) -> int {
         KParams gp = kp;
         gp.B = g1 - g0;
         const float *a = d_audio + (size_t)g0 * 4 * kp.N;
         float *o = d_out + (size_t)g0 * 7 * T * kp.F;
         float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
         unsigned long long *vm = valid ? valid + (size_t)g0 * nchunks * ((kp.nd + 63) / 64) * 64 : nullptr;
+        const bool two = split && full && gp.nd > 0;
+        gp.pair_sel = two ? 0 : -1;
         int m = mark_begin(pl, s1, "stft_logspec");
         int rc = launch_stft(pl, gp, a, o, xs, s1);
         mark_end(pl, s1, m);
         if (rc || !full) return rc;
-        if (between) {
-            HIP_TRY(hipEventRecord(between, s1));
-            HIP_TRY(hipStreamWaitEvent(s2, between, 0));
+        if (s1 != s2) {
+            HIP_TRY(hipEventRecord(after_first, s1));
+            HIP_TRY(hipStreamWaitEvent(s2, after_first, 0));
         }
         if (gp.nd == 0) { // empty DOA band: channels 4-6 are all zero (:373-374)
             HIP_TRY(hipMemset2DAsync(o + 4 * T * kp.F, sizeof(float) * 7 * T * kp.F, 0, sizeof(float) * 3 * T * kp.F, (size_t)gp.B, s2));
             return SALSA_OK;
+        }
+        if (two) { // channels 2/3 (the tracker below only needs channel 0 and may run beside this launch)
+            gp.pair_sel = 1;
+            m = mark_begin(pl, s1, "stft_logspec");
+            rc = launch_stft(pl, gp, a, o, xs, s1);
+            mark_end(pl, s1, m);
+            if (rc) return rc;
+            gp.pair_sel = -1;
+            if (s1 != s2) HIP_TRY(hipEventRecord(after_second, s1));
         }
         if (gp.tracking) {
             m = mark_begin(pl, s2, "noise_floor_tracker");
@@ -1201,6 +1237,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
             mark_end(pl, s2, m);
             HIP_TRY(hipGetLastError());
         }
+        if (two && s1 != s2) HIP_TRY(hipStreamWaitEvent(s2, after_second, 0));
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
         dim3 grid(ntile, (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
@@ -1215,20 +1252,62 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         return SALSA_OK;
     };
-    const int G = (!full || pl->n_groups <= 1 || batch < 2) ? 1 : (batch < pl->n_groups ? batch : pl->n_groups);
-    if (G == 1) return run_group(0, batch, s, s, nullptr);
-    HIP_TRY(hipEventRecord(pl->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(pl->streams[0], pl->ev_fork, 0));
-    for (int g = 0; g < G; g++) {
-        HIP_TRY(hipStreamWaitEvent(pl->streams[1 + g], pl->ev_fork, 0)); // orders this call after the caller's earlier work
-        const int g0 = (int)((long)batch * g / G), g1 = (int)((long)batch * (g + 1) / G);
-        const int rc = run_group(g0, g1, pl->streams[0], pl->streams[1 + g], pl->ev_stft[g]);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(pl->ev_join[1 + g], pl->streams[1 + g]));
-        HIP_TRY(hipStreamWaitEvent(s, pl->ev_join[1 + g], 0));
+    const bool piped = full && !pl->timing && kp.nd > 0 && (pl->n_groups > 1 || (pl->pipe_flags & SALSA_PIPE_SPLIT_PAIRS));
+    if (!piped) return run_group(0, batch, s, s, nullptr, nullptr, false);
+    const int G = batch < pl->n_groups ? batch : pl->n_groups;
+    const bool split = (pl->pipe_flags & SALSA_PIPE_SPLIT_PAIRS) != 0;
+    // fork from `origin`, run the groups on the plan's streams, join back into `origin`
+    auto issue = [&](hipStream_t origin) -> int {
+        HIP_TRY(hipEventRecord(pl->ev_fork, origin));
+        HIP_TRY(hipStreamWaitEvent(pl->streams[0], pl->ev_fork, 0));
+        for (int g = 0; g < G; g++) {
+            HIP_TRY(hipStreamWaitEvent(pl->streams[1 + g], pl->ev_fork, 0)); // orders this call after the caller's earlier work
+            const int g0 = (int)((long)batch * g / G), g1 = (int)((long)batch * (g + 1) / G);
+            const int rc = run_group(g0, g1, pl->streams[0], pl->streams[1 + g], pl->ev_stft[g], pl->ev_stft2[g], split);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(pl->ev_join[1 + g], pl->streams[1 + g]));
+            HIP_TRY(hipStreamWaitEvent(origin, pl->ev_join[1 + g], 0));
+        }
+        HIP_TRY(hipEventRecord(pl->ev_join[0], pl->streams[0]));
+        HIP_TRY(hipStreamWaitEvent(origin, pl->ev_join[0], 0));
+        return SALSA_OK;
+    };
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &cap);
+    if (!(pl->pipe_flags & SALSA_PIPE_GRAPH) || cap != hipStreamCaptureStatusNone)
+        return issue(s); // eager fork/join (inside a caller's capture it becomes part of the caller's graph)
+    // one hipGraphLaunch per call: the fork/join above captured once for these buffers and sizes
+    const bool hit = pl->gexec && pl->gkey.audio == d_audio && pl->gkey.out == d_out && pl->gkey.ws == d_workspace &&
+                     pl->gkey.sc_mean == pl->sc_mean && pl->gkey.sc_std == pl->sc_std && pl->gkey.batch == batch &&
+                     pl->gkey.n_samples == n_samples && pl->gkey.n_groups == G && pl->gkey.flags == pl->pipe_flags;
+    if (!hit) {
+        if (pl->gexec) {
+            (void)hipGraphExecDestroy(pl->gexec);
+            pl->gexec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = issue(pl->cap_stream);
+        const hipError_t e = hipStreamEndCapture(pl->cap_stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        HIP_TRY(e);
+        const hipError_t ei = hipGraphInstantiate(&pl->gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ei);
+        pl->gkey.audio = d_audio;
+        pl->gkey.out = d_out;
+        pl->gkey.ws = d_workspace;
+        pl->gkey.sc_mean = pl->sc_mean;
+        pl->gkey.sc_std = pl->sc_std;
+        pl->gkey.batch = batch;
+        pl->gkey.n_samples = n_samples;
+        pl->gkey.n_groups = G;
+        pl->gkey.flags = pl->pipe_flags;
     }
-    HIP_TRY(hipEventRecord(pl->ev_join[0], pl->streams[0]));
-    HIP_TRY(hipStreamWaitEvent(s, pl->ev_join[0], 0));
+    HIP_TRY(hipGraphLaunch(pl->gexec, s));
     return SALSA_OK;
 }
 
@@ -1343,8 +1422,11 @@ static int ensure_group_streams(salsa_plan *pl)
     bool ok = true;
     for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++)
         ok = hipStreamCreateWithPriority(&pl->streams[i], hipStreamNonBlocking, i == 0 ? lo : hi) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < SALSA_MAX_GROUPS && ok; i++)
+        ok = hipEventCreateWithFlags(&pl->ev_stft[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&pl->ev_stft2[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i <= SALSA_MAX_GROUPS && ok; i++) ok = hipEventCreateWithFlags(&pl->ev_join[i], hipEventDisableTiming) == hipSuccess;
     return ok ? SALSA_OK : fail(SALSA_EHIP, "stream / event creation failed%s");
 }
@@ -1357,15 +1439,23 @@ int salsa_plan_set_scaler(salsa_plan *pl, const float *d_mean, const float *d_st
     return SALSA_OK;
 }
 
-int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
+int salsa_plan_set_pipeline(salsa_plan *pl, int n_groups, int flags)
 {
-    if (!pl || n_groups < 1) return fail(SALSA_EINVAL, "salsa_plan_set_groups: bad argument%s");
-    if (n_groups > 1) { // the plan-owned streams are only created when the pipeline is actually requested
+    if (!pl || n_groups < 1 || (flags & ~(SALSA_PIPE_SPLIT_PAIRS | SALSA_PIPE_GRAPH)))
+        return fail(SALSA_EINVAL, "salsa_plan_set_pipeline: bad argument%s");
+    if (n_groups > 1 || (flags & SALSA_PIPE_SPLIT_PAIRS)) { // the plan-owned streams are only created when a pipeline is requested
         const int rc = ensure_group_streams(pl);
         if (rc) return rc;
     }
     pl->n_groups = n_groups > SALSA_MAX_GROUPS ? SALSA_MAX_GROUPS : n_groups;
+    pl->pipe_flags = flags;
     return SALSA_OK;
+}
+
+int salsa_plan_set_groups(salsa_plan *pl, int n_groups)
+{
+    if (!pl) return fail(SALSA_EINVAL, "salsa_plan_set_groups: bad argument%s");
+    return salsa_plan_set_pipeline(pl, n_groups, pl->pipe_flags);
 }
 
 int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_channel_stride, float *d_out, int batch,

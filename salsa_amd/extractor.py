@@ -181,7 +181,17 @@ class SalsaExtractor:
 
     def set_groups(self, n_groups: int):
         """Clip-group pipelining depth of extract() (1 = single stream)."""
-        rc = self.L.salsa_plan_set_groups(self._plan, int(n_groups))
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_plan_set_groups(self._plan, int(n_groups))
+        if rc:
+            _raise(rc)
+
+    def set_pipeline(self, n_groups: int = 1, split_pairs: bool = False, graph: bool = False):
+        """Pipelined schedule of extract() (include/salsa_hip.h salsa_plan_set_pipeline): clip groups on plan-owned streams,
+        optionally the STFT split by channel pair so the tracker starts early, optionally replayed as one hipGraph."""
+        flags = (_lib.PIPE_SPLIT_PAIRS if split_pairs else 0) | (_lib.PIPE_GRAPH if graph else 0)
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_plan_set_pipeline(self._plan, int(n_groups), flags)
         if rc:
             _raise(rc)
 

@@ -370,15 +370,17 @@ def test_register_resident_gru_inference_scan():
     x = torch.randn(5, 300, 512, device=dev)
     with torch.no_grad():
         ref = gru(x)[0]
-        fast = fused_gru.bigru_forward(gru, x, training=False)
+        fast = fused_gru.bigru_forward(gru, x, training=False, half_weights=True)     # what a bf16-autocast caller gets
+        fp32 = fused_gru.bigru_forward(gru, x, training=False)                        # a float32 caller: float32 streaming scan
         fused_gru.REGISTER_WEIGHTS = False
         try:
-            slow = fused_gru.bigru_forward(gru, x, training=False)
+            slow = fused_gru.bigru_forward(gru, x, training=False, half_weights=True)
         finally:
             fused_gru.REGISTER_WEIGHTS = True
     torch.testing.assert_close(slow, ref, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(fast, ref, rtol=2e-3, atol=2e-3)                     # float16 weights: 2^-11 per weight
     assert not torch.equal(fast, slow)                                              # (the two kernels really are different)
+    assert torch.equal(fp32, slow)            # pure-float32 evaluation never takes the float16-weight kernel
 
 
 def test_eval_conv_with_folded_batchnorm_epilogue():
