@@ -337,16 +337,13 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 
 // ------------------------------------------------------------------------------------------------------------ K2
 // Noise-floor tracker.  The recurrence over time is strictly sequential per (clip, bin), but everything that feeds it
-// (|X0|^2, the 3-frame mean, the float64 divide and square root) is not.  One 512-lane workgroup serves TR_BINS adjacent
-// bins of one clip: wave 0 runs the recurrence (a ~5-instruction dependent chain per frame) at raised priority, waves
-// 1-7 stay one chunk of TR_CH frames ahead computing mag[t][bin] into an LDS ring, with the loads of the chunk after
-// that already in flight.  Spill layout: Xs[b][t][pair][bin] as float4 (c0.re, c0.im, c1.re, c1.im); channel 0 is the
-// .xy of pair 0.  Output: valid[b][chunk][group][j] = 64-bit HISTORY of bin 64*group+j over the chunk: bit i =
-// indicator_sig at frame 64*chunk+i.  (A lane appends its own bit per frame -- two integer instructions -- instead of the
-// wave building per-frame masks over bins; K3 turns the words back into per-frame masks with one ballot per frame.)
-constexpr int TR_CH = 64;       // frames per chunk (= bits per mask word)
+// (|X0|^2, the 3-frame mean, the float64 divide and square root) is not: producer waves stay one chunk of TR_CH frames
+// ahead of the consumer wave, computing mag[t][bin] into an LDS ring.  Spill layout: Xs[b][t][pair][bin] as float4
+// (c0.re, c0.im, c1.re, c1.im); channel 0 is the .xy of pair 0.  Output: valid32[b][32-bin group][t] = indicator_sig mask
+// of frame t (bit j = bin 32*group + j).
+constexpr int TR_CH = 64;       // frames per chunk
 #ifndef TR_WAVES_N
-#define TR_WAVES_N 8
+#define TR_WAVES_N 4
 #endif
 constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
 
@@ -381,103 +378,108 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
     }
 }
 
-// One workgroup = BINS adjacent bins of one clip.  Measured (probe builds): the kernel is bound by the PRODUCERS' float64
-// divide + square root, not by the consumer's recurrence (dropping the recurrence changes nothing; dropping the divide
-// and root saves 20 %), and a workgroup's producers all sit on one CU.  With BINS = 32 a producer instruction covers
-// 32 bins x 2 frames, so the same arithmetic is spread over twice as many workgroups / CUs (the consumer simply runs
-// with half its lanes; its chain is as long as before).
-template <int BINS>
+// One workgroup = 32 adjacent bins of one clip, TR_WAVES waves: wave 0 is the CONSUMER (the recurrence), the others are
+// producers.  What bounds this kernel is the consumer: 4801 strictly sequential steps per clip of ~16 instructions each, issued
+// by ONE wave -- so everything is arranged for that wave's issue rate and dependent-chain latency:
+//  * 4 waves per workgroup and 192 workgroups on 256 CUs: the consumer has a SIMD to itself (with 8 waves it shared one with a
+//    producer: the step took ~100 cycles, now ~55);
+//  * the step's dependent chain is  multiply -> select -> max  (salsa::tracker_step forms both candidate products first);
+//  * indicator_sig never becomes a per-lane value: the compare writes a scalar lane mask (one bit per bin), which is exactly
+//    the per-frame mask the covariance kernel wants; v_writelane drops it into lane `frame` of one VGPR and the chunk's 64
+//    masks leave as ONE coalesced 256-byte store: valid32[b][32-bin group][t].  (Round 1 shifted a bit into a per-bin history
+//    word -- three VALU instructions per step -- and K3 had to ballot the words back into frame masks.)
+//  * all 64 lanes run the recurrence (lanes 32-63 mirror 0-31), so the consumer has no divergent region around the writelanes;
+//  * producers keep TWO register sets of spectra and alternate them (the chunk loop is unrolled by two): the loads issued in
+//    one iteration are first used in the next, a whole chunk later.  (Round 1 copied "next" into "current" at the end of every
+//    iteration, which made each iteration wait for the loads it had just issued.)
+constexpr int TR_BINS = 32;
+// (v_writelane_b32 ignores EXEC and writes lane `sel` of the destination; the inline asm keeps `word` in one VGPR)
+static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + TR_BINS - 1) / TR_BINS)); }
+
 __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
-                                                                unsigned long long *__restrict__ valid)
+                                                                unsigned *__restrict__ valid32)
 {
-    static_assert(BINS == 64 || BINS == 32 || BINS == 16, "bins per workgroup");
-    constexpr int FS = 64 / BINS;                               // frames per producer instruction
+    constexpr int BINS = TR_BINS, FS = 64 / BINS;                                         // FS frames per producer instruction
     constexpr int PER_ALL = (TR_CH + TR_WAVES * FS - 1) / (TR_WAVES * FS);               // prologue: all waves produce chunk 0
     constexpr int PER_PROD = (TR_CH + (TR_WAVES - 1) * FS - 1) / ((TR_WAVES - 1) * FS);  // frames per producer lane per chunk
     __shared__ double ring[2][TR_CH * BINS];
-    const int ngroups = (kp.nd + 63) / 64;
-    const int b = blockIdx.x / (ngroups * FS), g = (blockIdx.x / FS) % ngroups, h = blockIdx.x % FS;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ng32 = (kp.nd + BINS - 1) / BINS;
+    const int b = blockIdx.x / ng32, g = blockIdx.x % ng32;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane % BINS, fsub = lane / BINS;            // producers: lane = (frame sub-slot, bin column)
-    const int bin = g * 64 + h * BINS + col;
+    const int bin = g * BINS + col;
     const bool active = bin < kp.nd;
     const int Tn = kp.T;
     const int stride = 2 * kp.nd; // float4 elements per frame
     const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
     const int nchunks = (Tn + TR_CH - 1) / TR_CH;
+    const bool raw = kp.flex != 0;
     {
         float2 x[PER_ALL + 2];
         const int first = (w * FS + fsub) * PER_ALL;
         tracker_load<PER_ALL>(kp, x0, stride, 0, first, active, x);
-        tracker_mag<PER_ALL, BINS>(x, first, ring[0], col, kp.flex != 0);
+        tracker_mag<PER_ALL, BINS>(x, first, ring[0], col, raw);
     }
-    float2 xr[PER_PROD + 2];
+    float2 xa[PER_PROD + 2], xb[PER_PROD + 2];
     const int pfirst = ((w - 1) * FS + fsub) * PER_PROD;
-    if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xr);
+    if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xa);
     __syncthreads();
-    // Consumer state: noise floor + countdown (salsa_feature_extraction.py:30, :58).  The recurrence is evaluated with
-    // exactly the reference's operations (one float64 multiply by 1.02 / 1.002 / 0.98, the 1e-6 clamp, the two strict
-    // compares), but arranged so the dependent chain per frame is  multiply -> select -> max : both candidate
-    // products are formed before the above/below compare resolves.  indicator_sig is shifted into the lane's own
-    // 64-frame history word: one coalesced 8-byte store per lane per chunk.
+    // Consumer state: noise floor + countdown (salsa_feature_extraction.py:30, :58), evaluated with exactly the reference's
+    // operations (one float64 multiply by 1.02 / 1.002 / 0.98, the 1e-6 clamp, the two strict compares).
     double fl = 0.0;
     int cd = 3;
     const double snr = kp.snr_ratio;
-    unsigned long long *vout = valid + (((long)b * nchunks) * ngroups + g) * TR_CH + h * BINS + col; // [b][chunk][group][bin]
+    unsigned *vout = valid32 + ((long)b * ng32 + g) * Tn; // [b][32-bin group][t]
     if (w == 0) __builtin_amdgcn_s_setprio(3);
-    for (int c = 0; c < nchunks; c++) {
-        const double *cur = ring[c & 1];
-        if (w == 0) {
-            if (lane < BINS) { // the consumer: one lane per bin
-                if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
-                    const int n0 = Tn < 5 ? Tn : 5;
-                    double acc = 0.0;
-                    for (int t = 0; t < n0; t++) acc += cur[t * BINS + lane];
-                    fl = 0.5 * (acc / (double)n0);
-                    if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
+    auto consume = [&](const int c) {
+        const double *cur = ring[c & 1] + col;
+        if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
+            const int n0 = Tn < 5 ? Tn : 5;
+            double acc = 0.0;
+            for (int t = 0; t < n0; t++) acc += cur[t * BINS];
+            fl = 0.5 * (acc / (double)n0);
+            if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
+        }
+        unsigned word = 0; // lane i: indicator_sig mask (bit j = bin 32 g + j) of frame 64 c + i
+        const int nfr = Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH; // wave-uniform
+        if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
+#pragma unroll
+            for (int i0 = 0; i0 < TR_CH; i0 += 16) {
+                double m[16]; // one LDS round trip per 16 frames, not per frame
+#pragma unroll
+                for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * BINS];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, m[i], snr)); // :65-87
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((unsigned)bal), "n"(i0 + i));
                 }
-                unsigned lo = 0, hi = 0; // this bin's indicator bits, newest in bit 0 (reversed once at the end of the chunk)
-                const int nfr = __builtin_amdgcn_readfirstlane(Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH); // scalar
-                if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
-#pragma unroll
-                    for (int i0 = 0; i0 < TR_CH; i0 += 16) {
-                        double m[16]; // one LDS round trip per 16 frames, not per frame
-#pragma unroll
-                        for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * BINS + lane];
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const unsigned s1 = salsa::tracker_step(fl, cd, m[i], snr) ? 1u : 0u;   // :65-87
-                            if (i0 < 32) lo = (lo << 1) | s1;
-                            else hi = (hi << 1) | s1;
-                        }
-                    }
-                    lo = __builtin_bitreverse32(lo);
-                    hi = __builtin_bitreverse32(hi);
-                } else {
-                    unsigned long long hw = 0;
-                    for (int i = 0; i < nfr; i++)
-                        hw |= (unsigned long long)(salsa::tracker_step(fl, cd, cur[i * BINS + lane], snr) ? 1u : 0u) << i;
-                    lo = (unsigned)hw;
-                    hi = (unsigned)(hw >> 32);
-                }
-                vout[(long)c * ngroups * TR_CH] = ((unsigned long long)hi << 32) | lo;
             }
-        } else if (c + 1 < nchunks) {
-            float2 xn[PER_PROD + 2];
-            if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, xn);
-            tracker_mag<PER_PROD, BINS>(xr, pfirst, ring[(c + 1) & 1], col, kp.flex != 0);
-#pragma unroll
-            for (int i = 0; i < PER_PROD + 2; i++) xr[i] = xn[i];
+        } else {
+            for (int i = 0; i < nfr; i++) {
+                const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, cur[i * BINS], snr));
+                word = lane == i ? (unsigned)bal : word; // (ragged last chunk only)
+            }
+        }
+        if (lane < nfr) vout[c * TR_CH + lane] = word;
+    };
+    // producers, iteration c: issue the loads of chunk c+2 into `nxt`, turn `now` (chunk c+1, loaded an iteration ago) into
+    // magnitudes in the ring half the consumer is not reading
+    auto produce = [&](const int c, const float2 *now, float2 *nxt) {
+        if (c + 1 >= nchunks) return;
+        if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, nxt);
+        tracker_mag<PER_PROD, BINS>(now, pfirst, ring[(c + 1) & 1], col, raw);
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        if (w == 0) consume(c);
+        else produce(c, xa, xb);
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            if (w == 0) consume(c + 1);
+            else produce(c + 1, xb, xa);
         }
         __syncthreads();
     }
 }
-
-#ifndef TR_BINS_N
-#define TR_BINS_N 32
-#endif
-constexpr int TR_BINS = TR_BINS_N;
-static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + 63) / 64) * (64 / TR_BINS)); }
 
 // ------------------------------------------------------------------------------------------------------------ K3
 // Covariance + eigen-gate + eigenvector.  Only TF bins that pass the noise gate need the (float64, ~700 instruction)
@@ -494,10 +496,18 @@ constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gat
 #define K3_GROUP 2
 #endif
 constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins + the zero band above them when it fits
+// Tile order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8, each with its own L2), so with
+// tile = blockIdx.x two neighbouring 8-frame tiles -- which share 6 of the 14 spill frames they read -- always sit on
+// different XCDs and the shared frames are fetched from HBM twice.  Runs of K3_XCD_CHUNK consecutive tiles are instead given to
+// ONE XCD (the j-th workgroup of XCD x takes tile (j / CHUNK * 8 + x) * CHUNK + j % CHUNK): neighbours run on the same L2 at
+// about the same time, while the runs themselves still rotate over the XCDs (bursts of heavy tiles spread over all eight).
+#ifndef K3_XCD_CHUNK
+#define K3_XCD_CHUNK 16
+#endif
 
 template <bool FEAT, int NHOP>
 __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
-                                                      const unsigned long long *__restrict__ valid,
+                                                      const unsigned *__restrict__ valid32,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
 {
@@ -511,9 +521,18 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     // 4-byte stores per result
     __shared__ __attribute__((aligned(16))) float otile[FEAT ? 3 * K3_FT * K3_OW : 4];
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
     const int Tn = kp.T;
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x, b = blockIdx.y;
+    if (K3_XCD_CHUNK > 0) {
+        const unsigned ntile = gridDim.x, total = ntile * gridDim.y, lin = blockIdx.x + ntile * blockIdx.y;
+        constexpr unsigned span = 8u * (K3_XCD_CHUNK > 0 ? K3_XCD_CHUNK : 1);
+        if (lin < total / span * span) { // (the ragged tail keeps the identity order)
+            const unsigned xcd = lin & 7u, j = lin >> 3;
+            const unsigned tl = ((j / (span / 8)) * 8u + xcd) * (span / 8) + j % (span / 8);
+            b = (int)(tl / ntile);
+            tile = (int)(tl - (unsigned)b * ntile);
+        }
+    }
     const int t0 = tile * K3_FT;
     const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
     const int bin0 = blockIdx.z * 256;
@@ -545,18 +564,29 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         // neighbouring bins.
         const int bl = tid;
         const bool in = bl < nbc;
-        const int nchunks = (Tn + TR_CH - 1) / TR_CH, ngroups = (kp.nd + 63) / 64;
+        const int ng32 = (kp.nd + TR_BINS - 1) / TR_BINS;
         const int bin = bin0 + bl;
         const int lane = tid & 63;
-        const int grp = __builtin_amdgcn_readfirstlane(bin >> 6) < ngroups ? __builtin_amdgcn_readfirstlane(bin >> 6) : ngroups - 1;
-        // this bin's 64-frame history word of the tile's chunk (coalesced 8-byte loads); frame ft of the tile is bit sh + ft
-        const unsigned long long mine = (kp.tracking && in) ? valid[(((long)b * nchunks + t0 / TR_CH) * ngroups + grp) * TR_CH + lane] : ~0ull;
-        const int sh = t0 % TR_CH;
+        const int grp = __builtin_amdgcn_readfirstlane(bin >> 6); // the wave's 64-bin group = two of the tracker's 32-bin groups
+        const unsigned long long inmask = __ballot(in);
+        // the tracker's per-frame masks of this wave's bins: wave-uniform scalar loads, no per-lane work at all
+        const unsigned *vlo = valid32 + ((long)b * ng32 + 2 * grp) * Tn + t0;
+        const bool has_lo = 2 * grp < ng32, has_hi = 2 * grp + 1 < ng32;
         unsigned long long words[K3_FT];
         int total = 0;
 #pragma unroll
-        for (int ft = 0; ft < K3_FT; ft++)
-            words[ft] = ft < nft ? __ballot(in && ((mine >> (sh + ft)) & 1)) : 0ull; // back to a mask over the wave's bins
+        for (int ft = 0; ft < K3_FT; ft++) {
+            unsigned long long wd = 0ull;
+            if (ft < nft) {
+                if (kp.tracking) {
+                    const unsigned lo = has_lo ? vlo[ft] : 0u, hi = has_hi ? vlo[Tn + ft] : 0u;
+                    wd = (((unsigned long long)hi << 32) | lo) & inmask;
+                } else {
+                    wd = inmask;
+                }
+            }
+            words[ft] = wd;
+        }
         // A work item is a GROUP of G neighbouring frames of one bin with at least one of them gated in.
         auto any_of = [&](int ft) {
             unsigned long long wd = 0ull;
@@ -690,7 +720,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
 }
 
 template <bool FEAT>
-static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned long long *valid,
+static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned *valid,
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
     if (kp.n_hop == 3)
@@ -1188,12 +1218,12 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
     KParams kp = make_kparams(pl, batch, n_samples);
     const bool full = pl->p.feature_type == SALSA_FEATURE_SALSA;
     float4 *Xs = nullptr;
-    unsigned long long *valid = nullptr;
+    unsigned *valid = nullptr;
     if (full) {
         const size_t need = salsa_workspace_bytes(pl, batch, n_samples);
         if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
         Xs = (float4 *)d_workspace;
-        valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
+        valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
     }
     pl->n_kernels = 0;
     const long T = kp.T;
@@ -1207,7 +1237,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         const float *a = d_audio + (size_t)g0 * 4 * kp.N;
         float *o = d_out + (size_t)g0 * 7 * T * kp.F;
         float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
-        unsigned long long *vm = valid ? valid + (size_t)g0 * nchunks * ((kp.nd + 63) / 64) * 64 : nullptr;
+        unsigned *vm = valid ? valid + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T : nullptr; // [b][32-bin group][t]
         const bool two = split && full && gp.nd > 0;
         gp.pair_sel = two ? 0 : -1;
         int m = mark_begin(pl, s1, "stft_logspec");
@@ -1233,7 +1263,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         if (gp.tracking) {
             m = mark_begin(pl, s2, "noise_floor_tracker");
-            hipLaunchKernelGGL(tracker_kernel<TR_BINS>, dim3(tracker_grid(gp)), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
+            hipLaunchKernelGGL(tracker_kernel, dim3(tracker_grid(gp)), dim3(64 * TR_WAVES), 0, s2, gp, xs, vm);
             mark_end(pl, s2, m);
             HIP_TRY(hipGetLastError());
         }
@@ -1350,12 +1380,12 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     kp.F = n_bins;
     kp.feature = SALSA_FEATURE_SALSA;
     float4 *Xs = (float4 *)d_workspace;
-    unsigned long long *valid = (unsigned long long *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
+    unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
     const long total = (long)batch * n_bins * n_frames * 2;
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
     if (kp.tracking) {
-        hipLaunchKernelGGL(tracker_kernel<TR_BINS>, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
+        hipLaunchKernelGGL(tracker_kernel, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
         HIP_TRY(hipGetLastError());
     }
     const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);
