@@ -393,7 +393,10 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 //    one iteration are first used in the next, a whole chunk later.  (Round 1 copied "next" into "current" at the end of every
 //    iteration, which made each iteration wait for the loads it had just issued.)
 constexpr int TR_BINS = 32;
-// (v_writelane_b32 ignores EXEC and writes lane `sel` of the destination; the inline asm keeps `word` in one VGPR)
+// v_writelane_b32 through the LLVM intrinsic (this clang has no __builtin for it).  Not inline asm: a VALU compare that writes
+// VCC needs two wait states before v_writelane may read it, and only the compiler's hazard recogniser inserts them -- the
+// hand-written form read stale masks in 0.7 % of the frames.
+extern "C" __device__ int salsa_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + TR_BINS - 1) / TR_BINS)); }
 
 __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, m[i], snr)); // :65-87
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(word) : "s"((unsigned)bal), "n"(i0 + i));
+                    word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
                 }
             }
         } else {
@@ -569,23 +572,22 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
         const int lane = tid & 63;
         const int grp = __builtin_amdgcn_readfirstlane(bin >> 6); // the wave's 64-bin group = two of the tracker's 32-bin groups
         const unsigned long long inmask = __ballot(in);
-        // the tracker's per-frame masks of this wave's bins: wave-uniform scalar loads, no per-lane work at all
-        const unsigned *vlo = valid32 + ((long)b * ng32 + 2 * grp) * Tn + t0;
-        const bool has_lo = 2 * grp < ng32, has_hi = 2 * grp + 1 < ng32;
+        // the tracker's per-frame masks of this wave's bins (two 32-bin groups x K3_FT frames): ONE vector load -- lane l takes
+        // frame l % K3_FT of half l / K3_FT -- then readlane; the masks are wave-uniform scalars and no ballot is needed.
+        // (Scalar loads here were measured 40 % slower for the whole kernel: sixteen serialised scalar-cache misses per wave.)
+        static_assert(2 * K3_FT <= 64, "one lane per (half, frame)");
+        unsigned myw = 0u;
+        if (kp.tracking && lane < 2 * K3_FT) {
+            const int ft = lane % K3_FT, half = lane / K3_FT;
+            if (ft < nft && 2 * grp + half < ng32) myw = valid32[((long)b * ng32 + 2 * grp + half) * Tn + t0 + ft];
+        }
         unsigned long long words[K3_FT];
         int total = 0;
 #pragma unroll
         for (int ft = 0; ft < K3_FT; ft++) {
-            unsigned long long wd = 0ull;
-            if (ft < nft) {
-                if (kp.tracking) {
-                    const unsigned lo = has_lo ? vlo[ft] : 0u, hi = has_hi ? vlo[Tn + ft] : 0u;
-                    wd = (((unsigned long long)hi << 32) | lo) & inmask;
-                } else {
-                    wd = inmask;
-                }
-            }
-            words[ft] = wd;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)myw, ft), hi = (unsigned)__builtin_amdgcn_readlane((int)myw, K3_FT + ft);
+            const unsigned long long tr = (((unsigned long long)hi << 32) | lo) & inmask;
+            words[ft] = kp.tracking ? tr : (ft < nft ? inmask : 0ull);
         }
         // A work item is a GROUP of G neighbouring frames of one bin with at least one of them gated in.
         auto any_of = [&](int ft) {
