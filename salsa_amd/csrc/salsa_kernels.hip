@@ -343,9 +343,9 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 // of frame t (bit j = bin 32*group + j).
 constexpr int TR_CH = 64;       // frames per chunk
 #ifndef TR_WAVES_N
-#define TR_WAVES_N 4
+#define TR_WAVES_N 8
 #endif
-constexpr int TR_WAVES = TR_WAVES_N; // 1 consumer + (TR_WAVES-1) producers
+constexpr int TR_WAVES = TR_WAVES_N; // wave 0 = consumer; with more than 4 waves, wave 4 idles (see tracker_kernel); the rest produce
 
 template <int COUNT>
 __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__restrict__ x0, int stride, int c0,
@@ -381,8 +381,11 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 // One workgroup = 32 adjacent bins of one clip, TR_WAVES waves: wave 0 is the CONSUMER (the recurrence), the others are
 // producers.  What bounds this kernel is the consumer: 4801 strictly sequential steps per clip of ~16 instructions each, issued
 // by ONE wave -- so everything is arranged for that wave's issue rate and dependent-chain latency:
-//  * 4 waves per workgroup and 192 workgroups on 256 CUs: the consumer has a SIMD to itself (with 8 waves it shared one with a
-//    producer: the step took ~100 cycles, now ~55);
+//  * a wave issues at most one instruction per 4-cycle slot of its SIMD, so the step costs ~4.5 cycles x its instruction count
+//    (17 here, 23 in round 1) -- PROVIDED the consumer has its SIMD to itself.  A workgroup's waves go to the four SIMDs
+//    cyclically, so wave 4 would share the consumer's: it does nothing but the barriers (a wave parked at s_barrier takes no
+//    issue slots) and the six producers are waves 1-3 and 5-7.  They need ~440 cycles per (2 frames x 32 bins) item -- the
+//    float64 divide and square root are quarter-rate -- i.e. ~2700 cycles per chunk against the consumer's ~4900;
 //  * the step's dependent chain is  multiply -> select -> max  (salsa::tracker_step forms both candidate products first);
 //  * indicator_sig never becomes a per-lane value: the compare writes a scalar lane mask (one bit per bin), which is exactly
 //    the per-frame mask the covariance kernel wants; v_writelane drops it into lane `frame` of one VGPR and the chunk's 64
@@ -403,8 +406,10 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                                                                 unsigned *__restrict__ valid32)
 {
     constexpr int BINS = TR_BINS, FS = 64 / BINS;                                         // FS frames per producer instruction
+    constexpr bool IDLE4 = TR_WAVES > 4;                                                 // wave 4 shares the consumer's SIMD: keep it idle
+    constexpr int NPROD = IDLE4 ? TR_WAVES - 2 : TR_WAVES - 1;
     constexpr int PER_ALL = (TR_CH + TR_WAVES * FS - 1) / (TR_WAVES * FS);               // prologue: all waves produce chunk 0
-    constexpr int PER_PROD = (TR_CH + (TR_WAVES - 1) * FS - 1) / ((TR_WAVES - 1) * FS);  // frames per producer lane per chunk
+    constexpr int PER_PROD = (TR_CH + NPROD * FS - 1) / (NPROD * FS);                    // frames per producer lane per chunk
     __shared__ double ring[2][TR_CH * BINS];
     const int ng32 = (kp.nd + BINS - 1) / BINS;
     const int b = blockIdx.x / ng32, g = blockIdx.x % ng32;
@@ -424,8 +429,10 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
         tracker_mag<PER_ALL, BINS>(x, first, ring[0], col, raw);
     }
     float2 xa[PER_PROD + 2], xb[PER_PROD + 2];
-    const int pfirst = ((w - 1) * FS + fsub) * PER_PROD;
-    if (w > 0 && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xa);
+    const bool producer = w > 0 && !(IDLE4 && w == 4);
+    const int pidx = (IDLE4 && w > 4) ? w - 2 : w - 1;           // producer number 0 .. NPROD-1
+    const int pfirst = (pidx * FS + fsub) * PER_PROD;
+    if (producer && nchunks > 1) tracker_load<PER_PROD>(kp, x0, stride, TR_CH, pfirst, active, xa);
     __syncthreads();
     // Consumer state: noise floor + countdown (salsa_feature_extraction.py:30, :58), evaluated with exactly the reference's
     // operations (one float64 multiply by 1.02 / 1.002 / 0.98, the 1e-6 clamp, the two strict compares).
@@ -433,7 +440,6 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     int cd = 3;
     const double snr = kp.snr_ratio;
     unsigned *vout = valid32 + ((long)b * ng32 + g) * Tn; // [b][32-bin group][t]
-    if (w == 0) __builtin_amdgcn_s_setprio(3);
     auto consume = [&](const int c) {
         const double *cur = ring[c & 1] + col;
         if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
@@ -474,11 +480,11 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     };
     for (int c = 0; c < nchunks; c += 2) {
         if (w == 0) consume(c);
-        else produce(c, xa, xb);
+        else if (producer) produce(c, xa, xb);
         __syncthreads();
         if (c + 1 < nchunks) {
             if (w == 0) consume(c + 1);
-            else produce(c + 1, xb, xa);
+            else if (producer) produce(c + 1, xb, xa);
         }
         __syncthreads();
     }

@@ -15,7 +15,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "WRITE_SIZE GRBM_GUI_ACTIVE" \
             "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-crnn --blocks 1 > $OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $CTRS"
 done
 python - <<PY

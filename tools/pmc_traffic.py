@@ -5,6 +5,9 @@ rocprofv3 PMC passes of tools/pmc_round.sh (separate --pmc runs, --kernel-trace 
 FETCH_SIZE counts 64 B per 128-B request (x2) -- confirmed here by profiles/*_pmc_calibration.csv (a 720 000 KiB
 elementwise read reports 360 036; the STFT kernel's 4-B/lane audio reads obey the same factor) -- and WRITE_SIZE needs
 no factor (720 000 KiB written reports 720 000; the STFT kernel's row writes report 1.034x their exact byte count).
+Also derives each kernel's VALU utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over the chip's SIMDs) x 4 /
+(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD cycles in which a vector instruction was executing -- for these
+float64 kernels the "what bounds it besides HBM" figure SURVEY section 8(d) asks for.
 usage: tools/pmc_traffic.py profiles/r1_v7_pmc_summary.csv [batch] [older_summary.csv]
 (a counter missing from the first summary -- a pass that timed out -- is taken from the older one and named in 'source')"""
 import csv
@@ -19,14 +22,18 @@ acc, origin = {}, {}
 for path in [src] + sys.argv[3:4]:
     for row in csv.DictReader(open(path)):
         k = name.get(row['kernel'])
-        if k and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE') and row['counter'] not in acc.get(k, {}):
+        if k and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU') and row['counter'] not in acc.get(k, {}):
             acc.setdefault(k, {})[row['counter']] = float(row['mean_per_dispatch'])
             origin[row['counter']] = os.path.basename(path)
-out = {'source': ', '.join('%s from %s' % (c, f) for c, f in sorted(origin.items())), 'batch_clips_per_launch': batch, 'correction': 'FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1',
+out = {'source': ', '.join('%s from %s' % (c, f) for c, f in sorted(origin.items())), 'batch_clips_per_launch': batch, 'correction': 'FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1; valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
        'kernels': {}}
 for k, v in acc.items():
     rd, wr = v.get('FETCH_SIZE', 0) * 1024 * 2, v.get('WRITE_SIZE', 0) * 1024
     out['kernels'][k] = {'hbm_read_bytes': int(rd), 'hbm_write_bytes': int(wr), 'hbm_bytes': int(rd + wr)}
+    if v.get('SQ_ACTIVE_INST_VALU') and v.get('GRBM_GUI_ACTIVE'):
+        out['kernels'][k]['valu_util'] = round(v['SQ_ACTIVE_INST_VALU'] * 4 / (v['GRBM_GUI_ACTIVE'] / 8 * 1024), 4)
+        out['kernels'][k]['valu_wave_instructions'] = int(v.get('SQ_INSTS_VALU', 0))
+        out['kernels'][k]['gpu_cycles'] = int(v['GRBM_GUI_ACTIVE'] / 8)
 path = os.path.join(os.path.dirname(src), 'traffic.json')
 json.dump(out, open(path, 'w'), indent=1)
 print(json.dumps(out, indent=1))
