@@ -396,6 +396,9 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 //    one iteration are first used in the next, a whole chunk later.  (Round 1 copied "next" into "current" at the end of every
 //    iteration, which made each iteration wait for the loads it had just issued.)
 constexpr int TR_BINS = 32;
+#ifndef TR_LAZY_CLAMP
+#define TR_LAZY_CLAMP 1
+#endif
 // v_writelane_b32 through the LLVM intrinsic (this clang has no __builtin for it).  Not inline asm: a VALU compare that writes
 // VCC needs two wait states before v_writelane may read it, and only the compiler's hazard recogniser inserts them -- the
 // hand-written form read stale masks in 0.7 % of the frames.
@@ -457,11 +460,38 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 double m[16]; // one LDS round trip per 16 frames, not per frame
 #pragma unroll
                 for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * BINS];
+#if TR_LAZY_CLAMP
+                // The 1e-6 clamp (:85) is a float64 max on the step's dependent chain (multiply -> select -> max), yet it only
+                // ever acts on near-silent bins.  So a block of 16 steps runs WITHOUT it, a running minimum of the floor rides
+                // along off the chain, and only if some lane's floor dipped below 1e-6 (wave-uniform test) the block is redone
+                // from its saved state with the clamp.  Where no clamp acts max(x, 1e-6) == x, so the result is bit-identical.
+                const double fl0 = fl;
+                const int cd0 = cd;
+                const unsigned word0 = word;
+                double mn = fl;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned long long bal = __ballot(salsa::tracker_step<false>(fl, cd, m[i], snr)); // :65-87
+                    asm("v_min_f64 %0, %0, %1" : "+v"(mn) : "v"(fl)); // (fmin() would canonicalise its operand first: one more float64 op)
+                    word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
+                }
+                if (__ballot(mn < 1e-6) != 0ull) {
+                    fl = fl0;
+                    cd = cd0;
+                    word = word0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const unsigned long long bal = __ballot(salsa::tracker_step<true>(fl, cd, m[i], snr));
+                        word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
+                    }
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, m[i], snr)); // :65-87
                     word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
                 }
+#endif
             }
         } else {
             for (int i = 0; i < nfr; i++) {

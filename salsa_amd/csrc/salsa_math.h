@@ -460,6 +460,7 @@ SALSA_HD int stockham_out(int i, int r, int p, int R) { int k = i & (p - 1); ret
 // the above/below compare resolves.  Same operations and constants as the reference: floor_up = 1+alpha,
 // floor_up_slow = 1+slow_scale*alpha, floor_down = 1-alpha (:31-35); "countdown -= 1; negative = countdown < 0" (:68-69)
 // is (cd < 1) on the value before the decrement; the 1e-6 clamp (:85) is an fmax (the floor is never NaN).
+template <bool CLAMP = true>
 SALSA_HD bool tracker_step(double &floor, int &countdown, double mag, double snr_ratio = 1.5)
 {
     const double up = (countdown < 1) ? 1.0 + 0.1 * 0.02 : 1.0 + 0.02;
@@ -471,14 +472,20 @@ SALSA_HD bool tracker_step(double &floor, int &countdown, double mag, double snr
     const bool above = mag > floor;
     countdown = above ? countdown - 1 : 3;
     const double sel = above ? pa : pb;
+    if (CLAMP) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // one v_max_f64: fmax() would first canonicalise its operand (a second v_max on the dependent chain); sel is a
-    // product of finite numbers, never a signalling NaN
-    const double lim = 1e-6;
-    asm("v_max_f64 %0, %1, %2" : "=v"(floor) : "v"(sel), "v"(lim));
+        // one v_max_f64: fmax() would first canonicalise its operand (a second v_max on the dependent chain); sel is a
+        // product of finite numbers, never a signalling NaN
+        const double lim = 1e-6;
+        asm("v_max_f64 %0, %1, %2" : "=v"(floor) : "v"(sel), "v"(lim));
 #else
-    floor = fmax(sel, 1e-6);
+        floor = fmax(sel, 1e-6);
 #endif
+    } else {
+        // CLAMP = false: the caller guarantees (by checking the minimum afterwards and redoing the block with CLAMP = true if it
+        // fails) that sel >= 1e-6, where max(sel, 1e-6) == sel bit for bit: the clamp's float64 latency leaves the chain
+        floor = sel;
+    }
     return mag > snr_ratio * floor; // :87 (snr_ratio = 1.5 there; contrib's floor_mask_ratio kwarg)
 }
 

@@ -129,3 +129,53 @@ def test_postprocess_matches_reference_statement(tmp_path):
     assert len(to_dcase_rows(prob, xyz, eval_version='2020')[0]) == 4
     write_dcase_csv(str(tmp_path / 'o.csv'), rows)
     assert sum(1 for _ in open(tmp_path / 'o.csv')) == len(rows)
+
+
+def _infer_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn.infer import infer_clips_sharded
+    from salsa_amd.crnn.testing import seeded_fill
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    net = SeldCRNN().eval()
+    seeded_fill(net, 3)
+    names = ['clip%02d' % i for i in (4, 0, 3, 1, 2)]                  # 5 clips over 2 ranks: shards of 3 and 2
+
+    def featurize(group):
+        return torch.stack([torch.randn(7, 128, 200, generator=torch.Generator().manual_seed(int(n[4:]))) for n in group])
+
+    def forward(x):
+        with torch.no_grad():
+            o = net(x)
+        return torch.sigmoid(o['event_frame_logit']), o['doa_frame_output']
+
+    rows = infer_clips_sharded(names, featurize, forward, rank, world, sub_batch=2, sed_threshold=0.5, n_label_frames=16)
+    torch.save(rows, os.path.join(tmp, 'rows%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_inference_matches_single_process(tmp_path):
+    """config 5's sharding on CPU (gloo): two ranks split the sorted clip list, every rank ends with every clip's DCASE rows,
+    identical to a single-process run."""
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn.infer import infer_clips_sharded
+    from salsa_amd.crnn.testing import seeded_fill
+    port = _free_port()
+    mp.spawn(_infer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'rows0.pt'), torch.load(tmp_path / 'rows1.pt')
+    assert r0 == r1 and sorted(r0) == ['clip%02d' % i for i in range(5)]
+    net = SeldCRNN().eval()
+    seeded_fill(net, 3)
+
+    def forward(x):
+        with torch.no_grad():
+            o = net(x)
+        return torch.sigmoid(o['event_frame_logit']), o['doa_frame_output']
+
+    featurize = lambda group: torch.stack([torch.randn(7, 128, 200, generator=torch.Generator().manual_seed(int(n[4:]))) for n in group])
+    solo = infer_clips_sharded(sorted(r0), featurize, forward, 0, 1, sub_batch=5, sed_threshold=0.5, n_label_frames=16)
+    assert solo == r0 and any(len(v) > 0 for v in solo.values())
