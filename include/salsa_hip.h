@@ -168,6 +168,16 @@ enum { SALSA_PIPE_SPLIT_PAIRS = 1, SALSA_PIPE_GRAPH = 2 };
 int salsa_plan_set_pipeline(salsa_plan *plan, int n_groups, int flags);
 int salsa_plan_set_groups(salsa_plan *plan, int n_groups);
 
+/* contrib/salsa_flexible.py accepts any number of microphones (stacked_covmat_eigh :52-77).  Up to 4 go through
+ * salsa_extract_batch (fewer than 4: pad with silent channels).  5 - 8 go through this entry point: plan created with
+ * SALSA_FLAG_FLEX (SALSA or SALSA-Lite, MIC), d_audio float32 planar [B][n_channels][N] with n_channels = 6 or 8 (an odd
+ * count: append one silent channel -- the covariance only gains a zero eigenvalue -- and drop its output planes),
+ * d_out float32 [B][2*n_channels - 1][T][F]: n_channels log-spectrograms, then n_channels - 1 spatial planes.  The
+ * N x N eigenproblem is solved by cyclic complex Jacobi in float64, one lane per gated TF bin. */
+size_t salsa_multichannel_workspace_bytes(const salsa_plan *plan, int n_channels, int batch, int64_t n_samples);
+int salsa_extract_multichannel(salsa_plan *plan, const float *d_audio, int n_channels, int batch, int64_t n_samples,
+                               float *d_out, void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
 /* Diagnostic: the kernels' float32 dB conversion 10*log10(max(1e-10, p)) (librosa.power_to_db(ref=1, amin=1e-10, top_db=None),
  * salsa_feature_extraction.py:194-195) applied elementwise to d_power[n] -> d_db[n].  It is the SAME device function the STFT
  * kernel inlines (hardware v_log_f32 times a constant); exported so a test can bound its error over the whole float32

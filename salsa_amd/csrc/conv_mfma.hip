@@ -262,13 +262,56 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
 // image load from a 16-byte zero constant.
 __device__ uint4 conv_zero16; // zero-initialised
 
-#ifndef CONV_ORDER
-#define CONV_ORDER 1 // 1: fragments ordered so that consecutive MFMAs never share an accumulator (0: row by row, round 1)
-#endif
 constexpr int APIX = 64;                             // bf16 per pixel in LDS (no padding)
 constexpr int ABUF = HALO_H * HALO_W * APIX;         // one tile
 constexpr int NBUF = 3;
 constexpr int AFETCH = (HALO_PIECES + 255) / 256;    // load instructions per thread per tile (the last one partial)
+
+// The 48 fragment steps of one tile of the LDS-direct kernel as a compile-time recursion (every index a constant: written as a
+// loop over a permuted step number the filter array was indexed "dynamically" and the compiler moved it to scratch memory).
+// Step S multiplies fragment FRAG(S) = (input row ir, tap column sx, channel block kc) while the next AD fragments are in
+// flight; rb[] are the lane's eight rotated base addresses (see the kernel).
+#ifndef CONV_ORDER
+#define CONV_ORDER 1 // 1: fragments ordered so that consecutive MFMAs never share an accumulator (0: row by row, round 1)
+#endif
+constexpr int conv64_frag(int s) { return CONV_ORDER ? (s < 24 ? ((s & 1) ? 36 + (s >> 1) : (s >> 1)) : 12 + (s - 24)) : s; }
+
+template <int U>
+__device__ __forceinline__ void conv64_lds_read(bf16x8 &dst, const unsigned (&rb)[8])
+{
+    constexpr int ir = U / 12, sx = (U / 4) % 3, kc = U & 3;
+    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                 : "=v"(dst)
+                 : "v"(rb[(2 * kc + sx + 2 * ir) & 7]), "n"(2 * ((ir * (TW + 2) + sx) * 64)));
+}
+
+template <int S, int AD>
+__device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&bb)[AD + 1], f32x16 (&acc)[RPW], const unsigned (&rb)[8])
+{
+    constexpr int RING = AD + 1;
+    if constexpr (S == 0) {
+#pragma unroll
+        for (int s = 0; s < AD; s++) { // (AD is 1 or 2: spelled out so that the fragment numbers stay template constants)
+            if (s == 0) conv64_lds_read<conv64_frag(0)>(bb[0], rb);
+            if (s == 1) conv64_lds_read<conv64_frag(1)>(bb[1 % RING], rb);
+            if (s == 2) conv64_lds_read<conv64_frag(2)>(bb[2 % RING], rb);
+        }
+    }
+    if constexpr (S < 48) {
+        if constexpr (S + AD < 48) conv64_lds_read<conv64_frag(S + AD < 48 ? S + AD : 0)>(bb[(S + AD) % RING], rb);
+        // fragment S has landed when at most the younger reads are outstanding
+        if constexpr (S + AD < 48) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bb[S % RING]) : "n"(AD));
+        else if constexpr (47 - S == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bb[S % RING]));
+        else if constexpr (47 - S == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bb[S % RING]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[S % RING]));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int u = conv64_frag(S), ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
+        if constexpr (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[S % RING], acc[0], 0, 0, 0);
+        if constexpr (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[S % RING], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        conv64_steps<S + 1, AD>(af, bb, acc, rb);
+    }
+}
 
 template <bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const unsigned short *__restrict__ x,
@@ -395,28 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         // v_mfma_f32_32x32x16_bf16 cannot start until its predecessor's 8 passes have drained (with the ds_read / s_waitcnt /
         // s_nop issue slots between them the gap is the microarchitecture guide's "+43 cycles" case): a third of the MFMAs
         // ran at half rate.  Interleaving row 0 with row 3 alternates the two accumulators on EVERY step.
-#if CONV_ORDER
-#define FRAG(s) ((s) < 24 ? (((s) & 1) ? 36 + ((s) >> 1) : ((s) >> 1)) : 12 + ((s) - 24))
-#else
-#define FRAG(s) (s)
-#endif
-#pragma unroll
-        for (int s = 0; s < AD; s++) LDS_BA(bb[s % RING], FRAG(s));
-#pragma unroll
-        for (int s = 0; s < 48; s++) {
-            if (s + AD < 48) LDS_BA(bb[(s + AD) % RING], FRAG(s + AD));
-            // fragment s has landed when at most the younger reads are outstanding
-            if (s + AD < 48) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bb[s % RING]) : "n"(AD));
-            else if (47 - s == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bb[s % RING]));
-            else if (47 - s == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bb[s % RING]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[s % RING]));
-            __builtin_amdgcn_sched_barrier(0);
-            const int u = FRAG(s), ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
-            if (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[s % RING], acc[0], 0, 0, 0);
-            if (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[s % RING], acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef FRAG
+        conv64_steps<0, AD>(af, bb, acc, rb);
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

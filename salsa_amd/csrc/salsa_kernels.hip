@@ -65,6 +65,7 @@ struct KParams {
     int tracking;
     int n_hop;
     int pair_sel;         // K1: -1 = both channel pairs of every frame in one launch; 0 / 1 = only channels {0,1} / {2,3}
+    int nch;              // audio channels per clip (even): 4, or 6 / 8 on the multichannel contrib surface; OC = 2*nch - 1
     double cond;
     double inv_cond;      // 1/cond (0 when cond == 0: unused, cond <= 1 short-circuits the gate)
     double delta;         // 2 pi fs / (n_fft * 343)
@@ -121,7 +122,7 @@ template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : 4;
 };
 
-template <int N, typename T, bool LITE, int NF>
+template <int N, typename T, bool LITE, int NF, int NPAIRS = 2>
 __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
@@ -156,12 +157,13 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
         }
     }
     if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
-    const float *clip = audio + (long)b * 4 * Ns;
+    constexpr int NCH = 2 * NPAIRS;              // channels per clip: 4 (the dataset scripts), 6 / 8 on the contrib surface
+    const float *clip = audio + (long)b * NCH * Ns;
     // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
     // path -- no per-load branching; frames that overlap a clip end take the reflect path (np.pad(mode='reflect'); one
     // fold suffices because Ns > N/2, checked on the host).
     const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
-    const int sstride = planar ? 1 : 4;
+    const int sstride = planar ? 1 : NCH;
     // Item order.  Full SALSA: PAIR-major (all the wave's frames of channels 0/1, then of channels 2/3), so consecutive
     // items re-read the 41 % of samples that overlapping frames share while they are still in L2 (frame-major order
     // puts another 4 KiB item and a whole CU's worth of traffic in between: measured 1.7x audio over-fetch).  SALSA-Lite
@@ -173,8 +175,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
 #endif
     const int nfr_ = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
     const int psel = LITE ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
-    auto item_frame = [&](int item) { return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1; };
-    auto item_pair = [&](int item) { return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1; };
+    auto item_frame = [&](int item) {
+        if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / NPAIRS;
+        return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1;
+    };
+    auto item_pair = [&](int item) {
+        if (NPAIRS != 2) return PAIR_MAJOR ? item / nfr_ : item % NPAIRS;
+        return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1;
+    };
     auto load_item = [&](int item, float *y0, float *y1) {
         const int t = t_begin + item_frame(item);
         const int c0 = 2 * item_pair(item);
@@ -200,10 +208,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
         }
     };
 
-    const int nitems = psel >= 0 ? nfr_ : nfr_ * 2;
+    const int nitems = psel >= 0 ? nfr_ : nfr_ * NPAIRS;
     float y0[R], y1[R];
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
-    float4 *xs = Xs + (long)b * Tn * 2 * kp.nd;
+    float4 *xs = Xs + (long)b * Tn * NPAIRS * kp.nd;
     const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    st_off(xs, 16u * (unsigned)((t * 2 + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
+                    st_off(xs, 16u * (unsigned)((t * NPAIRS + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
                 if (k >= kp.spec_lo && k < kp.spec_hi) {
                     const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + (k - kp.spec_lo));
                     st_off(o, off, spec(pa, c0, k - kp.spec_lo));
@@ -291,7 +299,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                     // (contrib's float32 frequency vector differs from delta*k by <= 6e-8 relative: same float32 result)
                     const float inv_scale = kp.feature == SALSA_FEATURE_IPD ? 0.318309886183790672f
                                                                            : (float)(1.0 / (kp.delta * (double)(k == 0 ? 1 : k)));
-                    // pair 0 contributes channel 1 (phase vs channel 0); pair 1 contributes channels 2 and 3
+                    // pair 0 contributes channel 1 (phase vs channel 0); pair p >= 1 contributes channels 2p and 2p+1: the phase of
+                    // channel c goes to output plane NCH + c - 1, i.e. NCH - 1 and NCH planes above this pair's spectrogram
                     auto phase = [&](const float2 xc) -> float {
                         if (!(f < kp.upper)) return 0.f; // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
                         float wr = xc.x * x0.x + xc.y * x0.y;
@@ -304,8 +313,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                         }
                         return atan2f(wi, wr) * inv_scale;
                     };
-                    if (pr == 1) st_off(o, off + 3u * plane, phase(xa));
-                    st_off(o, off + 4u * plane, phase(xb));
+                    if (pr >= 1) st_off(o, off + (unsigned)(NCH - 1) * plane, phase(xa));
+                    st_off(o, off + (unsigned)NCH * plane, phase(xb));
                 }
             }
         };
@@ -397,7 +406,7 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 //    iteration, which made each iteration wait for the loads it had just issued.)
 constexpr int TR_BINS = 32;
 #ifndef TR_LAZY_CLAMP
-#define TR_LAZY_CLAMP 1
+#define TR_LAZY_CLAMP 0 // measured: 0.35 ms with the lazy clamp against 0.22 ms without -- the chain is not what bounds the step
 #endif
 // v_writelane_b32 through the LLVM intrinsic (this clang has no __builtin for it).  Not inline asm: a VALU compare that writes
 // VCC needs two wait states before v_writelane may read it, and only the compiler's hazard recogniser inserts them -- the
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     const int bin = g * BINS + col;
     const bool active = bin < kp.nd;
     const int Tn = kp.T;
-    const int stride = 2 * kp.nd; // float4 elements per frame
+    const int stride = (kp.nch / 2) * kp.nd; // float4 elements per frame (one per channel pair and bin)
     const float4 *x0 = Xs + (long)b * Tn * stride + (active ? bin : 0);
     const int nchunks = (Tn + TR_CH - 1) / TR_CH;
     const bool raw = kp.flex != 0;
@@ -767,6 +776,151 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
 }
 
+// ------------------------------------------------------------------------------------------------------------ K3, N channels
+// contrib/salsa_flexible.py takes ANY number of microphones (stacked_covmat_eigh :52-77: an N x N Hermitian eigenproblem per
+// gated TF bin).  The 4 x 4 closed form above does not generalise, so 5 - 8 microphones (padded to an even count NCH = 6 | 8
+// with a silent channel, which only adds a zero eigenvalue) take this kernel: one lane per (frame, bin), summed covariance of
+// the 2*n_hop+1 frames in float64, cyclic complex Jacobi with the rotations accumulated (eigenvalues = the diagonal, eigen-
+// vectors = the accumulated columns), gate "largest > second largest * ew_thresh" (:353), feature angle(conj(u_0) u_c) / f
+// (:360-362).  A completeness path, not a tuned one: the 2 x NCH^2 float64 matrices spill to scratch.
+template <int NCH> struct hermn {
+    double ar[NCH][NCH], ai[NCH][NCH];
+};
+
+template <int NCH>
+__device__ __forceinline__ void hermn_rotate(hermn<NCH> &A, hermn<NCH> &V, const int p, const int q)
+{
+    const double xr = A.ar[p][q], xi = A.ai[p][q];
+    const double r2 = xr * xr + xi * xi;
+    if (r2 == 0.0) return;
+    const double r = sqrt(r2);
+    // a_pq = r e^{i phi}.  U = D G: D_qq = e^{-i phi} makes the pivot real, G is the real Jacobi rotation that zeroes it.
+    const double er = xr / r, ei = xi / r;
+    const double tau = (A.ar[q][q] - A.ar[p][p]) / (2.0 * r);
+    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+    // U_pp = c, U_qp = -sn e^{-i phi}, U_pq = sn, U_qq = c e^{-i phi}
+    const double uqp_r = -sn * er, uqp_i = sn * ei, uqq_r = c * er, uqq_i = -c * ei;
+    auto cols = [&](hermn<NCH> &M) { // M <- M U (columns p and q)
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const double pr = M.ar[i][p], pi = M.ai[i][p], qr = M.ar[i][q], qi = M.ai[i][q];
+            M.ar[i][p] = pr * c + (qr * uqp_r - qi * uqp_i);
+            M.ai[i][p] = pi * c + (qr * uqp_i + qi * uqp_r);
+            M.ar[i][q] = pr * sn + (qr * uqq_r - qi * uqq_i);
+            M.ai[i][q] = pi * sn + (qr * uqq_i + qi * uqq_r);
+        }
+    };
+    cols(A);
+#pragma unroll
+    for (int j = 0; j < NCH; j++) { // A <- U^H A (rows p and q): conj(U_pp) = c, conj(U_qp), conj(U_pq) = sn, conj(U_qq)
+        const double pr = A.ar[p][j], pi = A.ai[p][j], qr = A.ar[q][j], qi = A.ai[q][j];
+        A.ar[p][j] = c * pr + (uqp_r * qr + uqp_i * qi);
+        A.ai[p][j] = c * pi + (uqp_r * qi - uqp_i * qr);
+        A.ar[q][j] = sn * pr + (uqq_r * qr + uqq_i * qi);
+        A.ai[q][j] = sn * pi + (uqq_r * qi - uqq_i * qr);
+    }
+    A.ar[p][q] = A.ai[p][q] = A.ar[q][p] = A.ai[q][p] = 0.0; // exactly, as the algebra says
+    A.ai[p][p] = A.ai[q][q] = 0.0;
+    cols(V);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64) void cov_eig_n_kernel(const KParams kp, const float4 *__restrict__ Xs,
+                                                       const unsigned *__restrict__ valid32, float *__restrict__ out)
+{
+    constexpr int NP = NCH / 2;
+    const int t = blockIdx.x, b = blockIdx.y, Tn = kp.T;
+    const int ng32 = (kp.nd + TR_BINS - 1) / TR_BINS;
+    float *of = out + ((long)b * kp.OC + NCH) * Tn * kp.F + (long)t * kp.F; // first spatial plane, this frame's row
+    const long plane = (long)Tn * kp.F;
+    const float4 *xclip = Xs + (long)b * Tn * NP * kp.nd;
+    for (int bin = threadIdx.x; bin < kp.F; bin += 64) {
+        float e[NCH - 1];
+#pragma unroll
+        for (int c = 0; c < NCH - 1; c++) e[c] = 0.f;
+        bool gated = bin < kp.nd;
+        if (gated && kp.tracking) gated = (valid32[((long)b * ng32 + (bin >> 5)) * Tn + t] >> (bin & 31)) & 1u;
+        if (gated) {
+            hermn<NCH> A, V;
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    A.ar[i][j] = A.ai[i][j] = 0.0;
+                    V.ar[i][j] = i == j ? 1.0 : 0.0;
+                    V.ai[i][j] = 0.0;
+                }
+            for (int k = -kp.n_hop; k <= kp.n_hop; k++) { // summed covariance, wrap on the time axis (:316-318, :347-349)
+                int tt = t + k;
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                double xr[NCH], xi[NCH];
+#pragma unroll
+                for (int pr = 0; pr < NP; pr++) {
+                    const float4 v = xclip[((long)tt * NP + pr) * kp.nd + bin];
+                    xr[2 * pr] = v.x; xi[2 * pr] = v.y; xr[2 * pr + 1] = v.z; xi[2 * pr + 1] = v.w;
+                }
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) { // x_i conj(x_j)
+                        A.ar[i][j] += xr[i] * xr[j] + xi[i] * xi[j];
+                        A.ai[i][j] += xi[i] * xr[j] - xr[i] * xi[j];
+                    }
+            }
+            double tr = 0.0;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) tr += A.ar[i][i];
+            bool good = false;
+            if (tr > 0.0) {
+                for (int sweep = 0; sweep < 16; sweep++) {
+                    double off = 0.0;
+#pragma unroll
+                    for (int p = 0; p < NCH; p++)
+#pragma unroll
+                        for (int q = p + 1; q < NCH; q++) off += A.ar[p][q] * A.ar[p][q] + A.ai[p][q] * A.ai[p][q];
+                    if (off <= 1e-34 * tr * tr) break;
+#pragma unroll
+                    for (int p = 0; p < NCH; p++)
+#pragma unroll
+                        for (int q = p + 1; q < NCH; q++) hermn_rotate<NCH>(A, V, p, q);
+                }
+                int i1 = 0;
+                double l1 = A.ar[0][0];
+#pragma unroll
+                for (int i = 1; i < NCH; i++)
+                    if (A.ar[i][i] > l1) { l1 = A.ar[i][i]; i1 = i; }
+                double l2 = -1e300;
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+                    if (i != i1 && A.ar[i][i] > l2) l2 = A.ar[i][i];
+                good = l1 > l2 * kp.cond; // ews[:, -1] > ews[:, -2] * ew_thresh (:353)
+                if (good) {
+                    double ur[NCH], ui[NCH];
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) {
+                        ur[i] = ui[i] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NCH; j++)
+                            if (j == i1) { ur[i] = V.ar[i][j]; ui[i] = V.ai[i][j]; }
+                    }
+                    const int kb = bin + kp.lower;
+                    const double den = (double)((float)(kb == 0 ? 1 : kb) * (float)kp.delta); // float32 norm_freq (:188-190)
+#pragma unroll
+                    for (int c = 1; c < NCH; c++) { // angle(conj(u_0) u_c) / f   (:360-362)
+                        const double wr = ur[0] * ur[c] + ui[0] * ui[c], wi = ur[0] * ui[c] - ui[0] * ur[c];
+                        e[c - 1] = (float)(atan2(wi, wr) / den);
+                    }
+                }
+            }
+            if (!good && !kp.tracking) e[0] = __builtin_nanf(""); // marks "failed the test" for flex_allpass_kernel
+        }
+#pragma unroll
+        for (int c = 0; c < NCH - 1; c++) of[c * plane + bin] = e[c];
+    }
+}
+
 // reference layout (n_bins, n_frames, 4) complex64 -> internal Xs[b][t][pair][bin] float4
 __global__ void relayout_kernel(const float4 *__restrict__ X, float4 *__restrict__ Xs, int B, int nb, int Tn)
 {
@@ -826,14 +980,13 @@ __global__ __launch_bounds__(256) void flex_allpass_kernel(const KParams kp, flo
 {
     const int bin = blockIdx.x * 256 + threadIdx.x;
     if (bin >= kp.nd) return;
-    float *of = out + ((long)blockIdx.y * kp.OC + 4) * kp.T * kp.F + bin;
+    float *of = out + ((long)blockIdx.y * kp.OC + kp.nch) * kp.T * kp.F + bin; // first spatial plane
     bool dead = false;
     for (int t = 0; t < kp.T; t++) {
         const float v = of[t * kp.F];
         dead = dead || (v != v);
         if (dead) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) of[(c * kp.T + t) * kp.F] = 0.f;
+            for (int c = 0; c < kp.nch - 1; c++) of[(c * kp.T + t) * kp.F] = 0.f;
         }
     }
 }
@@ -965,6 +1118,23 @@ struct salsa_plan {
         int64_t n_samples;
     } gkey;
 };
+
+template <int NPAIRS>
+static int launch_stft_multi(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
+{
+    const bool lite = kp.feature == SALSA_FEATURE_LITE;
+    constexpr int NF = 4;
+    dim3 grid((unsigned)((kp.T + 4 * NF - 1) / (4 * NF)), (unsigned)kp.B);
+    if (pl->p.n_fft == 512) {
+        if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF, NPAIRS>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<512, double, false, NF, NPAIRS>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    } else {
+        if (lite) hipLaunchKernelGGL((stft_kernel<256, double, true, NF, NPAIRS>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<256, double, false, NF, NPAIRS>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    }
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
 
 extern "C" {
 
@@ -1189,6 +1359,7 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.tracking = pl->p.is_tracking;
     kp.n_hop = pl->p.n_hopframes;
     kp.pair_sel = -1;
+    kp.nch = 4;
     kp.cond = pl->p.cond_num;
     kp.inv_cond = pl->p.cond_num > 0 ? 1.0 / pl->p.cond_num : 0.0;
     kp.delta = pl->delta;
@@ -1376,6 +1547,65 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         pl->gkey.flags = pl->pipe_flags;
     }
     HIP_TRY(hipGraphLaunch(pl->gexec, s));
+    return SALSA_OK;
+}
+
+size_t salsa_multichannel_workspace_bytes(const salsa_plan *pl, int n_channels, int batch, int64_t n_samples)
+{
+    if (!pl || batch <= 0 || n_samples <= 0 || n_channels < 4 || n_channels > 8 || (n_channels & 1)) return 0;
+    if (pl->p.feature_type != SALSA_FEATURE_SALSA) return 256;
+    const size_t T = 1 + n_samples / pl->p.hop_len;
+    return align256((size_t)batch * T * n_channels * pl->nd * sizeof(float2)) +
+           align256((size_t)batch * ((pl->nd + TR_BINS - 1) / TR_BINS) * T * sizeof(unsigned)) + 256;
+}
+
+int salsa_extract_multichannel(salsa_plan *pl, const float *d_audio, int n_channels, int batch, int64_t n_samples, float *d_out,
+                               void *d_workspace, size_t workspace_bytes, void *hip_stream)
+{
+    if (!pl || !d_audio || !d_out || batch <= 0 || n_samples <= 0) return fail(SALSA_EINVAL, "salsa_extract_multichannel: bad argument%s");
+    if (!pl->flex || pl->p.audio_layout != SALSA_LAYOUT_PLANAR)
+        return fail(SALSA_EINVAL, "salsa_extract_multichannel is the contrib (SALSA_FLAG_FLEX) surface, planar audio%s");
+    if (n_channels != 6 && n_channels != 8)
+        return fail(SALSA_EINVAL, "salsa_extract_multichannel takes 6 or 8 channels (pad an odd count with a silent channel; <= 4: salsa_extract_batch)%s");
+    if (n_samples <= pl->p.n_fft / 2) return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
+    const int64_t T64 = 1 + n_samples / pl->p.hop_len;
+    const int OC = 2 * n_channels - 1;
+    if (n_samples * 4 * n_channels >= INT32_MAX || T64 * OC * pl->F >= INT32_MAX / 2 || T64 * n_channels * (pl->nd > 0 ? pl->nd : 1) >= INT32_MAX / 16 ||
+        T64 > 65535 * 16)
+        return fail(SALSA_EINVAL, "clip too long for 32-bit per-clip indexing (split it)%s");
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != pl->device)
+            return fail(SALSA_EINVAL, "the plan's tables live on the device that was current at salsa_plan_create; make it current%s");
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    KParams kp = make_kparams(pl, batch, n_samples);
+    kp.nch = n_channels;
+    kp.OC = OC;
+    kp.sc_mean = kp.sc_std = nullptr;
+    const bool full = pl->p.feature_type == SALSA_FEATURE_SALSA;
+    float4 *Xs = nullptr;
+    unsigned *valid = nullptr;
+    if (full) {
+        const size_t need = salsa_multichannel_workspace_bytes(pl, n_channels, batch, n_samples);
+        if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
+        Xs = (float4 *)d_workspace;
+        valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * n_channels * kp.nd * sizeof(float2)));
+    }
+    int rc = n_channels == 6 ? launch_stft_multi<3>(pl, kp, d_audio, d_out, Xs, s) : launch_stft_multi<4>(pl, kp, d_audio, d_out, Xs, s);
+    if (rc || !full) return rc;
+    if (kp.tracking && kp.nd > 0) {
+        hipLaunchKernelGGL(tracker_kernel, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
+        HIP_TRY(hipGetLastError());
+    }
+    dim3 grid((unsigned)kp.T, (unsigned)kp.B);
+    if (n_channels == 6) hipLaunchKernelGGL(cov_eig_n_kernel<6>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
+    else hipLaunchKernelGGL(cov_eig_n_kernel<8>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
+    HIP_TRY(hipGetLastError());
+    if (!kp.tracking && kp.nd > 0) {
+        hipLaunchKernelGGL(flex_allpass_kernel, dim3((unsigned)((kp.nd + 255) / 256), (unsigned)kp.B), dim3(256), 0, s, kp, d_out);
+        HIP_TRY(hipGetLastError());
+    }
     return SALSA_OK;
 }
 

@@ -128,6 +128,25 @@ class SalsaExtractor:
 
     __call__ = extract
 
+    def extract_multichannel(self, audio: torch.Tensor) -> torch.Tensor:
+        """contrib surface, 6 or 8 microphones (salsa_extract_multichannel): audio float32 CUDA [B, C, N] planar ->
+        [B, 2C-1, T, F] float32 (C log-spectrograms, then C-1 spatial planes).  The plan must carry FLAG_FLEX."""
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.is_contiguous()
+        B, ch, N = audio.shape
+        if ch not in (6, 8):
+            raise ValueError('extract_multichannel takes 6 or 8 channels, got %d' % ch)
+        if audio.device != self.device:
+            raise ValueError('plan is bound to %s, audio is on %s' % (self.device, audio.device))
+        _, T, F = self.output_shape(N)
+        out = torch.empty((B, 2 * ch - 1, T, F), dtype=torch.float32, device=audio.device)
+        ws = self._workspace(int(self.L.salsa_multichannel_workspace_bytes(self._plan, ch, B, N)))
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_extract_multichannel(self._plan, C.c_void_p(audio.data_ptr()), ch, B, N, C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        if rc:
+            _raise(rc)
+        return out
+
     def logspec(self, audio: torch.Tensor) -> torch.Tensor:
         """MagStftExtractor.extract on device: audio [B,4,N] planar -> [B,4,T,F]."""
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.is_contiguous()

@@ -8,9 +8,11 @@ Same constructor arguments, call arguments, defaults, assertions and output layo
 and ``SalsaLiteFeatures`` (:373-400); the arithmetic runs in libsalsa_hip.so (salsa_extract_batch with
 SALSA_FLAG_FLEX + salsa_to_freq_major -- include/salsa_hip.h lists what that flag changes relative to the dataset
 scripts).  ``extract_batch`` is the same computation for a device-resident batch of clips (the Dataset-fused form SURVEY
-config 4 wants).  1 < channels <= 4: clips with 2 or 3 microphones are padded with silent channels, which leaves the
-coherence gate and the principal eigenvector unchanged (the covariance only gains zero eigenvalues); the padded output
-channels are dropped.  More than 4 microphones are not supported by the gfx950 kernels (4 x 4 closed-form eigen-solver).
+config 4 wants).  Any microphone count from 2 to 8, like the reference's "arbitrary channels": 2 or 3 microphones are padded
+with silent channels to the 4-channel kernels (closed-form 4 x 4 eigen-solver), 5 - 8 to an even count for
+salsa_extract_multichannel (N x N Hermitian eigenproblem by cyclic Jacobi, one lane per gated TF bin).  A silent channel
+leaves the coherence gate and the principal eigenvector unchanged (the covariance only gains a zero eigenvalue); its
+output planes are dropped.
 """
 import ctypes as C
 
@@ -61,12 +63,20 @@ class SpatialFeaturesAbstract:
         return self._plans[key]
 
     def extract_batch(self, audio: torch.Tensor, clip_freqs=True, clip_spatial_alias=False, **feat_kwargs) -> torch.Tensor:
-        """audio float32 CUDA [B, C, N], 2 <= C <= 4 -> float64 CUDA [B, 2C-1, F, T] (freq-major like the reference)."""
+        """audio float32 CUDA [B, C, N], 2 <= C <= 8 -> float64 CUDA [B, 2C-1, F, T] (freq-major like the reference)."""
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3
         B, n_ch, N = audio.shape
-        if not 2 <= n_ch <= 4:
-            raise ValueError('the MI355X kernels take 2 to 4 microphones, got %d' % n_ch)
+        if not 2 <= n_ch <= 8:
+            raise ValueError('the MI355X kernels take 2 to 8 microphones, got %d' % n_ch)
         ex = self._plan(clip_freqs, clip_spatial_alias, **feat_kwargs)
+        if n_ch > 4:
+            n_pad = n_ch + (n_ch & 1)                                              # 6 or 8
+            if n_pad != n_ch:
+                audio = torch.cat([audio, audio.new_zeros((B, 1, N))], dim=1)
+            out = to_freq_major(ex.extract_multichannel(audio.contiguous()))        # [B, 2*n_pad-1, F, T] float64
+            if n_pad != n_ch:
+                out = torch.cat([out[:, :n_ch], out[:, n_pad:n_pad + n_ch - 1]], dim=1)
+            return out
         if n_ch < 4:
             audio = torch.cat([audio, audio.new_zeros((B, 4 - n_ch, N))], dim=1)
         feat = ex.extract(audio.contiguous())                                  # [B, 7, T, F] float32

@@ -420,11 +420,13 @@ def test_fused_scaler_equals_separate_normalisation(dev):
 
 
 # ----------------------------------------------------------------------------------------------- contrib on-the-fly surface
-def test_contrib_flexible_surface_matches_reference_golden(dev):
-    """SalsaFeatures / SalsaLiteFeatures of contrib/salsa_flexible.py, called like the reference's docstrings."""
+@pytest.mark.parametrize('fixture', ['g10_flexible', 'g13_flexible_multi'])
+def test_contrib_flexible_surface_matches_reference_golden(dev, fixture):
+    """SalsaFeatures / SalsaLiteFeatures of contrib/salsa_flexible.py, called like the reference's docstrings:
+    2 - 4 microphones (g10, the 4-channel kernels) and 5 - 8 (g13, salsa_extract_multichannel: N x N Jacobi eigen-solver)."""
     from flex_compare import compare_flexible
     from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures
-    meta, g = load_golden('g10_flexible')
+    meta, g = load_golden(fixture)
     for name, c in meta['cases'].items():
         y = synth_clip(c['seed'], meta['n'], n_ch=c['n_ch'])
         assert sha256_of(y) == c['sha']
@@ -488,7 +490,7 @@ def test_to_freq_major(dev):
     assert torch.equal(to_freq_major(x), x.permute(0, 1, 3, 2).double())
     with pytest.raises(ValueError):
         from salsa_amd.flexible import SalsaFeatures
-        SalsaFeatures().extract_batch(torch.zeros(1, 5, 4000, device=dev))
+        SalsaFeatures().extract_batch(torch.zeros(1, 9, 4000, device=dev))          # 2 - 8 microphones
     with pytest.raises(AssertionError):
         from salsa_amd.flexible import SalsaFeatures
         SalsaFeatures(fmax_doa=9500)                                            # contrib :183
@@ -541,3 +543,30 @@ def test_host_pipeline_matches_direct_extraction(dev):
     assert all(np.array_equal(a, b) for a, b in zip(got2, want[:2]))
     got3 = [o.copy() for o in pipe.run(fill=lambda buf, i: buf.__setitem__(Ellipsis, ys[i]), n_batches=5, shape=ys[0].shape)]
     assert all(np.array_equal(a, b) for a, b in zip(got3, want[:5]))
+
+
+@pytest.mark.parametrize('n_ch', [5, 6, 8])
+def test_contrib_multichannel_batch_against_oracle(dev, oracle, n_ch):
+    """salsa_extract_multichannel (5 - 8 microphones: N x N Hermitian eigenproblem by Jacobi) on a batch of longer clips,
+    tracking on and off, against the oracle (which golden g13 ties to the reference)."""
+    from flex_compare import compare_flexible
+    from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures
+    n = 2 * 24000 + 77
+    ys = np.stack([synth_clip(600 + 10 * n_ch + i, n, n_ch=n_ch) for i in range(2)])
+    a = torch.from_numpy(ys).to(dev)
+    ctor = dict(fs=24000, stft_winsize=512, hop_length=300, fmin_doa=50, fmax_doa=4000, fmax_spec=9000)
+    for kind, cls, call in (('salsa', SalsaFeatures, dict(clip_freqs=True, clip_spatial_alias=True, ew_thresh=4.0)),
+                            ('salsa', SalsaFeatures, dict(clip_freqs=False, clip_spatial_alias=False, is_tracking=False,
+                                                          ew_thresh=1.05)),
+                            ('lite', SalsaLiteFeatures, dict(clip_freqs=True, clip_spatial_alias=False))):
+        out = cls(**ctor).extract_batch(a, **call).cpu().numpy()
+        assert out.shape[1] == 2 * n_ch - 1
+        for i in range(2):
+            kw = dict(ctor)
+            kw.update(call)
+            ref = oracle.flexible(ys[i], kind=kind, **kw)
+            case = {'n_ch': n_ch, 'ctor': ctor, 'call': {'clip_freqs': call['clip_freqs']}}
+            compare_flexible(out[i], ref[:n_ch].astype(np.float32), ref[n_ch:], case, n, spec_tol=(RTOL, ATOL_DB),
+                             spat_tol=ATOL_SP, spat_rtol=RTOL)
+        if kind == 'salsa' and call.get('is_tracking', True):
+            assert (out[:, n_ch:] != 0).any(), 'degenerate case: nothing passed the gates'

@@ -249,9 +249,10 @@ def g8_stft():
 
 
 # ----------------------------------------------------------------------------------------------- G10: contrib on-the-fly
-def g10_flexible():
+def g10_flexible(fixture='g10_flexible', n=27000, cases=None):
     """contrib/salsa_flexible.py: SalsaFeatures / SalsaLiteFeatures called as their docstrings show.
-    Spectrogram channels are stored as float32 (their working dtype), spatial channels as float64."""
+    Spectrogram channels are stored as float32 (their working dtype), spatial channels as float64.
+    fixture g13_flexible_multi: the same for 5 - 8 microphones (shorter clips: 15 planes per case)."""
     import importlib.util
     if not hasattr(np, 'bool'):
         np.bool = bool        # removed in numpy >= 1.24; used at contrib/salsa_flexible.py:335
@@ -259,8 +260,7 @@ def g10_flexible():
                                                   os.path.join(ref_shims.REF_ROOT, 'contrib', 'salsa_flexible.py'))
     flex = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(flex)
-    n = 27000                                                     # 1.125 s -> 91 frames
-    cases = [  # name, kind, seed, n_ch, ctor kwargs, call kwargs
+    cases = cases or [  # name, kind, seed, n_ch, ctor kwargs, call kwargs;  n = 27000: 1.125 s -> 91 frames
         ('salsa_default', 'salsa', 171, 4, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
         ('salsa_alias', 'salsa', 172, 4, {}, dict(clip_freqs=True, clip_spatial_alias=True)),
         ('salsa_full_axis', 'salsa', 173, 4, {}, dict(clip_freqs=False, clip_spatial_alias=True)),
@@ -286,9 +286,25 @@ def g10_flexible():
         arrays[name + '_spatial'] = out[n_ch:]
         meta['cases'][name] = {'kind': kind, 'seed': seed, 'n_ch': n_ch, 'sha': sha256_of(y), 'ctor': ctor, 'call': kw,
                                'nonzero': float((out[n_ch:] != 0).mean())}
-    save('g10_flexible', meta, **arrays)
+    save(fixture, meta, **arrays)
     for k, v in meta['cases'].items():
         print('   ', k, 'spatial non-zero fraction %.3f' % v['nonzero'])
+
+
+G13_CASES = [
+    # more than 4 microphones ("arbitrary channels", stacked_covmat_eigh :52-77): N x N eigenproblems
+        ('salsa_6mics', 'salsa', 181, 6, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('salsa_8mics_alias', 'salsa', 182, 8, {}, dict(clip_freqs=True, clip_spatial_alias=True)),
+        ('salsa_5mics_kwargs', 'salsa', 183, 5, dict(fmin_doa=100, fmax_doa=4000, fmax_spec=8000),
+         dict(clip_freqs=True, clip_spatial_alias=True, ew_thresh=3.0, covmat_avg_neighbours=2, floor_mask_ratio=2.0)),
+        ('salsa_7mics_notrack', 'salsa', 184, 7, {}, dict(clip_freqs=True, clip_spatial_alias=False, is_tracking=False)),
+        ('lite_8mics', 'lite', 185, 8, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('lite_5mics_full_axis', 'lite', 186, 5, {}, dict(clip_freqs=False, clip_spatial_alias=True)),
+]
+
+
+def g13_flexible_multi():
+    g10_flexible('g13_flexible_multi', 13500, G13_CASES)              # 0.5625 s -> 46 frames
 
 
 # ----------------------------------------------------------------------------------------------- G11: train augmentation
@@ -382,5 +398,6 @@ if __name__ == '__main__':
     g4_lite()
     g8_stft()
     g10_flexible()
+    g13_flexible_multi()
     g11_augment()
     g12_metrics()
