@@ -10,12 +10,13 @@ cd /tmp
 python -c "import sys; sys.path.insert(0,'$GRAFT_REPO_ROOT'); import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
 i=0
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
+            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" \
             "FETCH_SIZE GRBM_GUI_ACTIVE" \
             "WRITE_SIZE GRBM_GUI_ACTIVE" \
-            "TCC_HIT_sum TCC_MISS_sum" ; do
+            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-crnn --blocks 1 > $OUT/p$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-crnn --blocks 1 > $OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $CTRS"
 done
 python - <<PY
