@@ -50,6 +50,13 @@ int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, const float
  * shift NULL: plain convolution, else y = [relu](conv + shift[co]) with the BatchNorm folded as above */
 int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *wq, const float *shift,
                           void *y, int relu, int64_t N, int Cin, int H, int W, void *hip_stream);
+/* the WIDE 3x3 / stride 1 / pad 1 convolutions (Cin a multiple of 32, Cout a multiple of 64: the 128 / 256 / 512-channel
+ * residual stages, models/model_utils.py:312-367, :429-500): implicit GEMM over the flattened pixel axis, both operands staged
+ * through LDS (salsa_amd/csrc/conv_wide.hip).  x [N][H][W][Cin], w [Cout][3][3][Cin], y [N][H][W][Cout], all bf16; float32
+ * accumulation.  The data gradient is the same call on dy with w'[ci][r][s][co] = w[co][2-r][2-s][ci].
+ * salsa_nn_conv3x3_wide_supported: 1 if the shape is taken (the padded input chunk of a 512-pixel tile must fit its LDS buffer). */
+int salsa_nn_conv3x3_wide_supported(int64_t N, int H, int W, int Cin, int Cout);
+int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

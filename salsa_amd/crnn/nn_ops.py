@@ -13,6 +13,7 @@ _DT = {torch.float32: (0, 4), torch.bfloat16: (1, 8)}
 USE_HIP_POOL = os.environ.get('SALSA_HIP_POOL', '1') != '0'
 USE_HIP_BN = os.environ.get('SALSA_HIP_BN', '1') != '0'
 USE_HIP_CONV = os.environ.get('SALSA_HIP_CONV', '1') != '0'
+USE_HIP_CONV_WIDE = os.environ.get('SALSA_HIP_CONV_WIDE', '1') != '0'   # the 128 / 256 / 512-channel 3x3 layers (conv_wide.hip)
 
 
 def _stream(t):
@@ -181,6 +182,42 @@ class _Conv3x3C64(torch.autograd.Function):
         return gx, gw
 
 
+def _conv_wide(x, w):
+    """salsa_nn_conv3x3_wide: x (N,Cin,H,W) bf16 channels-last, w (Cout,Cin,3,3) bf16 channels-last -> (N,Cout,H,W)."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_nn_conv3x3_wide(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, _stream(x))
+    if rc:
+        raise RuntimeError('salsa_nn_conv3x3_wide failed (%d)' % rc)
+    return y
+
+
+class _Conv3x3Wide(torch.autograd.Function):
+    """The wide 3x3 convolutions (Cin, Cout in 64..512, not 64 -> 64) on the flattened-pixel implicit-GEMM MFMA kernel
+    (salsa_amd/csrc/conv_wide.hip): forward and data gradient (the same kernel with the flipped / transposed filter); the
+    weight gradient stays with MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, wb)
+        return _conv_wide(x, wb)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wb = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_wide(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].float()
+        return gx, gw
+
+
 def _planar_rows(x):
     """(N, C, H, W) view whose rows are contiguous and whose planes / batches do not overlap (e.g. a time crop of NCHW)."""
     N, Cn, H, W = x.shape
@@ -251,10 +288,22 @@ class Conv3x3(torch.nn.Conv2d):
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.bias is None
                 and self.dilation == (1, 1) and self.groups == 1 and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31 // 64)
 
+    def _wide_eligible(self, x):
+        bf16 = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        return (USE_HIP_CONV and USE_HIP_CONV_WIDE and x.is_cuda and bf16 and x.dim() == 4 and self.kernel_size == (3, 3)
+                and self.stride == (1, 1) and self.padding == (1, 1) and self.bias is None and self.dilation == (1, 1)
+                and self.groups == 1 and not (self.in_channels == 64 and self.out_channels == 64)
+                and _lib.load().salsa_nn_conv3x3_wide_supported(x.shape[0], x.shape[2], x.shape[3], self.in_channels,
+                                                                self.out_channels))
+
     def forward(self, x):
         if self._hip_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
+        if self._wide_eligible(x):
+            with torch.autocast('cuda', enabled=False):
+                return _Conv3x3Wide.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
         if self._stem_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3Stem.apply(x, self.weight)

@@ -442,3 +442,33 @@ def test_register_resident_gru_training_scan_gradients():
     torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-2, atol=2e-3)
     for (n, p), (_, q) in zip(gru.named_parameters(), ref.named_parameters()):
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-2, atol=1e-2 * float(q.grad.abs().max()), msg=n)
+
+
+def test_wide_conv_kernel_matches_torch_forward_and_gradients():
+    """salsa_nn_conv3x3_wide (flattened-pixel implicit GEMM, conv_wide.hip) against float32 F.conv2d on the bf16-rounded
+    operands: every channel pairing of the residual stages, map widths 50 / 25 / 12, batches whose 512-pixel tiles straddle
+    image boundaries and end ragged; forward and data gradient (the weight gradient is MIOpen's)."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(0)
+    for n, cin, cout, h, w in ((3, 64, 128, 40, 50), (2, 128, 128, 37, 50), (5, 128, 256, 20, 25), (3, 256, 256, 23, 25),
+                               (7, 256, 512, 40, 12), (5, 512, 512, 9, 12), (2, 128, 64, 16, 50), (1, 96, 192, 5, 7)):
+        assert nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(n, h, w, cin, cout)
+        x = torch.randn((n, cin, h, w), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        xa = x.clone().requires_grad_(True)
+        wa = wt.clone().requires_grad_(True)
+        y = nn_ops._Conv3x3Wide.apply(xa, wa)
+        xr = x.float().requires_grad_(True)
+        wr = wt.to(torch.bfloat16).float().requires_grad_(True)
+        ref = F.conv2d(xr, wr, padding=1)
+        scale = float(ref.abs().max())
+        assert float((y.float() - ref).abs().max()) < 1e-2 * scale, (cin, cout, h, w)      # bf16 output rounding: 2^-9 relative
+        gy = torch.randn(ref.shape, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y.backward(gy)
+        ref.backward(gy.float())
+        assert float((xa.grad.float() - xr.grad).abs().max()) < 1e-2 * float(xr.grad.abs().max()), (cin, cout, h, w)
+        assert float((wa.grad - wr.grad).abs().max()) < 3e-2 * float(wr.grad.abs().max()), (cin, cout, h, w)
+    assert not nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(2, 8, 8, 48, 64)          # Cin not a multiple of 32
+    assert not nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(2, 40, 200, 128, 128)     # 200-pixel rows: chunk exceeds its LDS buffer
