@@ -27,11 +27,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WV = 8;                 // waves per workgroup
-constexpr int TM = 64 * WV;           // pixels per workgroup
 constexpr int KC = 32;                // input channels per chunk (2 MFMA k-steps)
-constexpr int XL_BYTES = 53248;       // input chunk: up to 832 slots of 64 bytes
-constexpr int MAX_PIECES = (XL_BYTES / 16 + 64 * WV - 1) / (64 * WV); // 16-byte pieces a thread stages per chunk
+constexpr int MAX_XL_BYTES = 53248;   // input chunk: up to 832 slots of 64 bytes (a multiple of 1 KiB: whole wave-loads)
+
+__device__ uint4 wide_zero16; // zero-initialised: the source of every padding piece
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
@@ -43,16 +42,27 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 // byte offset of 16-byte piece q of 64-byte row `row` (XOR swizzle, see the header)
 __device__ __forceinline__ unsigned swz_off(int row, int q) { return (unsigned)row * 64u + (unsigned)((q ^ ((row >> 2) & 3)) * 16); }
 
-template <int TN>
+// Staging is LDS-direct (global_load_lds_dwordx4: a wave-instruction fills 64 consecutive 16-byte LDS pieces, no staging
+// registers) and double-buffered: the loads of step i+1 -- the next filter row's weights, and at the first row of a channel
+// chunk the NEXT chunk's input pixels -- are issued right after the single barrier of step i and land while its MFMAs run.
+// Because the LDS side of such a load is fixed (piece i of the buffer <- lane i), the XOR swizzle is applied on the GLOBAL
+// side: the lane that fills position (row, pos) fetches channel piece pos ^ ((row >> 2) & 3) of that row; padding positions
+// fetch a 16-byte zero constant.
+template <int TN, int WV>
 __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned short *__restrict__ x,
                                                                const unsigned short *__restrict__ w,
                                                                unsigned short *__restrict__ y, int N, int H, int W, int CIN,
-                                                               int COUT, int n_rows /* local rows of the padded layout */)
+                                                               int COUT, int n_rows /* local rows of the padded layout */,
+                                                               int xl_bytes /* one input buffer, a multiple of 1024 */)
 {
-    constexpr int CT = TN / 32; // output-channel tiles per wave
-    __shared__ __attribute__((aligned(16))) unsigned char xl[XL_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char wl[3 * TN * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int CT = TN / 32;          // output-channel tiles per wave
+    constexpr int NT = 64 * WV, TM = 64 * WV;
+    constexpr int WL_BYTES = 3 * TN * 64; // one weight buffer: 3 taps x TN rows x 64 bytes
+    constexpr int W_INSTR = (WL_BYTES / 16 + NT - 1) / NT;           // wave-loads per thread per weight chunk
+    constexpr int X_INSTR = (MAX_XL_BYTES / 16 + NT - 1) / NT;       // ... per input chunk (upper bound)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *xl0 = lds, *wl0 = lds + 2 * xl_bytes;            // xl[2], then wl[2]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, khalf = lane >> 5;
     const long P = (long)N * H * W;
     const long p0 = (long)blockIdx.x * TM;
@@ -61,24 +71,51 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
     // virtual (padded) row of the tile's first pixel, minus one: local row 0
     const int n_first = (int)(p0 / HW), h_first = (int)((p0 - (long)n_first * HW) / W);
     const int v_first = n_first * (H + 1) + h_first; // = v(n_first, h_first) - 1
-    // ---- staging descriptors of this thread's input pieces (the same for every channel chunk)
-    int src_off[MAX_PIECES];      // element offset of the piece's first channel in x (without the chunk offset), or -1: zeros
-    unsigned dst_off[MAX_PIECES]; // byte offset in xl, or 0xffffffff: nothing to write
-    const int n_slots = n_rows * W2;
+    // ---- staging descriptors of this thread's input pieces (the same for every channel chunk): element offset in x of the
+    // 8 channels this lane fetches (without the chunk offset), or -1: zeros
+    int src_off[X_INSTR];
+    const int n_pieces = n_rows * W2 * 4;
 #pragma unroll
-    for (int j = 0; j < MAX_PIECES; j++) {
-        const int idx = tid + j * 64 * WV;
-        const int slot = idx >> 2, q = idx & 3;
+    for (int j = 0; j < X_INSTR; j++) {
+        const int idx = tid + j * NT;
+        const int slot = idx >> 2, pos = idx & 3;
         src_off[j] = -1;
-        dst_off[j] = 0xffffffffu;
-        if (slot < n_slots) {
+        if (idx < n_pieces) {
             const int lr = slot / W2, ws = slot - lr * W2;
             const int v = v_first + lr;
             const int n = v / (H + 1), hv = v - n * (H + 1);
-            dst_off[j] = swz_off(slot, q);
+            const int q = pos ^ ((slot >> 2) & 3);
             if (hv >= 1 && n < N && ws >= 1 && ws <= W) src_off[j] = (((n * H + hv - 1) * W + ws - 1) * CIN) + q * 8;
         }
     }
+    // weight pieces: position i of a buffer = row i/4 (= tap s * TN + co), pos i%4 <- channel piece pos ^ ((row >> 2) & 3)
+    int wsrc[W_INSTR];
+#pragma unroll
+    for (int j = 0; j < W_INSTR; j++) {
+        const int idx = tid + j * NT, row = idx >> 2, pos = idx & 3;
+        const int sidx = row / TN, co = row - sidx * TN;
+        wsrc[j] = ((co0 + co) * 9 + sidx) * CIN + (pos ^ ((row >> 2) & 3)) * 8; // + r*3*CIN + cc per step
+    }
+    auto stage_x = [&](int cc, int buf) {
+#pragma unroll
+        for (int j = 0; j < X_INSTR; j++) {
+            if ((j * NT + wv * 64) * 16 < xl_bytes && (j * NT + wv * 64) < n_pieces) { // wave-uniform: this wave-load lies inside the chunk
+                const unsigned short *src = src_off[j] >= 0 ? x + (long)src_off[j] + cc : (const unsigned short *)&wide_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(xl0 + buf * xl_bytes + (j * NT + wv * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_w = [&](int cc, int r, int buf) {
+#pragma unroll
+        for (int j = 0; j < W_INSTR; j++) {
+            if ((j * NT + wv * 64) * 16 < WL_BYTES) { // wave-uniform
+                const unsigned short *src = w + (long)wsrc[j] + r * 3 * CIN + cc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(wl0 + buf * WL_BYTES + (j * NT + wv * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
     // ---- this lane's two output pixels (one per 32-pixel tile of the wave) and their LDS slots
     unsigned b_addr[9][2];
     long pix[2];
@@ -104,40 +141,39 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
 #pragma unroll
         for (int pt = 0; pt < 2; pt++) acc[ct][pt] = f32x16{};
 
-    for (int cc = 0; cc < CIN; cc += KC) {
-        __syncthreads(); // the previous chunk's reads of xl are done
-#pragma unroll
-        for (int j = 0; j < MAX_PIECES; j++) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (src_off[j] >= 0) v = *(const uint4 *)(x + (long)src_off[j] + cc);
-            if (dst_off[j] != 0xffffffffu) *(uint4 *)(xl + dst_off[j]) = v;
+    const int n_steps = (CIN / KC) * 3; // step = (channel chunk, filter row)
+    stage_x(0, 0);
+    stage_w(0, 0, 0);
+    for (int step = 0, cc = 0, r = 0; step < n_steps; step++) {
+        __syncthreads(); // (waits for this thread's loads, then the barrier) step's data is complete; the other buffers are free
+        const int xb = (cc / KC) & 1, wb = step & 1;
+        {   // the next step's loads, in flight during this step's MFMAs
+            const int nr = r == 2 ? 0 : r + 1, ncc = r == 2 ? cc + KC : cc;
+            if (step + 1 < n_steps) stage_w(ncc, nr, wb ^ 1);
+            if (r == 0 && cc + KC < CIN) stage_x(cc + KC, xb ^ 1);
         }
-        for (int r = 0; r < 3; r++) {
-            __syncthreads(); // the previous filter row's reads of wl are done (and, for r = 0, xl is complete after the next barrier)
+        const unsigned char *xl = xl0 + xb * xl_bytes, *wl = wl0 + wb * WL_BYTES;
 #pragma unroll
-            for (int j = 0; j < 3 * TN * 4 / (64 * WV); j++) { // 3 taps x TN rows x 4 pieces
-                const int idx = tid + j * 64 * WV;
-                const int q = idx & 3, row = idx >> 2; // row = s * TN + co
-                const int s = row / TN, co = row - s * TN;
-                const uint4 v = *(const uint4 *)(w + ((long)(co0 + co) * 9 + r * 3 + s) * CIN + cc + q * 8);
-                *(uint4 *)(wl + swz_off(row, q)) = v;
-            }
-            __syncthreads();
+        for (int sidx = 0; sidx < 3; sidx++)
 #pragma unroll
-            for (int s = 0; s < 3; s++)
+            for (int k16 = 0; k16 < 2; k16++) {
+                bf16x8 a[CT], b[2];
 #pragma unroll
-                for (int k16 = 0; k16 < 2; k16++) {
-                    bf16x8 a[CT], b[2];
+                for (int ct = 0; ct < CT; ct++) a[ct] = *(const bf16x8 *)(wl + ((a_addr[ct] + (unsigned)(sidx * TN * 64)) ^ (unsigned)(k16 * 32)));
 #pragma unroll
-                    for (int ct = 0; ct < CT; ct++) a[ct] = *(const bf16x8 *)(wl + ((a_addr[ct] + (unsigned)(s * TN * 64)) ^ (unsigned)(k16 * 32)));
-#pragma unroll
-                    for (int pt = 0; pt < 2; pt++) b[pt] = *(const bf16x8 *)(xl + (b_addr[r * 3 + s][pt] ^ (unsigned)(k16 * 32)));
-#pragma unroll
-                    for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                        for (int pt = 0; pt < 2; pt++)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+                for (int pt = 0; pt < 2; pt++) {
+                    const unsigned ba = r == 0 ? b_addr[sidx][pt] : r == 1 ? b_addr[3 + sidx][pt] : b_addr[6 + sidx][pt];
+                    b[pt] = *(const bf16x8 *)(xl + (ba ^ (unsigned)(k16 * 32)));
                 }
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                    for (int pt = 0; pt < 2; pt++)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+            }
+        if (++r == 3) {
+            r = 0;
+            cc += KC;
         }
     }
     // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 8-byte bf16 stores
@@ -158,12 +194,32 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
     }
 }
 
-// local rows of the padded layout a 512-pixel tile can touch: its own rows, one above and below, one zero row per image start
-int wide_rows(int H, int W)
+// local rows of the padded layout a TM-pixel tile can touch: its own rows, one above and below, one zero row per image start
+int wide_rows(int TM, int H, int W)
 {
     const int own = (TM + W - 2) / W + 1;                // rows a run of TM pixels can span
     const int images = (TM + H * W - 2) / (H * W) + 1;   // images it can span
     return own + 2 + images;
+}
+int wide_xl_bytes(int TM, int H, int W) { return ((wide_rows(TM, H, W) * (W + 2) * 64) + 1023) & ~1023; }
+
+template <int TN, int WV>
+int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int Cin, int Cout, hipStream_t st)
+{
+    constexpr int TM = 64 * WV;
+    const long P = N * H * W;
+    const int xlb = wide_xl_bytes(TM, H, W);
+    const size_t lds = 2 * (size_t)xlb + 2 * 3 * TN * 64;
+    static bool attr_set = false; // more than 64 KiB of dynamic LDS needs the attribute once per kernel
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)conv3x3_wide_kernel<TN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return -6;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wide_kernel<TN, WV>), dim3((unsigned)((P + TM - 1) / TM), (unsigned)(Cout / TN)), dim3(64 * WV), lds, st,
+                       (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout,
+                       wide_rows(TM, H, W), xlb);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
 } // namespace
@@ -172,7 +228,7 @@ extern "C" int salsa_nn_conv3x3_wide_supported(int64_t N, int H, int W, int Cin,
 {
     if (N <= 0 || H <= 0 || W <= 0 || Cin < KC || Cin % KC || Cout < 64 || Cout % 64) return 0;
     if (N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) >= INT32_MAX) return 0;          // 32-bit element offsets
-    return (int64_t)wide_rows(H, W) * (W + 2) * 64 <= XL_BYTES;
+    return wide_xl_bytes(256, H, W) <= MAX_XL_BYTES;
 }
 
 // x: [N][H][W][Cin] bf16, w: [Cout][3][3][Cin] bf16 (a channels-last torch.nn.Conv2d weight), y: [N][H][W][Cout] bf16
@@ -181,13 +237,14 @@ extern "C" int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int6
 {
     if (!x || !w || !y || x == y || !salsa_nn_conv3x3_wide_supported(N, H, W, Cin, Cout)) return -1;
     const long P = (long)N * H * W;
-    const int rows = wide_rows(H, W);
-    const unsigned nb = (unsigned)((P + TM - 1) / TM);
-    if (Cout % 128 == 0)
-        hipLaunchKernelGGL(conv3x3_wide_kernel<128>, dim3(nb, (unsigned)(Cout / 128)), dim3(64 * WV), 0, (hipStream_t)hip_stream,
-                           (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout, rows);
-    else
-        hipLaunchKernelGGL(conv3x3_wide_kernel<64>, dim3(nb, (unsigned)(Cout / 64)), dim3(64 * WV), 0, (hipStream_t)hip_stream,
-                           (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout, rows);
-    return hipGetLastError() == hipSuccess ? 0 : -6;
+    hipStream_t st = (hipStream_t)hip_stream;
+    // tile choice: 512 pixels x 128 channels per workgroup when that still gives every CU a workgroup; smaller tiles for the
+    // small maps (40 x 12 x 32 clips = 15 360 pixels: 30 tiles of 512)
+    const bool big_ok = wide_xl_bytes(512, H, W) <= MAX_XL_BYTES;
+    const long wg_big = (P + 511) / 512 * (Cout / 128);
+    if (Cout % 128 == 0 && big_ok && wg_big >= 192) return wide_launch<128, 8>(x, w, y, N, H, W, Cin, Cout, st);
+    const long wg_mid = (P + 255) / 256 * (Cout / 128);
+    if (Cout % 128 == 0 && wg_mid >= 192) return wide_launch<128, 4>(x, w, y, N, H, W, Cin, Cout, st);
+    if (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) return wide_launch<64, 8>(x, w, y, N, H, W, Cin, Cout, st);
+    return wide_launch<64, 4>(x, w, y, N, H, W, Cin, Cout, st);
 }
