@@ -210,11 +210,16 @@ class _Conv3x3Wide(torch.autograd.Function):
         x, wb = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        N, Cin, H, W = x.shape
+        # the data gradient is a Cout -> Cin convolution: the kernel takes it when Cin is a multiple of 64 (always in the CRNN)
+        own_dgrad = ctx.needs_input_grad[0] and bool(_lib.load().salsa_nn_conv3x3_wide_supported(N, H, W, wb.shape[0], Cin))
+        if own_dgrad:
             gx = _conv_wide(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
-        if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1].float()
+        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1], False]
+        if need[0] or need[1]:
+            r = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
+            gx = r[0] if need[0] else gx
+            gw = r[1].float() if need[1] else None
         return gx, gw
 
 

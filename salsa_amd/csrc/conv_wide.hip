@@ -144,36 +144,71 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
     const int n_steps = (CIN / KC) * 3; // step = (channel chunk, filter row)
     stage_x(0, 0);
     stage_w(0, 0, 0);
-    for (int step = 0, cc = 0, r = 0; step < n_steps; step++) {
-        __syncthreads(); // (waits for this thread's loads, then the barrier) step's data is complete; the other buffers are free
-        const int xb = (cc / KC) & 1, wb = step & 1;
-        {   // the next step's loads, in flight during this step's MFMAs
-            const int nr = r == 2 ? 0 : r + 1, ncc = r == 2 ? cc + KC : cc;
-            if (step + 1 < n_steps) stage_w(ncc, nr, wb ^ 1);
-            if (r == 0 && cc + KC < CIN) stage_x(cc + KC, xb ^ 1);
+    // One step = 3 taps x 2 k-steps = 6 sub-steps of (CT filter fragments + 2 pixel fragments -> 2*CT MFMAs).  The LDS reads are
+    // software-pipelined by hand (the compiler otherwise waits for ALL outstanding reads before every MFMA group): sub-step i+1's
+    // fragments are requested before sub-step i's MFMAs issue, and the counted wait lets exactly those younger reads stay in
+    // flight.  Reads are asm with the tap's constant part as the instruction's immediate offset.
+    const unsigned lds_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)lds;
+    auto compute = [&](const int r, const unsigned xl_off, const unsigned wl_off) {
+        unsigned a_lo[CT], a_hi[CT], b_ad[3][2];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            a_lo[ct] = lds_base + wl_off + a_addr[ct];
+            a_hi[ct] = a_lo[ct] ^ 32u; // (the buffer offsets are multiples of 1024: the XOR commutes with the addition)
         }
-        const unsigned char *xl = xl0 + xb * xl_bytes, *wl = wl0 + wb * WL_BYTES;
 #pragma unroll
         for (int sidx = 0; sidx < 3; sidx++)
 #pragma unroll
-            for (int k16 = 0; k16 < 2; k16++) {
-                bf16x8 a[CT], b[2];
+            for (int pt = 0; pt < 2; pt++) b_ad[sidx][pt] = lds_base + xl_off + (r == 0 ? b_addr[sidx][pt] : r == 1 ? b_addr[3 + sidx][pt] : b_addr[6 + sidx][pt]);
+        bf16x8 fa[2][CT], fb[2][2];
+        auto issue = [&](const int i) {
+            const int sidx = i >> 1, k16 = i & 1;
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++) a[ct] = *(const bf16x8 *)(wl + ((a_addr[ct] + (unsigned)(sidx * TN * 64)) ^ (unsigned)(k16 * 32)));
+            for (int ct = 0; ct < CT; ct++) {
+                if (sidx == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][ct]) : "v"(k16 ? a_hi[ct] : a_lo[ct]), "n"(0));
+                if (sidx == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][ct]) : "v"(k16 ? a_hi[ct] : a_lo[ct]), "n"(TN * 64));
+                if (sidx == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i & 1][ct]) : "v"(k16 ? a_hi[ct] : a_lo[ct]), "n"(2 * TN * 64));
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) {
+                const unsigned ad = k16 ? b_ad[sidx][pt] ^ 32u : b_ad[sidx][pt];
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[i & 1][pt]) : "v"(ad));
+            }
+        };
+        issue(0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i + 1 < 6) {
+                issue(i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // sub-step i's fragments have landed when only the CT + 2 younger reads are outstanding
+                if (CT == 4) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++) {
-                    const unsigned ba = r == 0 ? b_addr[sidx][pt] : r == 1 ? b_addr[3 + sidx][pt] : b_addr[6 + sidx][pt];
-                    b[pt] = *(const bf16x8 *)(xl + (ba ^ (unsigned)(k16 * 32)));
+                    asm volatile("" : "+v"(fa[i & 1][ct]), "+v"(fb[i & 1][pt])); // (the MFMAs stay behind the wait)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][ct], fb[i & 1][pt], acc[ct][pt], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int step = 0, cc = 0; step < n_steps; cc += KC) {
+        const int xb = (cc / KC) & 1;
 #pragma unroll
-                for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-                    for (int pt = 0; pt < 2; pt++)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+        for (int r = 0; r < 3; r++, step++) {
+            __syncthreads(); // (waits for this thread's loads, then the barrier) the step's data is complete; the other buffers are free
+            const int wb = step & 1;
+            {   // the next step's loads, in flight during this step's MFMAs
+                const int nr = r == 2 ? 0 : r + 1, ncc = r == 2 ? cc + KC : cc;
+                if (step + 1 < n_steps) stage_w(ncc, nr, wb ^ 1);
+                if (r == 0 && cc + KC < CIN) stage_x(cc + KC, xb ^ 1);
             }
-        if (++r == 3) {
-            r = 0;
-            cc += KC;
+            compute(r, (unsigned)(xb * xl_bytes), (unsigned)(2 * xl_bytes + wb * WL_BYTES));
         }
     }
     // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 8-byte bf16 stores
