@@ -24,6 +24,9 @@ def conv_backend_note() -> str:
     """Which convolution layers run on the hand-written MFMA kernels (for the bench lines)."""
     if not USE_HIP_CONV:
         return 'all on MIOpen through torch (SALSA_HIP_CONV=0)'
+    if USE_HIP_CONV_WIDE:
+        return ('every 3x3 layer forward + data gradient on hand-written MFMA kernels (stem 7->64 and 64->64: conv_mfma.hip; 128/256/512 '
+                'channels: conv_wide.hip); weight gradients: 64->64 hand-written, the rest MIOpen; 1x1 shortcuts MIOpen')
     return 'stem 7->64 and the five 64->64 3x3 layers on the hand-written MFMA kernels (conv_mfma.hip), the 128/256/512-channel layers on MIOpen through torch'
 
 
