@@ -57,6 +57,10 @@ int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int64_t x_chan
  * salsa_nn_conv3x3_wide_supported: 1 if the shape is taken (the padded input chunk of a 512-pixel tile must fit its LDS buffer). */
 int salsa_nn_conv3x3_wide_supported(int64_t N, int H, int W, int Cin, int Cout);
 int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
+/* inference: y = [relu](conv(x, w) + shift[co] [+ residual]) with the BatchNorm that follows folded in (w pre-scaled per output
+ * channel, shift float32 [Cout], residual bf16 like y or NULL), applied to the float32 sums before the single rounding */
+int salsa_nn_conv3x3_wide_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y, int relu,
+                                   int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

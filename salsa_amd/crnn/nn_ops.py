@@ -342,6 +342,23 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_c64_bias_act%s failed (%d)' % ('_pool' if fuse_pool else '', rc))
         return y if fuse_pool or not pool else avg_pool2x2(y)
+    if (isinstance(conv, Conv3x3) and conv._wide_eligible(x) and not bn.training and not torch.is_grad_enabled()
+            and bn.track_running_stats and bn.affine and not pool
+            and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == conv.out_channels
+                                      and residual.is_contiguous(memory_format=torch.channels_last)))):
+        # the wide layers at inference: the same folding on conv_wide.hip's epilogue
+        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
+        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        N, Cin, H, W = xb.shape
+        y = torch.empty((N, conv.out_channels, H, W), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_conv3x3_wide_bias_act(_ptr(xb), _ptr(wf), _ptr(shift), _ptr(residual), _ptr(y), int(relu), N, H, W,
+                                                            Cin, conv.out_channels, _stream(xb))
+        if rc:
+            raise RuntimeError('salsa_nn_conv3x3_wide_bias_act failed (%d)' % rc)
+        return y
     if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
             and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
         scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
                                                                const unsigned short *__restrict__ w,
                                                                unsigned short *__restrict__ y, int N, int H, int W, int CIN,
                                                                int COUT, int n_rows /* local rows of the padded layout */,
-                                                               int xl_bytes /* one input buffer, a multiple of 1024 */)
+                                                               int xl_bytes /* one input buffer, a multiple of 1024 */,
+                                                               const float *__restrict__ shift /* [COUT] or NULL */,
+                                                               const unsigned short *__restrict__ residual /* like y, or NULL */,
+                                                               int relu)
 {
     constexpr int CT = TN / 32;          // output-channel tiles per wave
     constexpr int NT = 64 * WV, TM = 64 * WV;
@@ -211,18 +214,34 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
             compute(r, (unsigned)(xb * xl_bytes), (unsigned)(2 * xl_bytes + wb * WL_BYTES));
         }
     }
-    // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 8-byte bf16 stores
+    // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 8-byte bf16 stores.
+    // Inference epilogue (shift != NULL): folded BatchNorm shift (+ residual) (+ ReLU) on the float32 sums, one rounding.
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
         if (pix[pt] < P) {
-            unsigned short *o = y + pix[pt] * COUT + co0 + 4 * khalf;
+            const long off = pix[pt] * COUT + co0 + 4 * khalf;
+            unsigned short *o = y + off;
 #pragma unroll
             for (int ct = 0; ct < CT; ct++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
+                    float v4[4] = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+                    if (shift) {
+                        const float4 sh = *(const float4 *)(shift + co0 + 4 * khalf + ct * 32 + 8 * g);
+                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                        if (residual) {
+                            const uint2 rv = *(const uint2 *)(residual + off + ct * 32 + 8 * g);
+                            v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                            v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                        }
+                    }
                     uint2 v;
-                    v.x = pack_bf16(acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1]);
-                    v.y = pack_bf16(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
+                    v.x = pack_bf16(v4[0], v4[1]);
+                    v.y = pack_bf16(v4[2], v4[3]);
                     *(uint2 *)(o + ct * 32 + 8 * g) = v;
                 }
         }
@@ -239,7 +258,8 @@ int wide_rows(int TM, int H, int W)
 int wide_xl_bytes(int TM, int H, int W) { return ((wide_rows(TM, H, W) * (W + 2) * 64) + 1023) & ~1023; }
 
 template <int TN, int WV>
-int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int Cin, int Cout, hipStream_t st)
+int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int Cin, int Cout, hipStream_t st, const float *shift,
+                const void *residual, int relu)
 {
     constexpr int TM = 64 * WV;
     const long P = N * H * W;
@@ -253,7 +273,7 @@ int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int
     }
     hipLaunchKernelGGL((conv3x3_wide_kernel<TN, WV>), dim3((unsigned)((P + TM - 1) / TM), (unsigned)(Cout / TN)), dim3(64 * WV), lds, st,
                        (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout,
-                       wide_rows(TM, H, W), xlb);
+                       wide_rows(TM, H, W), xlb, shift, (const unsigned short *)residual, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -266,9 +286,8 @@ extern "C" int salsa_nn_conv3x3_wide_supported(int64_t N, int H, int W, int Cin,
     return wide_xl_bytes(256, H, W) <= MAX_XL_BYTES;
 }
 
-// x: [N][H][W][Cin] bf16, w: [Cout][3][3][Cin] bf16 (a channels-last torch.nn.Conv2d weight), y: [N][H][W][Cout] bf16
-extern "C" int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout,
-                                     void *hip_stream)
+static int wide_dispatch(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream,
+                         const float *shift, const void *residual, int relu)
 {
     if (!x || !w || !y || x == y || !salsa_nn_conv3x3_wide_supported(N, H, W, Cin, Cout)) return -1;
     const long P = (long)N * H * W;
@@ -277,9 +296,24 @@ extern "C" int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int6
     // small maps (40 x 12 x 32 clips = 15 360 pixels: 30 tiles of 512)
     const bool big_ok = wide_xl_bytes(512, H, W) <= MAX_XL_BYTES;
     const long wg_big = (P + 511) / 512 * (Cout / 128);
-    if (Cout % 128 == 0 && big_ok && wg_big >= 192) return wide_launch<128, 8>(x, w, y, N, H, W, Cin, Cout, st);
+    if (Cout % 128 == 0 && big_ok && wg_big >= 192) return wide_launch<128, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
     const long wg_mid = (P + 255) / 256 * (Cout / 128);
-    if (Cout % 128 == 0 && wg_mid >= 192) return wide_launch<128, 4>(x, w, y, N, H, W, Cin, Cout, st);
-    if (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) return wide_launch<64, 8>(x, w, y, N, H, W, Cin, Cout, st);
-    return wide_launch<64, 4>(x, w, y, N, H, W, Cin, Cout, st);
+    if (Cout % 128 == 0 && wg_mid >= 192) return wide_launch<128, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
+    if (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) return wide_launch<64, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
+    return wide_launch<64, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
+}
+
+// x: [N][H][W][Cin] bf16, w: [Cout][3][3][Cin] bf16 (a channels-last torch.nn.Conv2d weight), y: [N][H][W][Cout] bf16
+extern "C" int salsa_nn_conv3x3_wide(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout,
+                                     void *hip_stream)
+{
+    return wide_dispatch(x, w, y, N, H, W, Cin, Cout, hip_stream, nullptr, nullptr, 0);
+}
+
+// inference: y = [relu](conv(x, w) + shift[co] [+ residual]) -- w pre-scaled by the folded BatchNorm factor gamma / sigma
+extern "C" int salsa_nn_conv3x3_wide_bias_act(const void *x, const void *w, const float *shift, const void *residual, void *y,
+                                              int relu, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream)
+{
+    if (!shift) return -1;
+    return wide_dispatch(x, w, y, N, H, W, Cin, Cout, hip_stream, shift, residual, relu);
 }

@@ -472,3 +472,31 @@ def test_wide_conv_kernel_matches_torch_forward_and_gradients():
         assert float((wa.grad - wr.grad).abs().max()) < 3e-2 * float(wr.grad.abs().max()), (cin, cout, h, w)
     assert not nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(2, 8, 8, 48, 64)          # Cin not a multiple of 32
     assert not nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(2, 40, 200, 128, 128)     # 200-pixel rows: chunk exceeds its LDS buffer
+
+
+def test_eval_wide_conv_with_folded_batchnorm_epilogue():
+    """conv_bn_act in eval mode for the wide layers (conv_wide.hip's epilogue: folded BatchNorm shift, residual add, ReLU before
+    the single rounding) against the unfused float32 computation on the same bf16-valued inputs."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(8)
+    for cin, cout, h, w, n in ((64, 128, 20, 50, 3), (128, 128, 20, 50, 2), (256, 512, 40, 12, 3), (512, 512, 10, 12, 5)):
+        conv = nn_ops.Conv3x3(cin, cout, 3, padding=1, bias=False).to(dev).eval()
+        bn = nn_ops.BatchNormAct2d(cout).to(dev).eval()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(cout, device=dev, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(cout, device=dev, generator=g))
+            bn.running_mean.copy_(torch.randn(cout, device=dev, generator=g) * 0.3)
+            bn.running_var.copy_(torch.rand(cout, device=dev, generator=g) + 0.5)
+        for use_res, relu in ((False, True), (True, True), (True, False)):
+            x = torch.randn((n, cin, h, w), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+            r = torch.randn((n, cout, h, w), device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last) if use_res else None
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                y = nn_ops.conv_bn_act(conv, bn, x, residual=r, relu=relu)
+            assert y.dtype == torch.bfloat16 and y.shape == (n, cout, h, w)
+            ref = F.batch_norm(F.conv2d(x.float(), conv.weight.float(), padding=1), bn.running_mean, bn.running_var, bn.weight,
+                               bn.bias, False, 0.0, bn.eps)
+            ref = ref + r.float() if use_res else ref
+            ref = F.relu(ref) if relu else ref
+            torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)        # bf16 filter (scaled) and output rounding
