@@ -1,6 +1,7 @@
 /*
- * salsa_nn.h -- C ABI of the memory-bound layers of the SELD CRNN consumer that are hand-written for MI355X (the
- * convolutions stay with MIOpen).  Tensors are channels-last ([N][H][W][C], C fastest), device pointers, caller-owned;
+ * salsa_nn.h -- C ABI of the layers of the SELD CRNN consumer that are hand-written for MI355X: average pools, fused
+ * BatchNorm, and the 3x3 convolutions' forward / data gradient on the matrix cores (weight gradients: 64 -> 64 only; the rest
+ * and the 1x1 shortcuts stay with MIOpen).  Tensors are channels-last ([N][H][W][C], C fastest), device pointers, caller-owned;
  * dtype: 0 = float32, 1 = bfloat16; asynchronous on the given HIP stream.
  *
  *   salsa_nn_avgpool2x2_{fwd,bwd}: F.avg_pool2d(x, 2) of the upstream model (models/model_utils.py:187-228 ConvBlock,

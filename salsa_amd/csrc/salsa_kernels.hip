@@ -7,13 +7,15 @@
 //                       output and spills the DOA band of the spectra (float32-rounded, like the reference's
 //                       complex64 STFT) to the workspace as Xs[b][t][channel pair][bin] (float4).
 //   K2 tracker_kernel   one lane per (clip, bin): 3-frame RMS of channel 0 and the sequential noise-floor tracker
-//                       in float64 -> valid[b][64-frame chunk][bin] (64-bit indicator history per bin).
+//                       in float64 -> valid32[b][32-bin group][t] (per-frame indicator mask of the group's bins).
 //   K3 cov_eig_kernel   per tile of 8 frames x 256 bins the gated TF bins are compacted into an LDS work list (an item = two
 //                       neighbouring frames of one bin, at least one gated in: their 7-frame windows share 6 frames);
 //                       one lane per item: Hermitian covariances accumulated in registers, eigen-gate + principal
 //                       eigenvector (salsa_math.h), FOA / MIC normalisation, writes channels 4-6 (zeros where gated).
 // Further entry points: salsa_eigvec_batch (K2 + K3 on caller-supplied spectra), salsa_logspec_batch (K1 only), the scaler /
-// normalise kernels, the contrib-surface variants (SALSA_FLAG_FLEX), salsa_to_freq_major, salsa_augment_batch.
+// normalise kernels, the contrib-surface variants (SALSA_FLAG_FLEX; salsa_extract_multichannel for 5 - 8 microphones: K1 over
+// 3 / 4 channel pairs + cov_eig_n_kernel), salsa_to_freq_major, salsa_augment_batch, the pipelined schedules
+// (salsa_plan_set_pipeline).
 // SALSA-Lite / IPD is K1 alone (log-spectrogram + inter-channel phase fused into the unpack).
 //
 // Arithmetic types follow the reference (see DESIGN.md "Precision"): STFT evaluated in float64 and rounded to
