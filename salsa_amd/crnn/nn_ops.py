@@ -197,10 +197,42 @@ def _conv_wide(x, w):
     return y
 
 
+_WIDE_TABLES = {}
+USE_HIP_CONV_WIDE_WRW = os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
+
+
+def _wide_tables(N, H, W, device):
+    """(vpos, inv) int32 device tensors of a map shape for salsa_nn_conv3x3_wide_wrw, built once on the host and cached."""
+    key = (int(N), int(H), int(W), str(device))
+    if key not in _WIDE_TABLES:
+        import numpy as np
+        L = _lib.load()
+        vpos = np.empty(N * H * W, np.int32)
+        inv = np.empty(int(L.salsa_nn_conv3x3_wide_table_len(N, H, W)), np.int32)
+        rc = L.salsa_nn_conv3x3_wide_tables(N, H, W, vpos.ctypes.data_as(C.c_void_p), inv.ctypes.data_as(C.c_void_p))
+        if rc:
+            raise RuntimeError('salsa_nn_conv3x3_wide_tables failed (%d)' % rc)
+        _WIDE_TABLES[key] = (torch.from_numpy(vpos).to(device), torch.from_numpy(inv).to(device))
+    return _WIDE_TABLES[key]
+
+
+def _conv_wide_wrw(x, gy):
+    """salsa_nn_conv3x3_wide_wrw: x (N,Cin,H,W), gy (N,Cout,H,W) bf16 channels-last -> dW (Cout,Cin,3,3) float32."""
+    N, Cin, H, W = x.shape
+    Cout = gy.shape[1]
+    vpos, inv = _wide_tables(N, H, W, x.device)
+    gw = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_nn_conv3x3_wide_wrw(_ptr(x), _ptr(gy), _ptr(gw), _ptr(vpos), _ptr(inv), N, H, W, Cin, Cout, _stream(x))
+    if rc:
+        raise RuntimeError('salsa_nn_conv3x3_wide_wrw failed (%d)' % rc)
+    return gw
+
+
 class _Conv3x3Wide(torch.autograd.Function):
-    """The wide 3x3 convolutions (Cin, Cout in 64..512, not 64 -> 64) on the flattened-pixel implicit-GEMM MFMA kernel
-    (salsa_amd/csrc/conv_wide.hip): forward and data gradient (the same kernel with the flipped / transposed filter); the
-    weight gradient stays with MIOpen."""
+    """The wide 3x3 convolutions (Cin, Cout in 64..512, not 64 -> 64) on the flattened-pixel implicit-GEMM MFMA kernels
+    (salsa_amd/csrc/conv_wide.hip): forward, data gradient (the same kernel with the flipped / transposed filter) and weight
+    gradient (transposing LDS reads, float32 result); shapes a kernel does not take fall back to torch / MIOpen."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -218,11 +250,15 @@ class _Conv3x3Wide(torch.autograd.Function):
         own_dgrad = ctx.needs_input_grad[0] and bool(_lib.load().salsa_nn_conv3x3_wide_supported(N, H, W, wb.shape[0], Cin))
         if own_dgrad:
             gx = _conv_wide(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
-        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1], False]
+        own_wrw = (ctx.needs_input_grad[1] and USE_HIP_CONV_WIDE_WRW
+                   and bool(_lib.load().salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, wb.shape[0])))
+        if own_wrw:
+            gw = _conv_wide_wrw(x, gy)
+        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wrw, False]
         if need[0] or need[1]:
             r = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             gx = r[0] if need[0] else gx
-            gw = r[1].float() if need[1] else None
+            gw = r[1].float() if need[1] else gw
         return gx, gw
 
 

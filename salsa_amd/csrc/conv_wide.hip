@@ -317,3 +317,164 @@ extern "C" int salsa_nn_conv3x3_wide_bias_act(const void *x, const void *w, cons
     if (!shift) return -1;
     return wide_dispatch(x, w, y, N, H, W, Cin, Cout, hip_stream, shift, residual, relu);
 }
+
+// ------------------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + off(tap)][ci] for the wide layers: a GEMM whose reduction runs over
+// PIXELS, so both MFMA operands need 8 consecutive pixels of ONE channel per lane while memory is pixel-major -- gfx950's
+// transposing LDS read (ds_read_b64_tr_b16, mapping in conv_mfma.hip "weight gradient") builds them from pixel-major tiles.
+// Same flattened pixel axis and padded slot layout as the forward kernel, with two differences: the tiles are NOT swizzled (a
+// transposing read of 32 lanes covers four whole consecutive 64-byte slots = every bank once), and a workgroup walks MANY pixel
+// tiles, so the (n, h, w) arithmetic of the forward kernel's set-up is replaced by two small index tables built once per map
+// shape by the caller: vpos[p] = padded slot of pixel p, inv[slot] = pixel of a padded slot or -1.
+// Workgroup = 4 waves = 128 output channels (32 per wave) x one 32-channel input chunk x 9 taps (9 accumulator tiles per wave)
+// over a share of the pixel tiles; float32 partial sums are added to dW at the end.
+namespace {
+
+constexpr int WG_TM = 128;                          // pixels per tile
+constexpr int WG_XL = 28672;                        // input tile: up to 448 slots of 64 bytes
+constexpr int WG_DL = WG_TM * 4 * 64;               // dy tile: 4 channel groups x 128 pixels x 64 bytes
+
+struct wtr_frag {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
+{
+    union { unsigned long long q[2]; bf16x8 v; } u;
+    u.q[0] = f.lo;
+    u.q[1] = f.hi;
+    return u.v;
+}
+#define WTR_ISSUE(f, a0, a1) asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"((f).lo), "=&v"((f).hi) : "v"(a0), "v"(a1))
+#define WTR_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((f).lo), "+v"((f).hi))
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
+                                                                  const unsigned short *__restrict__ dy, float *__restrict__ dw,
+                                                                  const int *__restrict__ vpos, const int *__restrict__ inv, long P,
+                                                                  int W, int CIN, int COUT, int n_shares)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char xl[WG_XL];
+    __shared__ __attribute__((aligned(16))) unsigned char dl[WG_DL];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
+    const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 32;
+    const int W2 = W + 2;
+    const unsigned lane_chunk = (unsigned)(cb * 32 + (i16 & 3) * 8);   // this lane's 4 channels inside a 64-byte slot
+    const unsigned xbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)xl;
+    const unsigned dbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)dl;
+    // dy fragment of k-step ks: pixel rows 16 ks + 8 kh + (i16 >> 2) (+4), this wave's channel group
+    const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
+    int tapoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) tapoff[t] = ((t / 3 - 1) * W2 + (t % 3 - 1) + W2 + 1) * 64; // bytes, >= 0 (slot 0 = tap (-1,-1) of pixel 0)
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = f32x16{};
+    const long n_tiles = (P + WG_TM - 1) / WG_TM;
+    for (long tile = blockIdx.x; tile < n_tiles; tile += n_shares) {
+        const long p0 = tile * WG_TM;
+        const long p_last = p0 + WG_TM - 1 < P ? p0 + WG_TM - 1 : P - 1;
+        const int vbase = vpos[p0] - (W2 + 1);
+        const int n_slots = vpos[p_last] - vbase + W2 + 2;
+        __syncthreads(); // the previous tile's reads are done
+        // ---- stage x: local slot sl <- pixel inv[vbase + sl] (or zeros), channels ci0 .. ci0+31
+        for (int base = 0; base < n_slots * 4; base += 256) {
+            const int idx = base + tid, sl = idx >> 2, piece = idx & 3;
+            const int pixel = sl < n_slots ? inv[vbase + sl] : -1;
+            const unsigned short *src = pixel >= 0 ? x + ((long)pixel * CIN + ci0 + piece * 8) : (const unsigned short *)&wide_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(xl + (base + wv * 64) * 16), 16, 0, 0);
+        }
+        // ---- stage dy: position ((cg * 128 + j) * 4 + piece) <- dy[p0 + j][co0 + 32 cg + 8 piece ..]
+#pragma unroll
+        for (int k = 0; k < WG_DL / 16 / 256; k++) {
+            const int idx = k * 256 + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
+            const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : (const unsigned short *)&wide_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dl + (k * 256 + wv * 64) * 16), 16, 0, 0);
+        }
+        // this lane's x slots of every k-step: pixel rows 16 ks + 8 kh + (i16 >> 2) and + 4
+        unsigned xa[WG_TM / 16][2];
+#pragma unroll
+        for (int ks = 0; ks < WG_TM / 16; ks++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                long p = p0 + 16 * ks + 8 * kh + (i16 >> 2) + 4 * hf;
+                if (p >= P) p = P - 1; // (dy is zero there: no contribution)
+                xa[ks][hf] = xbase + (unsigned)((vpos[p] - vbase - (W2 + 1)) * 64) + lane_chunk;
+            }
+        __syncthreads(); // (drains the loads) both tiles are complete
+        // ---- 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs), the next fragment requested before the current MFMA
+        wtr_frag fr[2];
+        bf16x8 a;
+        WTR_ISSUE(fr[0], d_lane, d_lane + 4 * 64);
+        WTR_WAIT(fr[0]);
+#pragma unroll
+        for (int q = 0; q < (WG_TM / 16) * 10; q++) {
+            const int ks = q / 10, j = q % 10;
+            if (q + 1 < (WG_TM / 16) * 10) {
+                const int ks1 = (q + 1) / 10, j1 = (q + 1) % 10;
+                if (j1 == 0) WTR_ISSUE(fr[(q + 1) & 1], d_lane + (unsigned)(ks1 * 16 * 64), d_lane + (unsigned)(ks1 * 16 * 64 + 4 * 64));
+                else WTR_ISSUE(fr[(q + 1) & 1], xa[ks1][0] + (unsigned)tapoff[j1 - 1], xa[ks1][1] + (unsigned)tapoff[j1 - 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) a = wtr_value(fr[q & 1]);
+            else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q & 1]), acc[j - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < (WG_TM / 16) * 10) WTR_WAIT(fr[(q + 1) & 1]);
+            (void)ks;
+        }
+    }
+    // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the wave's 32
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int co = co0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * kh, ci = ci0 + (lane & 31);
+            atomicAdd(dw + ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
+        }
+}
+
+} // namespace
+
+extern "C" int salsa_nn_conv3x3_wide_wrw_supported(int64_t N, int H, int W, int Cin, int Cout)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout < 128 || Cout % 128) return 0;
+    if (N * H * W * (int64_t)(Cin > Cout ? Cin : Cout) >= INT32_MAX || Cout / 128 > 65535 || Cin / 32 > 65535) return 0;
+    return (int64_t)wide_rows(WG_TM, H, W) * (W + 2) * 64 <= WG_XL;
+}
+
+// Index tables of a map shape (host arrays the caller uploads once): vpos[N*H*W], inv[salsa_nn_conv3x3_wide_table_len]
+extern "C" int64_t salsa_nn_conv3x3_wide_table_len(int64_t N, int H, int W) { return (N * (H + 1) + 3) * (int64_t)(W + 2) + 16; }
+extern "C" int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos, int *inv)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || !vpos || !inv || N * (H + 2) * (int64_t)(W + 2) >= INT32_MAX) return -1;
+    const int64_t len = salsa_nn_conv3x3_wide_table_len(N, H, W);
+    for (int64_t i = 0; i < len; i++) inv[i] = -1;
+    int64_t p = 0;
+    for (int64_t n = 0; n < N; n++)
+        for (int h = 0; h < H; h++)
+            for (int w = 0; w < W; w++, p++) {
+                const int64_t v = (n * (H + 1) + h + 1) * (W + 2) + w + 1;
+                vpos[p] = (int)v;
+                inv[v] = (int)p;
+            }
+    return 0;
+}
+
+// dw: float32 [Cout][3][3][Cin], ADDED to (zero it first); x [N][H][W][Cin], dy [N][H][W][Cout] bf16; d_vpos / d_inv: the device
+// copies of salsa_nn_conv3x3_wide_tables(N, H, W)
+extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, int64_t N,
+                                         int H, int W, int Cin, int Cout, void *hip_stream)
+{
+    if (!x || !dy || !dw || !d_vpos || !d_inv || !salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, Cout)) return -1;
+    const long P = (long)N * H * W;
+    const long tiles = (P + WG_TM - 1) / WG_TM;
+    const long pairs = (long)(Cout / 128) * (Cin / 32);
+    long shares = (512 + pairs - 1) / pairs; // ~2 workgroups per CU in total
+    if (shares > tiles) shares = tiles;
+    if (shares < 1) shares = 1;
+    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256), 0,
+                       (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, W, Cin, Cout,
+                       (int)shares);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}

@@ -40,5 +40,14 @@ for cin, cout, H, W in shapes:
     t_hip = timed(lambda: nn_ops._conv_wide(x, w))
     t_mio = timed(lambda: F.conv2d(x, w, padding=1))
     fl = 2.0 * N * H * W * cin * cout * 9
+    if nn_ops._lib.load().salsa_nn_conv3x3_wide_wrw_supported(N, H, W, cin, cout):
+        gy = torch.randn((N, cout, H, W), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gw = nn_ops._conv_wide_wrw(x, gy)
+        ref_w = torch.ops.aten.convolution_backward(gy[:2].float(), x[:2].float(), w.float(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        gw2 = nn_ops._conv_wide_wrw(x[:2].contiguous(memory_format=torch.channels_last), gy[:2].contiguous(memory_format=torch.channels_last))
+        werr = float((gw2 - ref_w).abs().max() / ref_w.abs().max())
+        t_w = timed(lambda: nn_ops._conv_wide_wrw(x, gy))
+        t_wm = timed(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        print('      wrw: rel err %.2e   hip %.3f ms (%4.0f TF/s)   MIOpen %.3f ms (%4.0f TF/s)   ratio %.2f' % (werr, t_w, fl / t_w / 1e9, t_wm, fl / t_wm / 1e9, t_wm / t_w))
     print('%4d -> %4d @ %3dx%3d: rel err %.2e   hip %.3f ms (%4.0f TF/s)   MIOpen %.3f ms (%4.0f TF/s)   ratio %.2f'
           % (cin, cout, H, W, err, t_hip, fl / t_hip / 1e9, t_mio, fl / t_mio / 1e9, t_mio / t_hip), flush=True)
