@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2, conv_bn_act
+from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2, conv1x1, conv_bn_act
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -62,7 +62,7 @@ class ResBlock(nn.Module):
         y = avg_pool2x2(x) if self.stride == 2 else x
         out = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p)   # dropout(relu(bn1(conv1(y)))), training only
         if self.short_conv is not None:
-            x = self.short_bn(self.short_conv(y))
+            x = self.short_bn(conv1x1(self.short_conv, y))
         return conv_bn_act(self.conv2, self.bn2, out, residual=x)          # relu(bn2(conv2(out)) + shortcut)
 
 

@@ -354,6 +354,21 @@ class Conv3x3(torch.nn.Conv2d):
         return super().forward(x)
 
 
+USE_GEMM_1X1 = os.environ.get('SALSA_GEMM_1X1', '1') != '0'
+
+
+def conv1x1(conv, x):
+    """A 1x1 / stride 1 convolution (the residual shortcuts, models/model_utils.py:340-349) of a channels-last CUDA tensor as
+    what it is -- a plain GEMM over the flattened pixels, [N*H*W, Cin] x [Cin, Cout] -- through torch's linear (hipBLASLt;
+    bf16 under autocast, gradients by the same library) instead of MIOpen's convolution path and its cast passes."""
+    if (USE_GEMM_1X1 and x.is_cuda and x.dim() == 4 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and conv.bias is None and x.is_contiguous(memory_format=torch.channels_last)):
+        N, Cin, H, W = x.shape
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, Cin), conv.weight.reshape(conv.out_channels, Cin))
+        return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)            # (N, Cout, H, W), channels-last strides
+    return conv(x)
+
+
 def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
     """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
