@@ -347,22 +347,25 @@ __device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
 #define WTR_ISSUE(f, a0, a1) asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"((f).lo), "=&v"((f).hi) : "v"(a0), "v"(a1))
 #define WTR_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((f).lo), "+v"((f).hi))
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
+// Every tile costs two dependent global round trips before its first MFMA (index tables, then the tiles themselves) against
+// ~1 us of multiply, so the loop is pipelined two deep: while tile i is multiplied, tile i+1's LDS-direct loads are in flight
+// into the other half of LDS and tile i+2's table look-ups into registers.  (First version, everything serial with two
+// workgroups per CU to cover for each other: 324 - 488 TFLOP/s, on a par with MIOpen.)
+constexpr int WG_XP = WG_XL / 16 / 256;             // input wave-loads per thread per tile (upper bound): 7
+constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                   const int *__restrict__ vpos, const int *__restrict__ inv, long P,
                                                                   int W, int CIN, int COUT, int n_shares)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char xl[WG_XL];
-    __shared__ __attribute__((aligned(16))) unsigned char dl[WG_DL];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
     const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 32;
     const int W2 = W + 2;
     const unsigned lane_chunk = (unsigned)(cb * 32 + (i16 & 3) * 8);   // this lane's 4 channels inside a 64-byte slot
-    const unsigned xbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)xl;
-    const unsigned dbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)dl;
-    // dy fragment of k-step ks: pixel rows 16 ks + 8 kh + (i16 >> 2) (+4), this wave's channel group
-    const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
+    const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)wlds;
     int tapoff[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) tapoff[t] = ((t / 3 - 1) * W2 + (t % 3 - 1) + W2 + 1) * 64; // bytes, >= 0 (slot 0 = tap (-1,-1) of pixel 0)
@@ -370,21 +373,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_wrw_kernel(const unsigned
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x16{};
     const long n_tiles = (P + WG_TM - 1) / WG_TM;
-    for (long tile = blockIdx.x; tile < n_tiles; tile += n_shares) {
+
+    // table values of one tile, fetched a tile ahead: vb = first padded slot, ns = slots, pixel of each staged slot, slot of
+    // each of this lane's 16 fragment pixel rows
+    struct Look {
+        int vb, ns;
+        int pix[WG_XP];
+        int vp[WG_KS][2];
+    };
+    auto lookup = [&](long tile, Look &L) {
         const long p0 = tile * WG_TM;
         const long p_last = p0 + WG_TM - 1 < P ? p0 + WG_TM - 1 : P - 1;
-        const int vbase = vpos[p0] - (W2 + 1);
-        const int n_slots = vpos[p_last] - vbase + W2 + 2;
-        __syncthreads(); // the previous tile's reads are done
-        // ---- stage x: local slot sl <- pixel inv[vbase + sl] (or zeros), channels ci0 .. ci0+31
-        for (int base = 0; base < n_slots * 4; base += 256) {
-            const int idx = base + tid, sl = idx >> 2, piece = idx & 3;
-            const int pixel = sl < n_slots ? inv[vbase + sl] : -1;
-            const unsigned short *src = pixel >= 0 ? x + ((long)pixel * CIN + ci0 + piece * 8) : (const unsigned short *)&wide_zero16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(xl + (base + wv * 64) * 16), 16, 0, 0);
+        L.vb = vpos[p0] - (W2 + 1);
+        L.ns = vpos[p_last] - L.vb + W2 + 2;
+#pragma unroll
+        for (int j = 0; j < WG_XP; j++) {
+            const int sl = (j * 256 + tid) >> 2;
+            L.pix[j] = inv[L.vb + (sl < L.ns ? sl : 0)]; // (clamped address; the value is ignored beyond ns)
+            if (sl >= L.ns) L.pix[j] = -1;
         }
-        // ---- stage dy: position ((cg * 128 + j) * 4 + piece) <- dy[p0 + j][co0 + 32 cg + 8 piece ..]
+#pragma unroll
+        for (int ks = 0; ks < WG_KS; ks++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                long p = p0 + 16 * ks + 8 * kh + (i16 >> 2) + 4 * hf;
+                if (p >= P) p = P - 1; // (dy is zero there: no contribution)
+                L.vp[ks][hf] = vpos[p];
+            }
+    };
+    auto stage = [&](long tile, const Look &L, int buf) {
+        const long p0 = tile * WG_TM;
+        unsigned char *xl = wlds + buf * WG_XL, *dl = wlds + 2 * WG_XL + buf * WG_DL;
+#pragma unroll
+        for (int j = 0; j < WG_XP; j++) {
+            if (j * 256 < L.ns * 4) { // block-uniform: this 4-KiB piece range holds slots of the tile
+                const int piece = tid & 3;
+                const unsigned short *src = L.pix[j] >= 0 ? x + ((long)L.pix[j] * CIN + ci0 + piece * 8) : (const unsigned short *)&wide_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(xl + (j * 256 + wv * 64) * 16), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < WG_DL / 16 / 256; k++) {
             const int idx = k * 256 + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
@@ -392,26 +420,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_wrw_kernel(const unsigned
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dl + (k * 256 + wv * 64) * 16), 16, 0, 0);
         }
-        // this lane's x slots of every k-step: pixel rows 16 ks + 8 kh + (i16 >> 2) and + 4
-        unsigned xa[WG_TM / 16][2];
+    };
+    auto multiply = [&](const Look &L, int buf) {
+        const unsigned xbase = lbase + (unsigned)(buf * WG_XL), dbase = lbase + (unsigned)(2 * WG_XL + buf * WG_DL);
+        // dy fragment of k-step ks: pixel rows 16 ks + 8 kh + (i16 >> 2) (+4), this wave's channel group
+        const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
+        unsigned xa[WG_KS][2];
 #pragma unroll
-        for (int ks = 0; ks < WG_TM / 16; ks++)
+        for (int ks = 0; ks < WG_KS; ks++)
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                long p = p0 + 16 * ks + 8 * kh + (i16 >> 2) + 4 * hf;
-                if (p >= P) p = P - 1; // (dy is zero there: no contribution)
-                xa[ks][hf] = xbase + (unsigned)((vpos[p] - vbase - (W2 + 1)) * 64) + lane_chunk;
-            }
-        __syncthreads(); // (drains the loads) both tiles are complete
-        // ---- 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs), the next fragment requested before the current MFMA
+            for (int hf = 0; hf < 2; hf++) xa[ks][hf] = xbase + (unsigned)((L.vp[ks][hf] - L.vb - (W2 + 1)) * 64) + lane_chunk;
+        // 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs), the next fragment requested before the current MFMA
         wtr_frag fr[2];
         bf16x8 a;
         WTR_ISSUE(fr[0], d_lane, d_lane + 4 * 64);
         WTR_WAIT(fr[0]);
 #pragma unroll
-        for (int q = 0; q < (WG_TM / 16) * 10; q++) {
-            const int ks = q / 10, j = q % 10;
-            if (q + 1 < (WG_TM / 16) * 10) {
+        for (int q = 0; q < WG_KS * 10; q++) {
+            const int j = q % 10;
+            if (q + 1 < WG_KS * 10) {
                 const int ks1 = (q + 1) / 10, j1 = (q + 1) % 10;
                 if (j1 == 0) WTR_ISSUE(fr[(q + 1) & 1], d_lane + (unsigned)(ks1 * 16 * 64), d_lane + (unsigned)(ks1 * 16 * 64 + 4 * 64));
                 else WTR_ISSUE(fr[(q + 1) & 1], xa[ks1][0] + (unsigned)tapoff[j1 - 1], xa[ks1][1] + (unsigned)tapoff[j1 - 1]);
@@ -420,9 +447,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_wrw_kernel(const unsigned
             if (j == 0) a = wtr_value(fr[q & 1]);
             else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q & 1]), acc[j - 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < (WG_TM / 16) * 10) WTR_WAIT(fr[(q + 1) & 1]);
-            (void)ks;
+            if (q + 1 < WG_KS * 10) WTR_WAIT(fr[(q + 1) & 1]);
         }
+    };
+    // software pipeline over this workgroup's tiles, tile(i) = blockIdx.x + i * n_shares: at iteration i the data of tile i is
+    // in buffer i & 1 with its tables in Lcur, tile i+1's tables are in Lnext
+    Look Lcur, Lnext;
+    long tile = blockIdx.x;
+    if (tile < n_tiles) {
+        lookup(tile, Lcur);
+        stage(tile, Lcur, 0);
+        if (tile + n_shares < n_tiles) lookup(tile + n_shares, Lnext);
+    }
+    for (int buf = 0; tile < n_tiles; tile += n_shares, buf ^= 1) {
+        __syncthreads(); // (drains this thread's loads) tile's data is complete and the other buffer is free
+        if (tile + n_shares < n_tiles) stage(tile + n_shares, Lnext, buf ^ 1);
+        Look Lnn = Lnext;
+        if (tile + 2 * n_shares < n_tiles) lookup(tile + 2 * n_shares, Lnn);
+        multiply(Lcur, buf);
+        Lcur = Lnext;
+        Lnext = Lnn;
     }
     // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the wave's 32
 #pragma unroll
@@ -470,11 +514,16 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
     const long P = (long)N * H * W;
     const long tiles = (P + WG_TM - 1) / WG_TM;
     const long pairs = (long)(Cout / 128) * (Cin / 32);
-    long shares = (512 + pairs - 1) / pairs; // ~2 workgroups per CU in total
+    long shares = (256 + pairs - 1) / pairs; // one workgroup per CU (its 120 KiB of LDS fill it)
     if (shares > tiles) shares = tiles;
     if (shares < 1) shares = 1;
-    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256), 0,
-                       (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, W, Cin, Cout,
+    static bool attr_set = false; // 120 KiB of dynamic LDS
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -6;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256),
+                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, W, Cin, Cout,
                        (int)shares);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
