@@ -353,6 +353,9 @@ __device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
 // workgroups per CU to cover for each other: 324 - 488 TFLOP/s, on a par with MIOpen.)
 constexpr int WG_XP = WG_XL / 16 / 256;             // input wave-loads per thread per tile (upper bound): 7
 constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
+#ifndef WG_DEPTH
+#define WG_DEPTH 4                                   // fragments in flight ahead of the MFMA (<= 4: the counted waits below)
+#endif
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
@@ -430,24 +433,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         for (int ks = 0; ks < WG_KS; ks++)
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) xa[ks][hf] = xbase + (unsigned)((L.vp[ks][hf] - L.vb - (W2 + 1)) * 64) + lane_chunk;
-        // 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs), the next fragment requested before the current MFMA
-        wtr_frag fr[2];
+        // 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs).  With one wave per SIMD nothing else covers the LDS round trip
+        // (~150 cycles against a 32-cycle MFMA), so the fragment stream runs WG_DEPTH fragments ahead of the MFMA that consumes it
+        // (one fragment ahead: 13.5 k cycles per tile for 2.3 k cycles of matrix work); the counted wait lets exactly the younger
+        // fragments' reads (two per fragment) stay outstanding.
+        constexpr int NQ = WG_KS * 10, RING = WG_DEPTH + 1;
+        wtr_frag fr[RING];
         bf16x8 a;
-        WTR_ISSUE(fr[0], d_lane, d_lane + 4 * 64);
-        WTR_WAIT(fr[0]);
+        auto issue = [&](const int q1) {
+            const int ks1 = q1 / 10, j1 = q1 % 10;
+            if (j1 == 0) WTR_ISSUE(fr[q1 % RING], d_lane + (unsigned)(ks1 * 16 * 64), d_lane + (unsigned)(ks1 * 16 * 64 + 4 * 64));
+            else WTR_ISSUE(fr[q1 % RING], xa[ks1][0] + (unsigned)tapoff[j1 - 1], xa[ks1][1] + (unsigned)tapoff[j1 - 1]);
+        };
 #pragma unroll
-        for (int q = 0; q < WG_KS * 10; q++) {
-            const int j = q % 10;
-            if (q + 1 < WG_KS * 10) {
-                const int ks1 = (q + 1) / 10, j1 = (q + 1) % 10;
-                if (j1 == 0) WTR_ISSUE(fr[(q + 1) & 1], d_lane + (unsigned)(ks1 * 16 * 64), d_lane + (unsigned)(ks1 * 16 * 64 + 4 * 64));
-                else WTR_ISSUE(fr[(q + 1) & 1], xa[ks1][0] + (unsigned)tapoff[j1 - 1], xa[ks1][1] + (unsigned)tapoff[j1 - 1]);
+        for (int q = 0; q < WG_DEPTH; q++) issue(q);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (q + WG_DEPTH < NQ) issue(q + WG_DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // fragment q has landed when at most the 2 * min(WG_DEPTH, NQ - 1 - q) younger reads are outstanding
+                constexpr int full = 2 * WG_DEPTH;
+                const int younger = 2 * (NQ - 1 - q < WG_DEPTH ? NQ - 1 - q : WG_DEPTH);
+                if (younger == full) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi) : "n"(full));
+                else if (younger == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
+                else if (younger == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
+                else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
             }
+            const int j = q % 10;
+            if (j == 0) a = wtr_value(fr[q % RING]);
+            else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q % RING]), acc[j - 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) a = wtr_value(fr[q & 1]);
-            else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q & 1]), acc[j - 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < WG_KS * 10) WTR_WAIT(fr[(q + 1) & 1]);
         }
     };
     // software pipeline over this workgroup's tiles, tile(i) = blockIdx.x + i * n_shares: at iteration i the data of tile i is
