@@ -360,7 +360,7 @@ constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
 __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                   const int *__restrict__ vpos, const int *__restrict__ inv, long P,
-                                                                  int W, int CIN, int COUT, int n_shares)
+                                                                  int H, int W, int CIN, int COUT, int n_shares)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,8 +387,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
     auto lookup = [&](long tile, Look &L) {
         const long p0 = tile * WG_TM;
         const long p_last = p0 + WG_TM - 1 < P ? p0 + WG_TM - 1 : P - 1;
-        L.vb = vpos[p0] - (W2 + 1);
-        L.ns = vpos[p_last] - L.vb + W2 + 2;
+        // the tile's first and last padded slot by arithmetic (wave-uniform), NOT from the table: a table value here would make
+        // the inv[] loads below wait for it -- and, loads retiring in order, for the LDS-direct loads issued just before
+        auto vslot = [&](long p) {
+            const int HW = H * W, n = (int)(p / HW), rem = (int)(p - (long)n * HW), h = rem / W;
+            return (n * (H + 1) + h + 1) * W2 + (rem - h * W) + 1;
+        };
+        L.vb = __builtin_amdgcn_readfirstlane(vslot(p0)) - (W2 + 1);
+        L.ns = __builtin_amdgcn_readfirstlane(vslot(p_last)) - L.vb + W2 + 2;
 #pragma unroll
         for (int j = 0; j < WG_XP; j++) {
             const int sl = (j * 256 + tid) >> 2;
@@ -477,10 +483,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
     }
     for (int buf = 0; tile < n_tiles; tile += n_shares, buf ^= 1) {
         __syncthreads(); // (drains this thread's loads) tile's data is complete and the other buffer is free
+#ifndef WRW_NO_STAGE // (probe builds: WRW_NO_STAGE / WRW_NO_MULT / WRW_NO_ATOMIC drop one phase each)
         if (tile + n_shares < n_tiles) stage(tile + n_shares, Lnext, buf ^ 1);
+#endif
         Look Lnn = Lnext;
         if (tile + 2 * n_shares < n_tiles) lookup(tile + 2 * n_shares, Lnn);
+#ifndef WRW_NO_MULT
         multiply(Lcur, buf);
+#endif
         Lcur = Lnext;
         Lnext = Lnn;
     }
@@ -490,6 +500,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int co = co0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * kh, ci = ci0 + (lane & 31);
+#ifdef WRW_NO_ATOMIC
+            if (acc[t][reg] == 123.456f)
+#endif
             atomicAdd(dw + ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
         }
 }
@@ -539,7 +552,7 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
         attr_set = true;
     }
     hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256),
-                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, W, Cin, Cout,
+                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, H, W, Cin, Cout,
                        (int)shares);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
