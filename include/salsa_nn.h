@@ -65,12 +65,14 @@ int salsa_nn_conv3x3_wide_bias_act(const void *x, const void *w, const float *sh
 /* weight gradient of the wide layers (Cin a multiple of 32, Cout a multiple of 128): dw float32 [Cout][3][3][Cin] += sum_pixels
  * dy[p][co] * x[p+tap][ci] (zero it first), transposing LDS reads on the same flattened pixel axis.  The kernel walks many pixel
  * tiles per workgroup and takes its (n, h, w) arithmetic from two index tables of the map shape, built on the HOST by
- * salsa_nn_conv3x3_wide_tables (vpos: N*H*W ints, inv: salsa_nn_conv3x3_wide_table_len ints) and uploaded once by the caller. */
+ * salsa_nn_conv3x3_wide_tables (vpos: N*H*W ints, inv: salsa_nn_conv3x3_wide_table_len ints, tile_bounds: 2 *
+ * salsa_nn_conv3x3_wide_tile_count ints) and uploaded once by the caller. */
 int salsa_nn_conv3x3_wide_wrw_supported(int64_t N, int H, int W, int Cin, int Cout);
 int64_t salsa_nn_conv3x3_wide_table_len(int64_t N, int H, int W);
-int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos_host, int *inv_host);
-int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, int64_t N, int H, int W,
-                              int Cin, int Cout, void *hip_stream);
+int64_t salsa_nn_conv3x3_wide_tile_count(int64_t N, int H, int W);
+int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos_host, int *inv_host, int *tile_bounds_host);
+int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, const int *d_tile_bounds,
+                              int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

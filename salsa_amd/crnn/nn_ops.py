@@ -202,17 +202,19 @@ USE_HIP_CONV_WIDE_WRW = os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
 
 
 def _wide_tables(N, H, W, device):
-    """(vpos, inv) int32 device tensors of a map shape for salsa_nn_conv3x3_wide_wrw, built once on the host and cached."""
+    """(vpos, inv, tile bounds) int32 device tensors of a map shape for salsa_nn_conv3x3_wide_wrw, built once on the host and cached."""
     key = (int(N), int(H), int(W), str(device))
     if key not in _WIDE_TABLES:
         import numpy as np
         L = _lib.load()
         vpos = np.empty(N * H * W, np.int32)
         inv = np.empty(int(L.salsa_nn_conv3x3_wide_table_len(N, H, W)), np.int32)
-        rc = L.salsa_nn_conv3x3_wide_tables(N, H, W, vpos.ctypes.data_as(C.c_void_p), inv.ctypes.data_as(C.c_void_p))
+        tb = np.empty(2 * int(L.salsa_nn_conv3x3_wide_tile_count(N, H, W)), np.int32)
+        rc = L.salsa_nn_conv3x3_wide_tables(N, H, W, vpos.ctypes.data_as(C.c_void_p), inv.ctypes.data_as(C.c_void_p),
+                                            tb.ctypes.data_as(C.c_void_p))
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_wide_tables failed (%d)' % rc)
-        _WIDE_TABLES[key] = (torch.from_numpy(vpos).to(device), torch.from_numpy(inv).to(device))
+        _WIDE_TABLES[key] = tuple(torch.from_numpy(a).to(device) for a in (vpos, inv, tb))
     return _WIDE_TABLES[key]
 
 
@@ -220,10 +222,11 @@ def _conv_wide_wrw(x, gy):
     """salsa_nn_conv3x3_wide_wrw: x (N,Cin,H,W), gy (N,Cout,H,W) bf16 channels-last -> dW (Cout,Cin,3,3) float32."""
     N, Cin, H, W = x.shape
     Cout = gy.shape[1]
-    vpos, inv = _wide_tables(N, H, W, x.device)
+    vpos, inv, tb = _wide_tables(N, H, W, x.device)
     gw = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = _lib.load().salsa_nn_conv3x3_wide_wrw(_ptr(x), _ptr(gy), _ptr(gw), _ptr(vpos), _ptr(inv), N, H, W, Cin, Cout, _stream(x))
+        rc = _lib.load().salsa_nn_conv3x3_wide_wrw(_ptr(x), _ptr(gy), _ptr(gw), _ptr(vpos), _ptr(inv), _ptr(tb), N, H, W, Cin, Cout,
+                                                   _stream(x))
     if rc:
         raise RuntimeError('salsa_nn_conv3x3_wide_wrw failed (%d)' % rc)
     return gw

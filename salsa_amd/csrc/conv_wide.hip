@@ -359,8 +359,9 @@ constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
-                                                                  const int *__restrict__ vpos, const int *__restrict__ inv, long P,
-                                                                  int H, int W, int CIN, int COUT, int n_shares)
+                                                                  const int *__restrict__ vpos, const int *__restrict__ inv,
+                                                                  const int2 *__restrict__ tbounds, long P, int W, int CIN, int COUT,
+                                                                  int n_shares)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,14 +388,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
     auto lookup = [&](long tile, Look &L) {
         const long p0 = tile * WG_TM;
         const long p_last = p0 + WG_TM - 1 < P ? p0 + WG_TM - 1 : P - 1;
-        // the tile's first and last padded slot by arithmetic (wave-uniform), NOT from the table: a table value here would make
-        // the inv[] loads below wait for it -- and, loads retiring in order, for the LDS-direct loads issued just before
-        auto vslot = [&](long p) {
-            const int HW = H * W, n = (int)(p / HW), rem = (int)(p - (long)n * HW), h = rem / W;
-            return (n * (H + 1) + h + 1) * W2 + (rem - h * W) + 1;
-        };
-        L.vb = __builtin_amdgcn_readfirstlane(vslot(p0)) - (W2 + 1);
-        L.ns = __builtin_amdgcn_readfirstlane(vslot(p_last)) - L.vb + W2 + 2;
+        // the tile's first padded slot and slot count from the per-tile table through a SCALAR load (uniform address): a vector
+        // load here would make the inv[] loads below wait for it and -- vector loads retiring in order -- for the LDS-direct loads
+        // issued just before (measured: the whole kernel 15 % slower; computing the two values with integer divisions: 30 %)
+        const int2 tb = tbounds[__builtin_amdgcn_readfirstlane((int)tile)];
+        L.vb = tb.x;
+        L.ns = tb.y;
+        (void)p_last;
 #pragma unroll
         for (int j = 0; j < WG_XP; j++) {
             const int sl = (j * 256 + tid) >> 2;
@@ -516,11 +516,13 @@ extern "C" int salsa_nn_conv3x3_wide_wrw_supported(int64_t N, int H, int W, int 
     return (int64_t)wide_rows(WG_TM, H, W) * (W + 2) * 64 <= WG_XL;
 }
 
-// Index tables of a map shape (host arrays the caller uploads once): vpos[N*H*W], inv[salsa_nn_conv3x3_wide_table_len]
+// Index tables of a map shape (host arrays the caller uploads once): vpos[N*H*W], inv[salsa_nn_conv3x3_wide_table_len],
+// tile_bounds[2 * salsa_nn_conv3x3_wide_tile_count]
 extern "C" int64_t salsa_nn_conv3x3_wide_table_len(int64_t N, int H, int W) { return (N * (H + 1) + 3) * (int64_t)(W + 2) + 16; }
-extern "C" int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos, int *inv)
+extern "C" int64_t salsa_nn_conv3x3_wide_tile_count(int64_t N, int H, int W) { return (N * H * W + WG_TM - 1) / WG_TM; }
+extern "C" int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos, int *inv, int *tile_bounds)
 {
-    if (N <= 0 || H <= 0 || W <= 0 || !vpos || !inv || N * (H + 2) * (int64_t)(W + 2) >= INT32_MAX) return -1;
+    if (N <= 0 || H <= 0 || W <= 0 || !vpos || !inv || !tile_bounds || N * (H + 2) * (int64_t)(W + 2) >= INT32_MAX) return -1;
     const int64_t len = salsa_nn_conv3x3_wide_table_len(N, H, W);
     for (int64_t i = 0; i < len; i++) inv[i] = -1;
     int64_t p = 0;
@@ -531,15 +533,21 @@ extern "C" int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos, 
                 vpos[p] = (int)v;
                 inv[v] = (int)p;
             }
+    const int64_t P = N * H * W, W2 = W + 2;
+    for (int64_t t = 0; t < (P + WG_TM - 1) / WG_TM; t++) { // per 128-pixel tile: first padded slot its taps touch, number of slots
+        const int64_t pf = t * WG_TM, pl = pf + WG_TM - 1 < P ? pf + WG_TM - 1 : P - 1;
+        tile_bounds[2 * t] = (int)(vpos[pf] - (W2 + 1));
+        tile_bounds[2 * t + 1] = (int)(vpos[pl] - tile_bounds[2 * t] + W2 + 2);
+    }
     return 0;
 }
 
-// dw: float32 [Cout][3][3][Cin], ADDED to (zero it first); x [N][H][W][Cin], dy [N][H][W][Cout] bf16; d_vpos / d_inv: the device
-// copies of salsa_nn_conv3x3_wide_tables(N, H, W)
-extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, int64_t N,
-                                         int H, int W, int Cin, int Cout, void *hip_stream)
+// dw: float32 [Cout][3][3][Cin], ADDED to (zero it first); x [N][H][W][Cin], dy [N][H][W][Cout] bf16; d_vpos / d_inv / d_tbounds:
+// the device copies of salsa_nn_conv3x3_wide_tables(N, H, W)
+extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv,
+                                         const int *d_tbounds, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream)
 {
-    if (!x || !dy || !dw || !d_vpos || !d_inv || !salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, Cout)) return -1;
+    if (!x || !dy || !dw || !d_vpos || !d_inv || !d_tbounds || !salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, Cout)) return -1;
     const long P = (long)N * H * W;
     const long tiles = (P + WG_TM - 1) / WG_TM;
     const long pairs = (long)(Cout / 128) * (Cin / 32);
@@ -552,7 +560,7 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
         attr_set = true;
     }
     hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256),
-                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, P, H, W, Cin, Cout,
+                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
                        (int)shares);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
