@@ -354,7 +354,8 @@ __device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
 constexpr int WG_XP = WG_XL / 16 / 256;             // input wave-loads per thread per tile (upper bound): 7
 constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
 #ifndef WG_DEPTH
-#define WG_DEPTH 4                                   // fragments in flight ahead of the MFMA (<= 4: the counted waits below)
+#define WG_DEPTH 2                                   // fragments in flight ahead of the MFMA (<= 4: the counted waits below); measured
+                                                     // 1: 433, 2: 583, 3: 558, 4: 543 TFLOP/s on 256 -> 256
 #endif
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         // 8 k-steps x (1 dy fragment + 9 x fragments -> 9 MFMAs).  With one wave per SIMD nothing else covers the LDS round trip
         // (~150 cycles against a 32-cycle MFMA), so the fragment stream runs WG_DEPTH fragments ahead of the MFMA that consumes it
         // (one fragment ahead: 13.5 k cycles per tile for 2.3 k cycles of matrix work); the counted wait lets exactly the younger
-        // fragments' reads (two per fragment) stay outstanding.
+        // fragments' reads (two per fragment) stay outstanding.  Phase-drop probe builds of the finished kernel (128 -> 128,
+        // 0.142 ms): without the final atomics 0.125, without the multiply 0.080, without the staging 0.114, staging alone 0.058.
         constexpr int NQ = WG_KS * 10, RING = WG_DEPTH + 1;
         wtr_frag fr[RING];
         bf16x8 a;
