@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--fmax-doa', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-crnn', action='store_true', help='skip the CRNN-training half of the metric')
+    ap.add_argument('--no-infer', action='store_true', help='skip the batched-inference leg (BASELINE config 5)')
     ap.add_argument('--crnn-steps', type=int, default=20)
     ap.add_argument('--crnn-warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=1, help='extra leg: K steps round-robin over this many HIP streams / plans (reported as pipelined, never `value`)')
@@ -85,7 +86,7 @@ def main():
     ap.add_argument('--groups', type=int, default=0, help='clip-group pipelining depth (0 = library default)')
     args = ap.parse_args()
 
-    from bench_crnn import self_spawn, train_bench
+    from bench_crnn import infer_bench, self_spawn, train_bench
     self_spawn(args.gpus, __file__)           # `--gpus N` without a launcher: become N ranks (does not return then)
 
     fmt = args.format or ('foa' if args.feature == 'salsa' else 'mic')
@@ -279,6 +280,18 @@ def main():
             if world > 1:
                 raise
             crnn = {'error': '%s: %s' % (type(e).__name__, e)}
+    # ---- BASELINE config 5 (reported, not part of the metric): 32 x 60-s clips per GPU per step through SALSA + CRNN forward
+    infer = None
+    if not args.no_infer and not args.no_crnn and args.feature == 'salsa':
+        try:
+            from types import SimpleNamespace
+            from salsa_amd.crnn.train import Trainer
+            torch.cuda.empty_cache()
+            infer = infer_bench(SimpleNamespace(clips=32, sub_batch=32, steps=5, warmup=3), rank, world, dev, Trainer(dev, ddp=False))
+        except Exception as e:
+            if world > 1:
+                raise
+            infer = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
 
@@ -314,6 +327,7 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu,
         'crnn': crnn,
+        'inference': infer,
     }
     if pcie:
         line['pcie_inclusive'] = pcie

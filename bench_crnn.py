@@ -85,18 +85,17 @@ def infer_bench(args, rank, world, dev, tr):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        dist.destroy_process_group()
     if rank != 0:
-        return
+        return None
     lat.sort()
-    print(json.dumps({
+    return ({
         'metric': 'SALSA+CRNN inference clips/s', 'value': round(world * args.clips * args.steps / elapsed, 2),
         'unit': '60-s clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 (features)', 'data': 'synthetic',
         'p50_latency_ms_per_%dclip_subbatch' % sub: round(1e3 * lat[len(lat) // 2], 2),
         'config': {'workload': 'batched inference: %d x 60-s 4-ch clips per GPU per step, SALSA-FOA + CRNN forward, '
-                               'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}}))
+                               'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}})
 
 
 def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False):
@@ -196,7 +195,12 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     if args.infer:
         from salsa_amd.crnn.train import Trainer
-        return infer_bench(args, rank, world, dev, Trainer(dev))
+        line = infer_bench(args, rank, world, dev, Trainer(dev, ddp=False))
+        if world > 1:
+            dist.destroy_process_group()
+        if line is not None:
+            print(json.dumps(line))
+        return
     line = train_bench(rank, world, dev, args.batch, args.steps, args.warmup, args.on_the_fly, args.augment, args.fp32_grads)
     if world > 1:
         dist.destroy_process_group()
