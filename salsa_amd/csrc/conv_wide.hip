@@ -265,12 +265,10 @@ int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int
     const long P = N * H * W;
     const int xlb = wide_xl_bytes(TM, H, W);
     const size_t lds = 2 * (size_t)xlb + 2 * 3 * TN * 64;
-    static bool attr_set = false; // more than 64 KiB of dynamic LDS needs the attribute once per kernel
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_wide_kernel<TN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return -6;
-        attr_set = true;
-    }
+    // more than 64 KiB of dynamic LDS needs the attribute; it is per device, so it is (cheaply) set on every launch rather than
+    // cached in a process-wide flag that a second GPU driven by the same process would never see
+    if (hipFuncSetAttribute((const void *)conv3x3_wide_kernel<TN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return -6;
     hipLaunchKernelGGL((conv3x3_wide_kernel<TN, WV>), dim3((unsigned)((P + TM - 1) / TM), (unsigned)(Cout / TN)), dim3(64 * WV), lds, st,
                        (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout,
                        wide_rows(TM, H, W), xlb, shift, (const unsigned short *)residual, relu);
@@ -556,11 +554,8 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
     long shares = (256 + pairs - 1) / pairs; // one workgroup per CU (its 120 KiB of LDS fill it)
     if (shares > tiles) shares = tiles;
     if (shares < 1) shares = 1;
-    static bool attr_set = false; // 120 KiB of dynamic LDS
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -6;
-        attr_set = true;
-    }
+    if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return -6; // 120 KiB of dynamic LDS (per device: set on every launch)
     hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256),
                        2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
                        (int)shares);
