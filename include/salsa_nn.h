@@ -92,6 +92,16 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
                     float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, float drop_p, uint32_t drop_seed,
                     void *hip_stream);
 
+/* BatchNorm (training statistics) + ReLU + the 2x2 average pool that follows them in the upstream stem (models/model_utils.py:
+ * 187-228), one pass over x: x [N][H][W][C] -> y [N][H/2][W/2][C] (normalise + ReLU each of the four pixels, average in float32,
+ * one rounding); the full-resolution activation is never written.  Backward from the POOLED gradient, ReLU mask recomputed from x. */
+int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                               float *save_mean, float *save_invstd, double *sums_ws, void *hip_stream);
+int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
+                         const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
+                         double *sums_ws, float *coef_ws, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,11 +111,61 @@ class _BnAct(torch.autograd.Function):
         return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None
 
 
+class _BnReluPool(torch.autograd.Function):
+    """y = avg_pool2x2(relu(batch_norm(x))) in training mode (salsa_nn_bn_train_fwd_pool / salsa_nn_bn_bwd_pool): the stem's
+    tail; the full-resolution activation is neither written in the forward nor its gradient in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        N, Cn, H, W = x.shape
+        y = torch.empty((N, Cn, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
+                                                        float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_train_fwd_pool failed (%d)' % rc)
+        ctx.save_for_backward(x, weight, bias, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, save = ctx.saved_tensors
+        N, Cn, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dwb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_bn_bwd_pool(_ptr(gy), _ptr(x), _ptr(dx), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
+                                                  _ptr(save[0]), _ptr(save[1]), _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef),
+                                                  _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_bwd_pool failed (%d)' % rc)
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None
+
+
+USE_HIP_BN_POOL = os.environ.get('SALSA_HIP_BN_POOL', '1') != '0'
+
+
 class BatchNormAct2d(torch.nn.BatchNorm2d):
     """nn.BatchNorm2d (same parameters, buffers and state_dict keys) whose forward can take the residual add and the ReLU
     that follow it in the upstream blocks, and in training the dropout behind that ReLU: ``bn(x, residual=None, relu=False,
     dropout_p=0.0)``.  Channels-last CUDA bf16 / float32 inputs run the fused HIP kernels; anything else runs torch's
-    batch_norm + add + relu + dropout."""
+    batch_norm + add + relu + dropout.  ``relu_pool(x)`` = avg_pool2x2(relu(bn(x))), one kernel pass in training."""
+
+    def relu_pool(self, x):
+        if (USE_HIP_BN and USE_HIP_BN_POOL and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
+                and self.track_running_stats and self.momentum is not None and x.shape[2] >= 2 and x.shape[3] >= 2
+                and x.is_contiguous(memory_format=torch.channels_last)
+                and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
+            self.num_batches_tracked.add_(1)
+            return _BnReluPool.apply(x, self.weight.float(), self.bias.float(), self.running_mean, self.running_var, self.momentum,
+                                     self.eps)
+        return avg_pool2x2(self.forward(x, relu=True))
 
     def forward(self, x, residual=None, relu=False, dropout_p=0.0):
         if not self.training:
@@ -420,5 +470,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
         shift = (bn.bias - bn.running_mean * scale).float().contiguous()
         y = _conv_stem(x, _stem_filter(conv.weight, scale), shift, relu)
         return avg_pool2x2(y) if pool else y
+    if pool and relu and residual is None and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d):
+        return bn.relu_pool(conv(x))
     y = bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)
     return avg_pool2x2(y) if pool else y

@@ -295,15 +295,65 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
     }
 }
 
+// The stem's BatchNorm + ReLU is followed by a 2x2 average pool (models/model_utils.py:187-228): fused, the full-resolution
+// activation (524 MB per step at 32 x 640 x 200 x 64) is neither written nor read back -- one thread = one POOLED pixel x L
+// channels: four input vectors, normalise + ReLU each, average in float32, one rounding.  x: [N][H][W][C], y: [N][H/2][W/2][C].
+template <typename V, int L>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const char *__restrict__ x, char *__restrict__ y, long n_vec, int H, int W,
+                                                            int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_vec) return;
+    const int cv = C / L, Ho = H / 2, Wo = W / 2;
+    const int c = (int)(i % cv);
+    long r = i / cv;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long n = r / Ho;
+    const char *p = x + ((((n * H + 2 * ho) * W + 2 * wo) * cv + c) * 16);
+    float v[4][L], o[L];
+    vec_io<V, L>::load(p, v[0]);
+    vec_io<V, L>::load(p + (long)cv * 16, v[1]);
+    vec_io<V, L>::load(p + (long)W * cv * 16, v[2]);
+    vec_io<V, L>::load(p + ((long)W * cv + cv) * 16, v[3]);
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const float mu = mean[c * L + k], is = invstd[c * L + k], ga = gamma[c * L + k], be = beta[c * L + k];
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc += fmaxf(((v[q][k] - mu) * is) * ga + be, 0.f);
+        o[k] = acc * 0.25f;
+    }
+    vec_io<V, L>::store(y + i * 16, o);
+}
+
+// gradient vector of input row r when dy is the POOLED gradient [N][H/2][W/2][C]: dy[pooled row] / 4, zero in a dropped odd
+// row / column (F.avg_pool2d floor mode)
+template <typename V, int L>
+__device__ __forceinline__ void pooled_grad(const char *__restrict__ gp, long r, int cv, int cx, int H, int W, float (&g)[L])
+{
+    const int w = (int)(r % W);
+    const long t = r / W;
+    const int h = (int)(t % H);
+    const long n = t / H;
+    const int Ho = H / 2, Wo = W / 2;
+    const bool inside = h < 2 * Ho && w < 2 * Wo;
+    vec_io<V, L>::load(gp + ((((n * Ho + (inside ? h / 2 : 0)) * Wo + (inside ? w / 2 : 0)) * cv + cx) * 16), g);
+#pragma unroll
+    for (int k = 0; k < L; k++) g[k] = inside ? g[k] * 0.25f : 0.f;
+}
+
 // g = dy * (y > 0) ; sums[0][C] += sum g (= dbeta) ; sums[1][C] += sum g * xhat (= dgamma)
 // MASK: 0 no ReLU, 1 ReLU mask from the stored output y, 2 recomputed from x; DROP: fused dropout (compile-time, so the
 // element loop has no branches)
-template <typename V, int L, int MASK, bool DROP>
+template <typename V, int L, int MASK, bool DROP, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                             const char *__restrict__ x, long M, int C,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            DropArgs drop, float *__restrict__ part)
+                                                            DropArgs drop, float *__restrict__ part, int PH = 0, int PW = 0)
 {
     __shared__ float red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
@@ -329,7 +379,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                 const long r = row0 + (long)(it0 + u) * rpi + ry;
                 ok[u] = r < M;
                 vec[u] = (ok[u] ? r : M - 1) * cv + cx;
-                vec_io<V, L>::load(dy + vec[u] * 16, g[u]);
+                if (POOL) pooled_grad<V, L>(dy, ok[u] ? r : M - 1, cv, cx, PH, PW, g[u]); // dy = the pooled gradient
+                else vec_io<V, L>::load(dy + vec[u] * 16, g[u]);
                 vec_io<V, L>::load(x + vec[u] * 16, xv[u]);
                 if (MASK == 1) vec_io<V, L>::load(y + vec[u] * 16, yv[u]);
             }
@@ -381,11 +432,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     coef[6 * C + c] = gamma[c];
 }
 
-template <typename V, int L>
+template <typename V, int L, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                            const char *__restrict__ x, char *__restrict__ dx,
                                                            char *__restrict__ dres, long M, int C,
-                                                           const float *__restrict__ coef, int mask_from_x, DropArgs drop)
+                                                           const float *__restrict__ coef, int mask_from_x, DropArgs drop,
+                                                           int PH = 0, int PW = 0)
 {
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
@@ -408,7 +460,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         if (r >= M) break;
         const long off = (r * cv + cx) * 16;
         float g[L], xv[L], yv[L];
-        vec_io<V, L>::load(dy + off, g);
+        if (POOL) pooled_grad<V, L>(dy, r, cv, cx, PH, PW, g);
+        else vec_io<V, L>::load(dy + off, g);
         vec_io<V, L>::load(x + off, xv);
         if (y) vec_io<V, L>::load(y + off, yv);
         if (drop.thresh) {
@@ -576,6 +629,59 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
               (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x, drop);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* BatchNorm (training) + ReLU + 2x2 average pool in one pass over x (the stem's tail, models/model_utils.py:187-228):
+ * x [N][H][W][C] -> y [N][H/2][W/2][C]; statistics over all N*H*W rows like salsa_nn_bn_train_fwd. */
+int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                               float *save_mean, float *save_invstd, double *sums_ws, void *hip_stream)
+{
+    const int64_t M = N * H * W;
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
+        return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned nblk = bn_reduce_blocks(dtype, M, C);
+    float *part = (float *)(sums_ws + 2 * C);
+    NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var);
+    const long n_vec = (long)N * (H / 2) * (W / 2) * (C / (dtype == 1 ? 8 : 4));
+    NN_LAUNCH(bn_apply_pool_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), (const char *)x, (char *)y, n_vec, H, W, C,
+              save_mean, save_invstd, gamma, beta);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* its backward: dy_pooled [N][H/2][W/2][C] -> dx [N][H][W][C] (+ dgamma, dbeta); the ReLU mask is recomputed from x */
+int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
+                         const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
+                         double *sums_ws, float *coef_ws, void *hip_stream)
+{
+    const int64_t M = N * H * W;
+    if (!dy_pooled || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
+        N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
+        return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const unsigned nblk = bn_reduce_blocks(dtype, M, C);
+    float *part = (float *)(sums_ws + 2 * C);
+    const DropArgs drop = drop_args(0.f, 0u);
+    if (dtype == 1)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16x8, 8, 2, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled,
+                           (const char *)nullptr, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<f32x4, 4, 2, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled,
+                           (const char *)nullptr, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
+                       save_invstd, beta, coef_ws, dgamma, dbeta);
+    if (dtype == 1)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16x8, 8, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
+                           (const char *)dy_pooled, (const char *)nullptr, (const char *)x, (char *)dx, (char *)nullptr, (long)M, C,
+                           coef_ws, 1, drop, H, W);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<f32x4, 4, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
+                           (const char *)dy_pooled, (const char *)nullptr, (const char *)x, (char *)dx, (char *)nullptr, (long)M, C,
+                           coef_ws, 1, drop, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -144,6 +144,46 @@ def test_fused_batchnorm_add_relu_matches_torch(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_batchnorm_relu_avgpool_matches_torch(dtype):
+    """BatchNormAct2d.relu_pool (salsa_nn_bn_train_fwd_pool / salsa_nn_bn_bwd_pool, the stem's tail of
+    models/model_utils.py:187-228) against nn.BatchNorm2d + ReLU + F.avg_pool2d in float32: outputs, every gradient, running
+    statistics; even and odd extents (floor mode drops the last row / column, whose gradient is zero)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import BatchNormAct2d, _BnReluPool
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(3)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    for n, c, h, w in ((4, 64, 40, 24), (3, 64, 9, 7), (2, 128, 5, 6), (1, 512, 2, 3)):
+        ref, fus = nn.BatchNorm2d(c).to(dev), BatchNormAct2d(c).to(dev)
+        with torch.no_grad():
+            ref.weight.copy_(torch.rand(c, device=dev, generator=g) + 0.5)
+            ref.bias.copy_(torch.randn(c, device=dev, generator=g))
+        fus.load_state_dict(ref.state_dict())
+        for step in range(2):
+            x = (torch.randn((n, c, h, w), device=dev, generator=g) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+            xa, xb = x.clone().requires_grad_(True), x.float().clone().requires_grad_(True)
+            ya = fus.relu_pool(xa)
+            yb = F.avg_pool2d(F.relu(ref(xb)), 2)
+            assert isinstance(ya.grad_fn, _BnReluPool._backward_cls) and ya.dtype == dtype and ya.shape == yb.shape
+            torch.testing.assert_close(ya.float(), yb, **(tol if dtype == torch.float32 else dict(rtol=2.0 ** -8, atol=1e-3)))
+            gy = torch.randn(ya.shape, device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+            ya.backward(gy)
+            yb.backward(gy.float())
+            torch.testing.assert_close(xa.grad.float(), xb.grad, **tol)
+            torch.testing.assert_close(fus.weight.grad, ref.weight.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+            torch.testing.assert_close(fus.bias.grad, ref.bias.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+            torch.testing.assert_close(fus.running_mean, ref.running_mean, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(fus.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+            assert int(fus.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+            fus.zero_grad(); ref.zero_grad()
+    fus.eval()                                                                   # eval mode: the unfused composite
+    with torch.no_grad():
+        torch.testing.assert_close(fus.relu_pool(x).float(), F.avg_pool2d(F.relu(ref.eval()(x.float())), 2),
+                                   **(tol if dtype == torch.float32 else dict(rtol=2.0 ** -7, atol=2e-3)))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_fused_batchnorm_relu_dropout(dtype):
     """The dropout fused behind BatchNorm + ReLU (salsa_nn_bn_train_fwd drop_p): every output is either dropped or the
     undropped output / (1 - p); the drop rate is p; the same seed gives the same mask; the backward -- which regenerates the
