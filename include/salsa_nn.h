@@ -102,6 +102,13 @@ int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dty
                          const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
                          double *sums_ws, float *coef_ws, void *hip_stream);
 
+/* The bf16 working copies of the float32 master filters (what autocast's per-layer casts + permutes + flips produce in the
+ * reference's training step, models/seld_models.py:68-76 under torch.cuda.amp) for ALL layers in one launch: forward layout
+ * [Cout][3][3][Cin] and, when the descriptor's bwd pointer is not 0, the data-gradient layout [Cin][3][3][Cout] with flipped taps.
+ * desc (device memory): n_layers x 10 int64 = {src float32*, fwd bf16*, bwd bf16*, Cout, Cin, src element strides for
+ * (co, ci, ky, kx), first block}; layer l owns (Cout/32)*(Cin/32) consecutive blocks; n_blocks = the total.  Cout, Cin % 32 == 0. */
+int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

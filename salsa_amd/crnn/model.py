@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv3x3, avg_pool2x2, conv1x1, conv_bn_act
+from .nn_ops import BatchNormAct2d, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -80,6 +80,8 @@ class Encoder(nn.Module):
             blocks += [ResBlock(cin, cout, stride), ResBlock(cout, cout, 1)]
             cin = cout
         self.stages = nn.Sequential(*blocks)
+        # one kernel per step makes the bf16 working copies of all 3x3 filters (not a module, parameter or buffer: no state)
+        self._filter_bank = ConvFilterBank([m for m in self.modules() if isinstance(m, Conv3x3)])
 
     def forward(self, x):
         x = self.stem(x)

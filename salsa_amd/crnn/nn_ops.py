@@ -213,18 +213,20 @@ class _Conv3x3C64(torch.autograd.Function):
     kernel with the flipped / transposed filter) and weight gradient (float32, straight into the float32 parameter's grad)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
-        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        ctx.save_for_backward(x, wb)
+    def forward(ctx, x, weight, wb=None, wbt=None):
+        # wb / wbt: the bf16 filter and its flipped / transposed twin from the model's ConvFilterBank, when there is one
+        if wb is None:
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, wb, wbt)
         return _conv64(x, wb)
 
     @staticmethod
     def backward(ctx, gy):
-        x, wb = ctx.saved_tensors
+        x, wb, wbt = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv64(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+            gx = _conv64(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
         if ctx.needs_input_grad[1]:
             N, _, H, W = x.shape
             gw = torch.zeros((64, 64, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
@@ -232,7 +234,7 @@ class _Conv3x3C64(torch.autograd.Function):
                 rc = _lib.load().salsa_nn_conv3x3_c64_wrw(_ptr(x), _ptr(gy), _ptr(gw), N, H, W, _stream(x))
             if rc:
                 raise RuntimeError('salsa_nn_conv3x3_c64_wrw failed (%d)' % rc)
-        return gx, gw
+        return gx, gw, None, None
 
 
 def _conv_wide(x, w):
@@ -288,21 +290,22 @@ class _Conv3x3Wide(torch.autograd.Function):
     gradient (transposing LDS reads, float32 result); shapes a kernel does not take fall back to torch / MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight):
-        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        ctx.save_for_backward(x, wb)
+    def forward(ctx, x, weight, wb=None, wbt=None):
+        if wb is None:
+            wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(x, wb, wbt)
         return _conv_wide(x, wb)
 
     @staticmethod
     def backward(ctx, gy):
-        x, wb = ctx.saved_tensors
+        x, wb, wbt = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         N, Cin, H, W = x.shape
         # the data gradient is a Cout -> Cin convolution: the kernel takes it when Cin is a multiple of 64 (always in the CRNN)
         own_dgrad = ctx.needs_input_grad[0] and bool(_lib.load().salsa_nn_conv3x3_wide_supported(N, H, W, wb.shape[0], Cin))
         if own_dgrad:
-            gx = _conv_wide(gy, wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+            gx = _conv_wide(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
         own_wrw = (ctx.needs_input_grad[1] and USE_HIP_CONV_WIDE_WRW
                    and bool(_lib.load().salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, wb.shape[0])))
         if own_wrw:
@@ -312,7 +315,7 @@ class _Conv3x3Wide(torch.autograd.Function):
             r = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             gx = r[0] if need[0] else gx
             gw = r[1].float() if need[1] else gw
-        return gx, gw
+        return gx, gw, None, None
 
 
 def _planar_rows(x):
@@ -366,6 +369,69 @@ class _Conv3x3Stem(torch.autograd.Function):
         return gx, gw
 
 
+USE_FILTER_BANK = os.environ.get('SALSA_FILTER_BANK', '1') != '0'
+
+
+class ConvFilterBank:
+    """bf16 working copies of the hand-written 3x3 convolutions' float32 master filters -- the forward kernels' channels-last
+    layout and the data-gradient kernels' flipped / transposed one -- produced for ALL layers by one launch
+    (salsa_nn_conv_filter_bank) instead of four small torch kernels per layer per step (autocast's cast, the channels-last
+    copy, flip, transpose copy).  A layer asking for its filters compares its weight's version counter (every in-place update,
+    e.g. the optimizer step, bumps it) with the one recorded at the last refresh; the first stale layer refreshes the whole
+    bank.  The views handed out alias the bank: a refresh between a forward and its backward (a weight modified in place
+    mid-graph, which autograd itself rejects) would change what that backward reads."""
+
+    def __init__(self, convs):
+        self.convs = [c for c in convs if isinstance(c, Conv3x3) and c.kernel_size == (3, 3) and c.in_channels % 32 == 0
+                      and c.out_channels % 32 == 0 and c.groups == 1]
+        for i, c in enumerate(self.convs):
+            c._bank = (self, i)
+        self._ptrs = None
+
+    def _build(self):
+        dev = self.convs[0].weight.device
+        sizes = [c.weight.numel() for c in self.convs]
+        self._flat = torch.empty(2 * sum(sizes), dtype=torch.bfloat16, device=dev)
+        rows, off, blk, self._fwd, self._bwd = [], 0, 0, [], []
+        for c, n in zip(self.convs, sizes):
+            co, ci = c.out_channels, c.in_channels
+            f, b = self._flat[off:off + n], self._flat[off + n:off + 2 * n]
+            self._fwd.append(f.view(co, 3, 3, ci).permute(0, 3, 1, 2))          # (Cout, Cin, 3, 3), channels-last memory
+            self._bwd.append(b.view(ci, 3, 3, co).permute(0, 3, 1, 2))          # (Cin, Cout, 3, 3), taps flipped
+            rows.append([c.weight.data_ptr(), f.data_ptr(), b.data_ptr(), co, ci, *c.weight.stride(), blk])
+            off, blk = off + 2 * n, blk + (co // 32) * (ci // 32)
+        self._desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._blocks = blk
+        self._ptrs = [c.weight.data_ptr() for c in self.convs]
+        self._versions = [-1] * len(self.convs)
+
+    def refresh(self):
+        if self._ptrs is None or any(c.weight.data_ptr() != p for c, p in zip(self.convs, self._ptrs)):
+            self._build()                                            # first use, or the parameters moved (.to(), load)
+        w0 = self.convs[0].weight
+        with torch.cuda.device(w0.device):
+            rc = _lib.load().salsa_nn_conv_filter_bank(_ptr(self._desc), len(self.convs), self._blocks, _stream(w0))
+        if rc:
+            raise RuntimeError('salsa_nn_conv_filter_bank failed (%d)' % rc)
+        self._versions = [c.weight._version for c in self.convs]
+
+    def filters(self, i):
+        """(forward filter, data-gradient filter) of layer i as bf16 channels-last views, refreshed if its weight changed."""
+        w = self.convs[i].weight
+        if self._ptrs is None or self._versions[i] != w._version or self._ptrs[i] != w.data_ptr():
+            self.refresh()
+        return self._fwd[i], self._bwd[i]
+
+
+def _bank_filters(conv):
+    """the layer's filters from its model's ConvFilterBank, or (None, None): float32 CUDA master weights only"""
+    bank = getattr(conv, '_bank', None)
+    w = conv.weight
+    if bank is None or not USE_FILTER_BANK or not w.is_cuda or w.dtype != torch.float32:
+        return None, None
+    return bank[0].filters(bank[1])
+
+
 class Conv3x3(torch.nn.Conv2d):
     """nn.Conv2d(cin, cout, 3, padding=1, bias=False) whose 64 -> 64 instances run the MFMA kernel for bf16 channels-last
     CUDA inputs (i.e. under the trainer's autocast) and whose (Cin <= 8) -> 64 instance -- the network's first layer -- runs
@@ -397,10 +463,12 @@ class Conv3x3(torch.nn.Conv2d):
     def forward(self, x):
         if self._hip_eligible(x):
             with torch.autocast('cuda', enabled=False):
-                return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
+                return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
+                                         *_bank_filters(self))
         if self._wide_eligible(x):
             with torch.autocast('cuda', enabled=False):
-                return _Conv3x3Wide.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight)
+                return _Conv3x3Wide.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
+                                          *_bank_filters(self))
         if self._stem_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3Stem.apply(x, self.weight)

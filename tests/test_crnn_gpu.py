@@ -540,3 +540,36 @@ def test_eval_wide_conv_with_folded_batchnorm_epilogue():
             ref = ref + r.float() if use_res else ref
             ref = F.relu(ref) if relu else ref
             torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=8e-2)        # bf16 filter (scaled) and output rounding
+
+
+def test_conv_filter_bank_matches_torch_casts_and_tracks_weight_updates():
+    """ConvFilterBank (salsa_nn_conv_filter_bank: one launch for all layers) against what it replaces -- torch's per-layer
+    ``weight.to(bf16).contiguous(channels_last)`` and ``.flip(2, 3).transpose(0, 1).contiguous(channels_last)`` -- bit for
+    bit, for contiguous and channels-last master weights; an in-place weight update is picked up at the next request."""
+    from salsa_amd.crnn.nn_ops import Conv3x3, ConvFilterBank
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    convs = [Conv3x3(ci, co, 3, padding=1, bias=False).to(dev) for ci, co in ((64, 64), (64, 128), (128, 96), (256, 512), (512, 512))]
+    convs[2].weight.data = convs[2].weight.data.contiguous(memory_format=torch.channels_last)   # another stride pattern
+    extra = Conv3x3(7, 64, 3, padding=1, bias=False).to(dev)                                     # not bankable (Cin % 32)
+    bank = ConvFilterBank(convs + [extra])
+    assert len(bank.convs) == 5 and not hasattr(extra, '_bank')
+
+    def check():
+        for i, c in enumerate(convs):
+            f, b = bank.filters(i)
+            wb = c.weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            assert f.shape == wb.shape and f.is_contiguous(memory_format=torch.channels_last) and torch.equal(f, wb)
+            wt = wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            assert b.shape == wt.shape and b.is_contiguous(memory_format=torch.channels_last) and torch.equal(b, wt)
+
+    check()
+    launches = bank._versions[:]
+    bank.filters(3)
+    assert bank._versions == launches                                     # nothing changed: no refresh
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(1.5).add_(0.01)                                   # what an optimizer step does: in place
+    check()
+    convs[1].weight.data = torch.randn_like(convs[1].weight)              # re-allocated parameter storage
+    check()
