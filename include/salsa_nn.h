@@ -84,6 +84,7 @@ size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C); /* size of sums
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                           float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                          int64_t *batches_tracked /* nn.BatchNorm2d.num_batches_tracked (device), += 1; may be NULL */,
                           void *hip_stream);
 int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                          const float *beta, const float *mean, const float *invstd, int relu, void *hip_stream);
@@ -97,7 +98,7 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
  * one rounding); the full-resolution activation is never written.  Backward from the POOLED gradient, ReLU mask recomputed from x. */
 int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, void *hip_stream);
+                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked, void *hip_stream);
 int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                          const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
                          double *sums_ws, float *coef_ws, void *hip_stream);

@@ -72,7 +72,7 @@ class _BnAct(torch.autograd.Function):
     """y = [dropout]( [relu]( batch_norm(x) [+ residual] ) ) in training mode (salsa_nn_bn_train_fwd / salsa_nn_bn_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, drop_p=0.0):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, drop_p=0.0, batches_tracked=None):
         N, Cn, H, W = x.shape
         M = N * H * W
         y = torch.empty_like(x, memory_format=torch.channels_last)
@@ -84,7 +84,7 @@ class _BnAct(torch.autograd.Function):
             rc = _lib.load().salsa_nn_bn_train_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight),
                                                    _ptr(bias), float(eps), float(momentum), _ptr(running_mean),
                                                    _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu),
-                                                   float(drop_p), seed, _stream(x))
+                                                   float(drop_p), seed, _ptr(batches_tracked), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
         # the ReLU mask comes from y only when something was added before the ReLU; otherwise the backward recomputes it from x
@@ -108,7 +108,7 @@ class _BnAct(torch.autograd.Function):
                                              _ptr(dwb[1]), _ptr(ws), _ptr(coef), ctx.drop[0], ctx.drop[1], _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None, None
 
 
 class _BnReluPool(torch.autograd.Function):
@@ -116,7 +116,7 @@ class _BnReluPool(torch.autograd.Function):
     tail; the full-resolution activation is neither written in the forward nor its gradient in the backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None):
         N, Cn, H, W = x.shape
         y = torch.empty((N, Cn, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
@@ -124,7 +124,7 @@ class _BnReluPool(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
                                                         float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
-                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _stream(x))
+                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd_pool failed (%d)' % rc)
         ctx.save_for_backward(x, weight, bias, save)
@@ -145,7 +145,7 @@ class _BnReluPool(torch.autograd.Function):
                                                   _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd_pool failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None
 
 
 USE_HIP_BN_POOL = os.environ.get('SALSA_HIP_BN_POOL', '1') != '0'
@@ -162,9 +162,8 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
                 and self.track_running_stats and self.momentum is not None and x.shape[2] >= 2 and x.shape[3] >= 2
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
-            self.num_batches_tracked.add_(1)
             return _BnReluPool.apply(x, self.weight.float(), self.bias.float(), self.running_mean, self.running_var, self.momentum,
-                                     self.eps)
+                                     self.eps, self.num_batches_tracked)   # (the kernel counts the batch: no add_ launch)
         return avg_pool2x2(self.forward(x, relu=True))
 
     def forward(self, x, residual=None, relu=False, dropout_p=0.0):
@@ -184,8 +183,8 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             return F.dropout(y, p=dropout_p, training=True) if dropout_p > 0 else y
         w, b = self.weight.float(), self.bias.float()
         if self.training:
-            self.num_batches_tracked.add_(1)
-            return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu, float(dropout_p))
+            return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu, float(dropout_p),
+                                self.num_batches_tracked)                  # (the kernel counts the batch: no add_ launch)
         N, Cn, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
         invstd = torch.rsqrt(self.running_var + self.eps)

@@ -204,8 +204,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, float eps,
                                                           float momentum, float *__restrict__ save_mean,
                                                           float *__restrict__ save_invstd, float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var)
+                                                          float *__restrict__ running_var, long long *__restrict__ batches_tracked)
 {
+    if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1; // nn.BatchNorm2d.num_batches_tracked
     __shared__ double red[256];
     bn_sum_partials4(part, nblk, C, blockIdx.x * 4, red);
     const int c = blockIdx.x * 4 + threadIdx.x;
@@ -594,7 +595,7 @@ size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                           float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
-                          void *hip_stream)
+                          int64_t *batches_tracked, void *hip_stream)
 {
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C) || drop_p < 0.f ||
         drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32))
@@ -604,7 +605,7 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
     float *part = (float *)(sums_ws + 2 * C);
     NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var);
+                       save_invstd, running_mean, running_var, (long long *)batches_tracked);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
               (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed));
     return hipGetLastError() == hipSuccess ? 0 : -6;
@@ -666,7 +667,7 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
  * x [N][H][W][C] -> y [N][H/2][W/2][C]; statistics over all N*H*W rows like salsa_nn_bn_train_fwd. */
 int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, void *hip_stream)
+                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked, void *hip_stream)
 {
     const int64_t M = N * H * W;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
@@ -676,7 +677,7 @@ int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int
     float *part = (float *)(sums_ws + 2 * C);
     NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
-                       save_invstd, running_mean, running_var);
+                       save_invstd, running_mean, running_var, (long long *)batches_tracked);
     const long n_vec = (long)N * (H / 2) * (W / 2) * (C / (dtype == 1 ? 8 : 4));
     NN_LAUNCH(bn_apply_pool_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), (const char *)x, (char *)y, n_vec, H, W, C,
               save_mean, save_invstd, gamma, beta);
