@@ -656,20 +656,39 @@ __device__ __forceinline__ bf16x8 tr_value(const tr_frag &f)
 }
 
 
-template <int Q>
-__device__ __forceinline__ void wrw_steps(tr_frag (&fr)[2], bf16x8 &a, f32x16 (&acc)[9], const unsigned ga, const unsigned xa)
+#ifndef WRW_DEPTH
+#define WRW_DEPTH 2 // operand fragments requested ahead of the one being multiplied: 1: 603, 2: 676, 3: 654, 4: 635 TFLOP/s at
+                    // 32 x 640 x 200 (one fragment ahead left every step waiting out most of an LDS round trip)
+#endif
+// waits until all but the `n` newest LDS reads have returned (they return in order), naming fragment f as now valid
+#define LDS_TR_WAIT_N(f, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"((f).lo), "+v"((f).hi))
+
+template <int Q> __device__ __forceinline__ void wrw_issue(tr_frag &f, const unsigned ga, const unsigned xa)
 {
+    constexpr int ks_ = Q / 10, j_ = Q % 10, rr_ = ks_ >> 1, hw_ = ks_ & 1;
+    if constexpr (j_ == 0) LDS_TR_ISSUE(f, ga, 2 * ((rr_ * WT_W + 16 * hw_) * ROW));
+    else LDS_TR_ISSUE(f, xa, 2 * (((rr_ + (j_ - 1) / 3) * WHALO_W + 16 * hw_ + (j_ - 1) % 3) * ROW));
+}
+
+// (A variant in which a wave owns both co halves and a group of 4 - 5 taps -- 0.72 instead of 1.11 fragment reads per MFMA --
+// measured no faster, 621 - 648 TFLOP/s: the LDS read rate is not what this kernel waits for.)
+template <int Q>
+__device__ __forceinline__ void wrw_steps(tr_frag (&fr)[WRW_DEPTH + 1], bf16x8 &a, f32x16 (&acc)[9], const unsigned ga, const unsigned xa)
+{
+    constexpr int R = WRW_DEPTH + 1;
     if constexpr (Q < 80) {
-        if constexpr (Q + 1 < 80) {
-            constexpr int q1 = Q + 1, ks_ = q1 / 10, j_ = q1 % 10, rr_ = ks_ >> 1, hw_ = ks_ & 1;
-            if constexpr (j_ == 0) LDS_TR_ISSUE(fr[q1 & 1], ga, 2 * ((rr_ * WT_W + 16 * hw_) * ROW));
-            else LDS_TR_ISSUE(fr[q1 & 1], xa, 2 * (((rr_ + (j_ - 1) / 3) * WHALO_W + 16 * hw_ + (j_ - 1) % 3) * ROW));
+        if constexpr (Q + WRW_DEPTH < 80) wrw_issue<Q + WRW_DEPTH>(fr[(Q + WRW_DEPTH) % R], ga, xa);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q % 10 == 0) a = tr_value(fr[Q % R]);
+        else acc[Q % 10 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_value(fr[Q % R]), acc[Q % 10 - 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q + 1 < 80) { // fragment Q+1 must have landed; the younger ones (two reads each) may still be in flight
+            constexpr int younger = (Q + WRW_DEPTH < 80 ? WRW_DEPTH : 79 - Q) - 1;
+            if constexpr (younger <= 0) LDS_TR_WAIT_N(fr[(Q + 1) % R], 0);
+            else if constexpr (younger == 1) LDS_TR_WAIT_N(fr[(Q + 1) % R], 2);
+            else if constexpr (younger == 2) LDS_TR_WAIT_N(fr[(Q + 1) % R], 4);
+            else LDS_TR_WAIT_N(fr[(Q + 1) % R], 6);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (Q % 10 == 0) a = tr_value(fr[Q & 1]);
-        else acc[Q % 10 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tr_value(fr[Q & 1]), acc[Q % 10 - 1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (Q + 1 < 80) LDS_TR_WAIT(fr[(Q + 1) & 1]);
         wrw_steps<Q + 1>(fr, a, acc, ga, xa);
     }
 }
@@ -738,10 +757,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
         // the fragment of step q+1 is requested before step q's MFMA issues.  Step q = ks * 10 + j: j = 0 is the dy
         // fragment of K-step ks, j = 1..9 the x fragment of tap j-1.
         const unsigned ga = gbase + a_lane, xa = xbase + b_lane;
-        tr_frag fr[2];
+        tr_frag fr[WRW_DEPTH + 1];
         bf16x8 a;
-        LDS_TR_ISSUE(fr[0], ga, 0);
-        LDS_TR_WAIT(fr[0]);
+        wrw_issue<0>(fr[0], ga, xa);
+        if constexpr (WRW_DEPTH >= 2) wrw_issue<1>(fr[1], ga, xa);
+        if constexpr (WRW_DEPTH >= 3) wrw_issue<2>(fr[2], ga, xa);
+        if constexpr (WRW_DEPTH >= 4) wrw_issue<3>(fr[3], ga, xa);
+        if constexpr (WRW_DEPTH == 1) LDS_TR_WAIT_N(fr[0], 0);
+        else if constexpr (WRW_DEPTH == 2) LDS_TR_WAIT_N(fr[0], 2);
+        else if constexpr (WRW_DEPTH == 3) LDS_TR_WAIT_N(fr[0], 4);
+        else LDS_TR_WAIT_N(fr[0], 6);
         wrw_steps<0>(fr, a, acc, ga, xa);
     }
     // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the block
@@ -762,7 +787,8 @@ extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw
     if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     // persistent workgroups, two per CU; fewer when there are few tiles (every workgroup ends with 36 864 float atomics)
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 256 : tiles >= 128 ? 128 : tiles);
+    // (mid sizes, 32 x 320 x 100: 256 workgroups 0.158 ms, 384: 0.141, 512: 0.149)
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
     hipLaunchKernelGGL(conv3x3_c64_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)dy, dw, (int)N, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
