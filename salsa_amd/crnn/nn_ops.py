@@ -162,6 +162,7 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
                 and self.track_running_stats and self.momentum is not None and x.shape[2] >= 2 and x.shape[3] >= 2
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
+            self._stats_serial = getattr(self, '_stats_serial', 0) + 1
             return _BnReluPool.apply(x, self.weight.float(), self.bias.float(), self.running_mean, self.running_var, self.momentum,
                                      self.eps, self.num_batches_tracked)   # (the kernel counts the batch: no add_ launch)
         return avg_pool2x2(self.forward(x, relu=True))
@@ -183,6 +184,7 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             return F.dropout(y, p=dropout_p, training=True) if dropout_p > 0 else y
         w, b = self.weight.float(), self.bias.float()
         if self.training:
+            self._stats_serial = getattr(self, '_stats_serial', 0) + 1
             return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu, float(dropout_p),
                                 self.num_batches_tracked)                  # (the kernel counts the batch: no add_ launch)
         N, Cn, H, W = x.shape
@@ -490,6 +492,28 @@ def conv1x1(conv, x):
     return conv(x)
 
 
+def _folded(conv, bn, stem=False):
+    """(filter, shift) of an eval-mode conv + BatchNorm pair folded for the kernels' epilogue: filter = w * gamma / sigma in
+    bf16 (channels-last, or the stem kernel's layout), shift = beta - mean * gamma / sigma in float32.  Cached on the conv
+    module and keyed on the version counters of the five tensors involved (an optimizer step, load_state_dict or a training
+    forward bumps them), so repeated inference calls do not re-run the seven small kernels per layer."""
+    srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    # (_stats_serial: the fused training kernels update the running statistics through raw pointers, invisible to torch's counters)
+    key = tuple((t.data_ptr(), t._version) for t in srcs) + (float(bn.eps), stem, getattr(bn, '_stats_serial', 0))
+    hit = getattr(conv, '_fold_cache', None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
+        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        if stem:
+            wf = _stem_filter(conv.weight, scale)
+        else:
+            wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    conv._fold_cache = (key, wf, shift)
+    return wf, shift
+
+
 def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
     """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
@@ -500,9 +524,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
             and bn.track_running_stats and bn.affine
             and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == 64
                                       and residual.is_contiguous(memory_format=torch.channels_last)))):
-        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
-        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-        wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wf, shift = _folded(conv, bn)
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, _, H, W = xb.shape
         fuse_pool = pool and H % 2 == 0 and W % 2 == 0
@@ -519,9 +541,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
             and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == conv.out_channels
                                       and residual.is_contiguous(memory_format=torch.channels_last)))):
         # the wide layers at inference: the same folding on conv_wide.hip's epilogue
-        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
-        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-        wf = (conv.weight.float() * scale[:, None, None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wf, shift = _folded(conv, bn)
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, Cin, H, W = xb.shape
         y = torch.empty((N, conv.out_channels, H, W), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
@@ -533,9 +553,8 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
         return y
     if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
             and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
-        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).float()
-        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-        y = _conv_stem(x, _stem_filter(conv.weight, scale), shift, relu)
+        wq, shift = _folded(conv, bn, stem=True)
+        y = _conv_stem(x, wq, shift, relu)
         return avg_pool2x2(y) if pool else y
     if pool and relu and residual is None and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d):
         return bn.relu_pool(conv(x))

@@ -573,3 +573,39 @@ def test_conv_filter_bank_matches_torch_casts_and_tracks_weight_updates():
     check()
     convs[1].weight.data = torch.randn_like(convs[1].weight)              # re-allocated parameter storage
     check()
+
+
+def test_folded_filter_cache_follows_parameter_and_statistics_updates():
+    """conv_bn_act's eval path caches the folded (filter, shift) pair per layer; the cache must miss after an in-place weight
+    update AND after a training-mode forward (whose fused kernels update the running statistics through raw pointers)."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import BatchNormAct2d, Conv3x3, conv_bn_act
+    dev = torch.device('cuda:0')
+    torch.manual_seed(9)
+    conv, bn = Conv3x3(64, 64, 3, padding=1, bias=False).to(dev), BatchNormAct2d(64).to(dev)
+    x = torch.randn(2, 64, 24, 20, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def fused_eval():
+        conv.eval(); bn.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            return conv_bn_act(conv, bn, x).float()
+
+    def reference():
+        y = F.conv2d(x.float(), conv.weight.float(), padding=1)
+        return F.relu(F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+
+    tol = dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(fused_eval(), reference(), **tol)
+    assert conv._fold_cache is not None
+    first = conv._fold_cache[1]
+    fused_eval()
+    assert conv._fold_cache[1] is first                                      # unchanged parameters: cache hit
+    conv.train(); bn.train()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        for _ in range(3):
+            conv_bn_act(conv, bn, x * 3 + 1)                                 # moves the running statistics a long way
+    torch.testing.assert_close(fused_eval(), reference(), **tol)
+    assert conv._fold_cache[1] is not first
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    torch.testing.assert_close(fused_eval(), reference(), **tol)
