@@ -119,8 +119,8 @@ constexpr int BN_ROWS_PER_THREAD = BN_RPT;
 constexpr int BN_BATCH = BN_BATCH_N; // rows whose loads are in flight together in the reduction kernels
 static_assert(BN_RPT % BN_BATCH_N == 0, "row batches");
 
-template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], float (&b)[L], float *red /*[2L][256]*/, int cv,
-                                                                  float *part_a, float *part_b, int c0)
+template <int L, typename A = float>
+__device__ __forceinline__ void bn_block_reduce(A (&a)[L], A (&b)[L], A *red /*[2L][256]*/, int cv, A *part_a, A *part_b, int c0)
 {
     const int tid = threadIdx.x; // red[value][thread]: neighbouring lanes touch neighbouring banks
 #pragma unroll
@@ -148,7 +148,8 @@ template <int L> __device__ __forceinline__ void bn_block_reduce(float (&a)[L], 
 // Sum the blocks' partials [nblk][2][C] for FOUR channels (both sums) in float64: a 256-thread block = 8 outputs
 // (o = which * 4 + channel) x 32 threads that each add every 32nd partial, then an LDS tree over the 32.  On return
 // red[o] holds the totals; the statistics kernels below finish their per-channel arithmetic in the same launch.
-__device__ __forceinline__ void bn_sum_partials4(const float *__restrict__ part, int nblk, int C, int c0, double *red /*[256]*/)
+template <typename P>
+__device__ __forceinline__ void bn_sum_partials4(const P *__restrict__ part, int nblk, int C, int c0, double *red /*[256]*/)
 {
     const int o = threadIdx.x & 7, seg = threadIdx.x >> 3;
     const int c = c0 + (o & 3), which = o >> 2;
@@ -165,15 +166,18 @@ __device__ __forceinline__ void bn_sum_partials4(const float *__restrict__ part,
 
 // part[block][0][C] = sum x, part[block][1][C] = sum x^2 over the block's rows
 template <typename V, int L>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ x, long M, int C, float *__restrict__ part)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ x, long M, int C, double *__restrict__ part)
 {
-    __shared__ float red[256 * 2 * L];
+    // float64 sums (the same instruction rate as float32 on this chip, and the pass is HBM-bound): var = E[x^2] - mean^2 keeps
+    // its digits when |mean| >> std, where float32 sums of x^2 lose them (float32 PARTIALS alone cost 2e-3 of the variance at
+    // |mean| = 300 sigma)
+    __shared__ double red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
     const long chunk = (long)rpi * BN_ROWS_PER_THREAD;
-    float s[L], ss[L];
+    double s[L], ss[L];
 #pragma unroll
-    for (int k = 0; k < L; k++) s[k] = ss[k] = 0.f;
+    for (int k = 0; k < L; k++) s[k] = ss[k] = 0.0;
     for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
         // BN_BATCH rows' loads are issued together, with no branch between them (a row past the end re-reads the last row
         // and is weighted 0): row-at-a-time code with its bounds test waited for every load before issuing the next
@@ -190,18 +194,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
             for (int u = 0; u < BN_BATCH; u++)
 #pragma unroll
                 for (int k = 0; k < L; k++) {
-                    const float vk = v[u][k] * wgt[u];
+                    const double vk = (double)(v[u][k] * wgt[u]);
                     s[k] += vk;
-                    ss[k] += vk * vk;
+                    ss[k] = fma(vk, vk, ss[k]);
                 }
         }
     }
-    float *mine = part + (long)blockIdx.x * 2 * C;
-    bn_block_reduce<L>(s, ss, red, cv, mine, mine + C, cx * L);
+    double *mine = part + (long)blockIdx.x * 2 * C;
+    bn_block_reduce<L, double>(s, ss, red, cv, mine, mine + C, cx * L);
 }
 
 // training: mean / invstd from the blocks' partial sums, running statistics (momentum, unbiased variance); 4 channels per block
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nblk, long M, int C, float eps,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ part, int nblk, long M, int C, float eps,
                                                           float momentum, float *__restrict__ save_mean,
                                                           float *__restrict__ save_invstd, float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, long long *__restrict__ batches_tracked)
@@ -585,11 +589,11 @@ static DropArgs drop_args(float p, unsigned seed)
 }
 
 int salsa_nn_bn_supported(int dtype, int64_t M, int C) { return bn_geometry_ok(dtype, M, C); }
-/* bytes of the sums_ws scratch: 2*C float64 sums + one float32 partial pair per reduction block */
+/* bytes of the sums_ws scratch: 2*C float64 sums + one partial pair per reduction block (float64 forward, float32 backward) */
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
 {
     if (!bn_geometry_ok(dtype, M, C)) return 0;
-    return sizeof(double) * 2 * C + sizeof(float) * 2 * (size_t)C * bn_reduce_blocks(dtype, M, C);
+    return sizeof(double) * 2 * C + sizeof(double) * 2 * (size_t)C * bn_reduce_blocks(dtype, M, C);
 }
 
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
@@ -602,7 +606,7 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
-    float *part = (float *)(sums_ws + 2 * C);
+    double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
     NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
@@ -674,7 +678,7 @@ int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
-    float *part = (float *)(sums_ws + 2 * C);
+    double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
     NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
