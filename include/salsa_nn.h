@@ -103,11 +103,21 @@ int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dty
                          const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
                          double *sums_ws, float *coef_ws, void *hip_stream);
 
+/* The 1x1 / stride 1 convolutions of the residual shortcuts (models/model_utils.py:340-349) over the flattened pixel axis
+ * (salsa_amd/csrc/conv_1x1.hip): x bf16 [M][Cin] (channels-last pixels, M = N*H*W), w bf16 [Cout][Cin], y bf16 [M][Cout];
+ * the data gradient is the same call on dy with the transposed filter [Cin][Cout]; the weight gradient is float32 [Cout][Cin],
+ * ADDED to dw (zero it first).  *_supported: Cin % 16 == 0 and Cout % 64 == 0 (forward), Cin % 64 == 0 and Cout % 128 == 0 (wrw). */
+int salsa_nn_conv1x1_supported(int64_t M, int Cin, int Cout);
+int salsa_nn_conv1x1(const void *x, const void *w, void *y, int64_t M, int Cin, int Cout, void *hip_stream);
+int salsa_nn_conv1x1_wrw_supported(int64_t M, int Cin, int Cout);
+int salsa_nn_conv1x1_wrw(const void *x, const void *dy, float *dw, int64_t M, int Cin, int Cout, void *hip_stream);
+
 /* The bf16 working copies of the float32 master filters (what autocast's per-layer casts + permutes + flips produce in the
  * reference's training step, models/seld_models.py:68-76 under torch.cuda.amp) for ALL layers in one launch: forward layout
  * [Cout][3][3][Cin] and, when the descriptor's bwd pointer is not 0, the data-gradient layout [Cin][3][3][Cout] with flipped taps.
- * desc (device memory): n_layers x 10 int64 = {src float32*, fwd bf16*, bwd bf16*, Cout, Cin, src element strides for
- * (co, ci, ky, kx), first block}; layer l owns (Cout/32)*(Cin/32) consecutive blocks; n_blocks = the total.  Cout, Cin % 32 == 0. */
+ * desc (device memory): n_layers x 11 int64 = {src float32*, fwd bf16*, bwd bf16*, Cout, Cin, src element strides for
+ * (co, ci, ky, kx), first block, taps (9: 3x3 filter, 1: 1x1 filter)}; layer l owns (Cout/32)*(Cin/32) consecutive blocks;
+ * n_blocks = the total.  Cout, Cin % 32 == 0. */
 int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void *hip_stream);
 
 #ifdef __cplusplus

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act
+from .nn_ops import BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -27,7 +27,7 @@ def _xavier(layer):
 
 
 def _conv(cin, cout, k):
-    cls = Conv3x3 if k == 3 else nn.Conv2d                     # same parameters / state_dict; 64 -> 64 runs on the MFMA kernel
+    cls = Conv3x3 if k == 3 else Conv1x1 if k == 1 else nn.Conv2d                     # same parameters / state_dict; 64 -> 64 runs on the MFMA kernel
     return _xavier(cls(cin, cout, kernel_size=k, stride=1, padding=k // 2, bias=False))
 
 
@@ -81,7 +81,7 @@ class Encoder(nn.Module):
             cin = cout
         self.stages = nn.Sequential(*blocks)
         # one kernel per step makes the bf16 working copies of all 3x3 filters (not a module, parameter or buffer: no state)
-        self._filter_bank = ConvFilterBank([m for m in self.modules() if isinstance(m, Conv3x3)])
+        self._filter_bank = ConvFilterBank([m for m in self.modules() if isinstance(m, (Conv3x3, Conv1x1))])
 
     def forward(self, x):
         x = self.stem(x)

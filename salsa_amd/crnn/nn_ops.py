@@ -25,8 +25,10 @@ def conv_backend_note() -> str:
     if not USE_HIP_CONV:
         return 'all on MIOpen through torch (SALSA_HIP_CONV=0)'
     if USE_HIP_CONV_WIDE:
+        wrw = ('every 64..512-channel 3x3 layer hand-written (the 7->64 first layer: MIOpen)' if os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
+               else '64->64 hand-written, the rest MIOpen')
         return ('every 3x3 layer forward + data gradient on hand-written MFMA kernels (stem 7->64 and 64->64: conv_mfma.hip; 128/256/512 '
-                'channels: conv_wide.hip); weight gradients: 64->64 hand-written, the rest MIOpen; 1x1 shortcuts MIOpen')
+                'channels: conv_wide.hip); weight gradients: %s; 1x1 shortcuts MIOpen' % wrw)
     return 'stem 7->64 and the five 64->64 3x3 layers on the hand-written MFMA kernels (conv_mfma.hip), the 128/256/512-channel layers on MIOpen through torch'
 
 
@@ -363,11 +365,83 @@ class _Conv3x3Stem(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise RuntimeError('the stem convolution does not differentiate its input')
         if ctx.needs_input_grad[1]:
-            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            xb = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last)   # cast + layout in one pass
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             gw = torch.ops.aten.convolution_backward(gy.contiguous(memory_format=torch.channels_last), xb, wb, None, [1, 1], [1, 1],
                                                      [1, 1], False, [0, 0], 1, [False, True, False])[1].float()
         return gx, gw
+
+
+USE_HIP_CONV_1X1 = os.environ.get('SALSA_HIP_CONV_1X1', '1') != '0'
+
+
+def _conv1x1_hip(x, w):
+    """salsa_nn_conv1x1: x (N,Cin,H,W) bf16 channels-last, w (Cout,Cin,1,1) bf16 -> (N,Cout,H,W) bf16 channels-last."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().salsa_nn_conv1x1(_ptr(x), _ptr(w), _ptr(y), N * H * W, Cin, Cout, _stream(x))
+    if rc:
+        raise RuntimeError('salsa_nn_conv1x1 failed (%d)' % rc)
+    return y
+
+
+class _Conv1x1(torch.autograd.Function):
+    """The residual shortcuts' 1x1 convolutions (salsa_amd/csrc/conv_1x1.hip): forward, data gradient (the same kernel with
+    the transposed filter) and weight gradient (float32); a shape a kernel does not take goes to torch / MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wb=None, wbt=None):
+        if wb is None:
+            wb = weight.detach().to(torch.bfloat16).contiguous()
+        ctx.save_for_backward(x, wb, wbt)
+        return _conv1x1_hip(x, wb)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wb, wbt = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        N, Cin, H, W = x.shape
+        Cout, M = wb.shape[0], N * H * W
+        L = _lib.load()
+        gx = gw = None
+        own_dgrad = ctx.needs_input_grad[0] and bool(L.salsa_nn_conv1x1_supported(M, Cout, Cin))
+        if own_dgrad:
+            gx = _conv1x1_hip(gy, wbt if wbt is not None else wb.transpose(0, 1).contiguous())
+        own_wrw = ctx.needs_input_grad[1] and bool(L.salsa_nn_conv1x1_wrw_supported(M, Cin, Cout))
+        if own_wrw:
+            gw = torch.zeros((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = L.salsa_nn_conv1x1_wrw(_ptr(x), _ptr(gy), _ptr(gw), M, Cin, Cout, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_conv1x1_wrw failed (%d)' % rc)
+        need = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wrw, False]
+        if need[0] or need[1]:
+            r = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, need)
+            gx = r[0] if need[0] else gx
+            gw = r[1].float() if need[1] else gw
+        return gx, gw, None, None
+
+
+class Conv1x1(torch.nn.Conv2d):
+    """nn.Conv2d(cin, cout, 1, bias=False) -- same parameters and state_dict keys -- whose bf16 channels-last CUDA forward
+    (the trainer's autocast) runs the hand-written GEMM kernels; everything else is F.conv2d."""
+
+    def _hip_eligible(self, x):
+        bf16 = x.dtype == torch.bfloat16 or (x.is_cuda and torch.is_autocast_enabled('cuda') and
+                                             torch.get_autocast_dtype('cuda') == torch.bfloat16)
+        return (USE_HIP_CONV and USE_HIP_CONV_1X1 and x.is_cuda and bf16 and x.dim() == 4 and self.kernel_size == (1, 1)
+                and self.stride == (1, 1) and self.padding == (0, 0) and self.bias is None and self.dilation == (1, 1)
+                and self.groups == 1 and self.weight.dtype == torch.float32
+                and _lib.load().salsa_nn_conv1x1_supported(x.shape[0] * x.shape[2] * x.shape[3], self.in_channels, self.out_channels))
+
+    def forward(self, x):
+        if self._hip_eligible(x):
+            with torch.autocast('cuda', enabled=False):
+                return _Conv1x1.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
+                                      *_bank_filters(self))
+        return super().forward(x)
 
 
 USE_FILTER_BANK = os.environ.get('SALSA_FILTER_BANK', '1') != '0'
@@ -383,8 +457,9 @@ class ConvFilterBank:
     mid-graph, which autograd itself rejects) would change what that backward reads."""
 
     def __init__(self, convs):
-        self.convs = [c for c in convs if isinstance(c, Conv3x3) and c.kernel_size == (3, 3) and c.in_channels % 32 == 0
-                      and c.out_channels % 32 == 0 and c.groups == 1]
+        self.convs = [c for c in convs if ((isinstance(c, Conv3x3) and c.kernel_size == (3, 3)) or
+                                           (isinstance(c, Conv1x1) and c.kernel_size == (1, 1)))
+                      and c.in_channels % 32 == 0 and c.out_channels % 32 == 0 and c.groups == 1]
         for i, c in enumerate(self.convs):
             c._bank = (self, i)
         self._ptrs = None
@@ -395,11 +470,11 @@ class ConvFilterBank:
         self._flat = torch.empty(2 * sum(sizes), dtype=torch.bfloat16, device=dev)
         rows, off, blk, self._fwd, self._bwd = [], 0, 0, [], []
         for c, n in zip(self.convs, sizes):
-            co, ci = c.out_channels, c.in_channels
+            co, ci, k = c.out_channels, c.in_channels, c.kernel_size[0]
             f, b = self._flat[off:off + n], self._flat[off + n:off + 2 * n]
-            self._fwd.append(f.view(co, 3, 3, ci).permute(0, 3, 1, 2))          # (Cout, Cin, 3, 3), channels-last memory
-            self._bwd.append(b.view(ci, 3, 3, co).permute(0, 3, 1, 2))          # (Cin, Cout, 3, 3), taps flipped
-            rows.append([c.weight.data_ptr(), f.data_ptr(), b.data_ptr(), co, ci, *c.weight.stride(), blk])
+            self._fwd.append(f.view(co, k, k, ci).permute(0, 3, 1, 2))          # (Cout, Cin, k, k), channels-last memory
+            self._bwd.append(b.view(ci, k, k, co).permute(0, 3, 1, 2))          # (Cin, Cout, k, k), taps flipped
+            rows.append([c.weight.data_ptr(), f.data_ptr(), b.data_ptr(), co, ci, *c.weight.stride(), blk, k * k])
             off, blk = off + 2 * n, blk + (co // 32) * (ci // 32)
         self._desc = torch.tensor(rows, dtype=torch.int64).to(dev)
         self._blocks = blk

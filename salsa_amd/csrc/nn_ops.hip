@@ -493,27 +493,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
 // that was four small kernels per layer per step (cast, permute copy, flip, permute copy: 68 launches, ~0.5 ms); here ONE
 // launch does all layers.  A block = one layer's 32 x 32 (co, ci) tile with its nine taps: the 32 x 288 floats go through LDS
 // (row pitch 289: both read patterns below are bank-conflict-free) and leave as 64-byte runs in either layout.
-// desc: 10 x int64 per layer = src, fwd, bwd pointers, Cout, Cin, element strides of src (co, ci, ky, kx), first block.
+// desc: 11 x int64 per layer = src, fwd, bwd pointers, Cout, Cin, element strides of src (co, ci, ky, kx), first block, taps
+// (9, or 1 for the 1x1 shortcut filters: forward [Cout][Cin], data-gradient [Cin][Cout]).
 __global__ __launch_bounds__(256) void conv_filter_bank_kernel(const long long *__restrict__ desc, int n_layers)
 {
     __shared__ float tile[32][289];
     int l = 0;
-    while (l + 1 < n_layers && (long long)blockIdx.x >= desc[(l + 1) * 10 + 9]) l++;
-    const long long *d = desc + l * 10;
+    while (l + 1 < n_layers && (long long)blockIdx.x >= desc[(l + 1) * 11 + 9]) l++;
+    const long long *d = desc + l * 11;
     const float *src = (const float *)d[0];
     __hip_bfloat16 *fwd = (__hip_bfloat16 *)d[1], *bwd = (__hip_bfloat16 *)d[2];
-    const int Cout = (int)d[3], Cin = (int)d[4];
+    const int Cout = (int)d[3], Cin = (int)d[4], taps = (int)d[10], rw = 32 * taps; // taps = 9 or 1
     const long s_co = d[5], s_ci = d[6], s_ky = d[7], s_kx = d[8];
     const int t = (int)(blockIdx.x - d[9]), tiles_ci = Cin / 32, co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
-        const int co = e / 288, r = e % 288, ci = r / 9, tap = r % 9;
+    for (int e = threadIdx.x; e < 32 * rw; e += 256) {
+        const int co = e / rw, r = e % rw, ci = r / taps, tap = r % taps;
         tile[co][r] = src[(co0 + co) * s_co + (ci0 + ci) * s_ci + (tap / 3) * s_ky + (tap % 3) * s_kx];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
-        const int a = e % 32, tap = (e / 32) % 9, b = e / 288;
-        fwd[((long)(co0 + b) * 9 + tap) * Cin + ci0 + a] = __float2bfloat16(tile[b][a * 9 + tap]);        // (co = b, ci = a)
-        if (bwd) bwd[((long)(ci0 + b) * 9 + (8 - tap)) * Cout + co0 + a] = __float2bfloat16(tile[a][b * 9 + tap]); // (ci = b, co = a)
+    for (int e = threadIdx.x; e < 32 * rw; e += 256) {
+        const int a = e % 32, tap = (e / 32) % taps, b = e / rw;
+        fwd[((long)(co0 + b) * taps + tap) * Cin + ci0 + a] = __float2bfloat16(tile[b][a * taps + tap]);        // (co = b, ci = a)
+        if (bwd) bwd[((long)(ci0 + b) * taps + (taps - 1 - tap)) * Cout + co0 + a] = __float2bfloat16(tile[a][b * taps + tap]); // (ci = b, co = a)
     }
 }
 
@@ -721,8 +722,8 @@ int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dty
 }
 
 /* bf16 copies of all hand-written convolution layers' float32 filters in ONE launch: the forward layout [Cout][3][3][Cin] and
- * (when bwd != 0) the data-gradient layout [Cin][3][3][Cout] with the taps flipped.  desc (device): n_layers x 10 int64 =
- * {src, fwd, bwd, Cout, Cin, src element strides co / ci / ky / kx, first block}; layer l owns (Cout/32)*(Cin/32) blocks from
+ * (when bwd != 0) the data-gradient layout [Cin][3][3][Cout] with the taps flipped.  desc (device): n_layers x 11 int64 =
+ * {src, fwd, bwd, Cout, Cin, src element strides co / ci / ky / kx, first block, taps (9 | 1)}; layer l owns (Cout/32)*(Cin/32) blocks from
  * its first block on; n_blocks = their total.  Cout and Cin must be multiples of 32. */
 int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void *hip_stream)
 {

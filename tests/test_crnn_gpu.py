@@ -546,10 +546,11 @@ def test_conv_filter_bank_matches_torch_casts_and_tracks_weight_updates():
     """ConvFilterBank (salsa_nn_conv_filter_bank: one launch for all layers) against what it replaces -- torch's per-layer
     ``weight.to(bf16).contiguous(channels_last)`` and ``.flip(2, 3).transpose(0, 1).contiguous(channels_last)`` -- bit for
     bit, for contiguous and channels-last master weights; an in-place weight update is picked up at the next request."""
-    from salsa_amd.crnn.nn_ops import Conv3x3, ConvFilterBank
+    from salsa_amd.crnn.nn_ops import Conv1x1, Conv3x3, ConvFilterBank
     dev = torch.device('cuda:0')
     torch.manual_seed(4)
-    convs = [Conv3x3(ci, co, 3, padding=1, bias=False).to(dev) for ci, co in ((64, 64), (64, 128), (128, 96), (256, 512), (512, 512))]
+    convs = [Conv3x3(ci, co, 3, padding=1, bias=False).to(dev) for ci, co in ((64, 64), (64, 128), (128, 96), (256, 512))]
+    convs.append(Conv1x1(128, 256, 1, bias=False).to(dev))                                      # a shortcut's 1x1 filter
     convs[2].weight.data = convs[2].weight.data.contiguous(memory_format=torch.channels_last)   # another stride pattern
     extra = Conv3x3(7, 64, 3, padding=1, bias=False).to(dev)                                     # not bankable (Cin % 32)
     bank = ConvFilterBank(convs + [extra])
@@ -628,3 +629,32 @@ def test_batchnorm_statistics_survive_a_large_mean():
     torch.testing.assert_close(fus.running_mean.double(), 0.1 * mean64, rtol=1e-6, atol=0)
     y64 = (x64 - mean64[None, :, None, None]) / torch.sqrt(var64 + fus.eps)[None, :, None, None]
     torch.testing.assert_close(ya.double(), y64, rtol=1e-3, atol=1e-3)
+
+
+def test_conv1x1_kernels_match_torch_forward_and_gradients():
+    """Conv1x1 (salsa_amd/csrc/conv_1x1.hip: the residual shortcuts' forward, data gradient and weight gradient) against
+    float32 F.conv2d on the same bf16-valued inputs; pixel counts that are not multiples of the 128- / 64-pixel tiles; with
+    and without the model's filter bank."""
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import Conv1x1, ConvFilterBank, _Conv1x1
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(21)
+    for (cin, cout), (n, h, w), banked in (((64, 128), (3, 20, 13), False), ((128, 256), (2, 9, 7), True), ((256, 512), (4, 40, 12), True),
+                                           ((64, 128), (1, 1, 1), False)):
+        conv = Conv1x1(cin, cout, kernel_size=1, bias=False).to(dev)
+        if banked:
+            ConvFilterBank([conv])
+        x = torch.randn((n, cin, h, w), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        xa, xb = x.clone().requires_grad_(True), x.float().clone().requires_grad_(True)
+        wb = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            ya = conv(xa)
+        assert isinstance(ya.grad_fn, _Conv1x1._backward_cls) and ya.dtype == torch.bfloat16
+        yb = F.conv2d(xb, wb)
+        torch.testing.assert_close(ya.float(), yb, rtol=2.0 ** -7, atol=2e-3 * float(yb.abs().max()))
+        gy = torch.randn(ya.shape, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ya.backward(gy)
+        yb.backward(gy.float())
+        torch.testing.assert_close(xa.grad.float(), xb.grad, rtol=2.0 ** -7, atol=2e-3 * float(xb.grad.abs().max()))
+        assert conv.weight.grad.dtype == torch.float32
+        torch.testing.assert_close(conv.weight.grad, wb.grad, rtol=1e-3, atol=1e-3 * float(wb.grad.abs().max()))
