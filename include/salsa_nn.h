@@ -73,6 +73,10 @@ int64_t salsa_nn_conv3x3_wide_tile_count(int64_t N, int H, int W);
 int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos_host, int *inv_host, int *tile_bounds_host);
 int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, const int *d_tile_bounds,
                               int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
+/* weight gradient of the (Cin <= 7) -> 64 first layer: dw float32 [64 co][Cin][3][3] contiguous += sum_pixels dy[p][co] *
+ * x[ci][p + tap] (zero it first); x float32 planar as in salsa_nn_conv3x3_stem, dy bf16 channels-last [N][H][W][64] */
+int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *dy, float *dw, int64_t N,
+                              int Cin, int H, int W, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

@@ -25,10 +25,10 @@ def conv_backend_note() -> str:
     if not USE_HIP_CONV:
         return 'all on MIOpen through torch (SALSA_HIP_CONV=0)'
     if USE_HIP_CONV_WIDE:
-        wrw = ('every 64..512-channel 3x3 layer hand-written (the 7->64 first layer: MIOpen)' if os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
+        wrw = ('every 3x3 layer hand-written' if os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
                else '64->64 hand-written, the rest MIOpen')
         return ('every 3x3 layer forward + data gradient on hand-written MFMA kernels (stem 7->64 and 64->64: conv_mfma.hip; 128/256/512 '
-                'channels: conv_wide.hip); weight gradients: %s; 1x1 shortcuts MIOpen' % wrw)
+                'channels: conv_wide.hip); weight gradients: %s; 1x1 shortcuts: conv_1x1.hip (MIOpen: nothing)' % wrw)
     return 'stem 7->64 and the five 64->64 3x3 layers on the hand-written MFMA kernels (conv_mfma.hip), the 128/256/512-channel layers on MIOpen through torch'
 
 
@@ -350,8 +350,12 @@ def _conv_stem(x, wq, shift=None, relu=False):
     return y
 
 
+USE_HIP_STEM_WRW = os.environ.get('SALSA_HIP_STEM_WRW', '1') != '0'
+
+
 class _Conv3x3Stem(torch.autograd.Function):
-    """The first layer (7 -> 64) on the stem kernel; its weight gradient (the input needs none) stays with MIOpen."""
+    """The first layer (7 -> 64) on the stem kernels: forward, and the weight gradient straight from the float32 planar input
+    (salsa_nn_conv3x3_stem_wrw; 8 input channels: MIOpen).  The input needs no gradient."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -364,7 +368,15 @@ class _Conv3x3Stem(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             raise RuntimeError('the stem convolution does not differentiate its input')
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and USE_HIP_STEM_WRW and x.shape[1] <= 7:
+            N, Cin, H, W = x.shape
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            gw = torch.zeros((64, Cin, 3, 3), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = _lib.load().salsa_nn_conv3x3_stem_wrw(_ptr(x), x.stride(0), x.stride(1), _ptr(gy), _ptr(gw), N, Cin, H, W, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_conv3x3_stem_wrw failed (%d)' % rc)
+        elif ctx.needs_input_grad[1]:
             xb = x.to(dtype=torch.bfloat16, memory_format=torch.channels_last)   # cast + layout in one pass
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             gw = torch.ops.aten.convolution_backward(gy.contiguous(memory_format=torch.channels_last), xb, wb, None, [1, 1], [1, 1],

@@ -793,3 +793,129 @@ extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw
                        (const unsigned short *)dy, dw, (int)N, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
+
+// ------------------------------------------------------------------------------------------ weight gradient, first layer
+// dW[co][ci][tap] = sum_p dy[p][co] * x[ci][p + tap] for the (Cin <= 7) -> 64 first layer: the same pixel-reduction GEMM as
+// above with N = Cin*9 <= 63 columns (one 64-column block, column c = ci*9 + tap; column 63 multiplies a zero plane).  The A
+// operand (dy^T) comes from the pixel-major dy tile through transposing LDS reads exactly as in the 64 -> 64 kernel.  The B
+// operand needs, per lane, 8 consecutive pixels of ONE (ci, tap) -- and x is float32 PLANAR (the extractor's layout: no bf16
+// channels-last copy of the input is made for this kernel), so consecutive pixels ARE consecutive floats: the tile's halo is
+// converted to bf16 once and stored in LDS as three column-shifted copies per (ci, halo row), which makes every fragment one
+// aligned 16-byte read.  33.5 GFLOP against 0.64 GB of input: HBM-bound; a wave owns one 32 x 32 block of dW.
+namespace {
+
+constexpr int SW_XROW = 40;                               // bf16 per (ci, halo row, shift) row: 32 + pad (80-byte pitch)
+constexpr int SW_XS = 8 * WHALO_H * 3 * SW_XROW;          // 8 channel planes (those >= Cin stay zero)
+constexpr int SW_XPF = (7 * WHALO_H * WHALO_W + 255) / 256; // float32 halo elements per thread
+
+template <int KS>
+__device__ __forceinline__ void stem_wrw_steps(f32x16 &acc, const unsigned ga, const unsigned xa)
+{
+    if constexpr (KS < 8) {
+        constexpr int rr = KS >> 1, hw = KS & 1;
+        tr_frag fa;
+        bf16x8 b;
+        LDS_TR_ISSUE(fa, ga, 2 * ((rr * WT_W + 16 * hw) * ROW));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(xa), "n"(2 * (rr * 3 * SW_XROW + 16 * hw)));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa.lo), "+v"(fa.hi), "+v"(b));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa), b, acc, 0, 0, 0);
+        stem_wrw_steps<KS + 1>(acc, ga, xa);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
+                                                               const unsigned short *__restrict__ dy, float *__restrict__ dw,
+                                                               int N, int Cin, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xs[SW_XS];
+    __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int mb = wv & 1, nb = wv >> 1; // this wave: co 32*mb.., columns 32*nb..
+    const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
+    const unsigned a_lane = 2u * (unsigned)((8 * kh + (i16 >> 2)) * ROW + 32 * mb + 16 * cb + 4 * (i16 & 3));
+    const int c = 32 * nb + (lane & 31), ci = c / 9, tap = c - 9 * ci; // column 63: ci = 7, a zero plane (Cin <= 7)
+    const unsigned b_lane = 2u * (unsigned)(((ci * WHALO_H + tap / 3) * 3 + tap % 3) * SW_XROW + 8 * kh);
+    const unsigned ga = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)gl + a_lane;
+    const unsigned xa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xs + b_lane;
+    for (int i = tid; i < SW_XS / 8; i += 256) ((uint4 *)xs)[i] = make_uint4(0u, 0u, 0u, 0u);
+    f32x16 acc = f32x16{};
+    const int tiles_w = (W + WT_W - 1) / WT_W, tiles_h = (H + WT_H - 1) / WT_H;
+    const long n_tiles = (long)N * tiles_h * tiles_w;
+    constexpr int GP = WT_H * WT_W * 8 / 256;
+    const int n_x = Cin * WHALO_H * WHALO_W;
+    float px_[SW_XPF];
+    uint4 pg_[GP];
+    auto fetch = [&](long tile) {
+        const int tw = (int)(tile % tiles_w);
+        const int th = (int)((tile / tiles_w) % tiles_h);
+        const long n = tile / ((long)tiles_w * tiles_h);
+        const int h0 = th * WT_H, w0 = tw * WT_W;
+#pragma unroll
+        for (int j = 0; j < SW_XPF; j++) {
+            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), r = i - cc * (WHALO_H * WHALO_W);
+            const int hh = r / WHALO_W, ww = r - hh * WHALO_W;
+            const int h = h0 + hh - 1, wc = w0 + ww - 1;
+            px_[j] = 0.f;
+            if (i < n_x && h >= 0 && h < H && wc >= 0 && wc < W) px_[j] = x[n * xbs + cc * xcs + (long)h * W + wc];
+        }
+#pragma unroll
+        for (int j = 0; j < GP; j++) {
+            const int i = tid + j * 256, piece = i & 7, p = i >> 3;
+            const int hh = p / WT_W, ww = p - hh * WT_W;
+            const int h = h0 + hh, wc = w0 + ww;
+            pg_[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (h < H && wc < W) pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
+        }
+    };
+    long tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads(); // the previous tile's LDS reads (and, the first time, the zero fill) are done
+#pragma unroll
+        for (int j = 0; j < SW_XPF; j++) {
+            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), r = i - cc * (WHALO_H * WHALO_W);
+            const int hh = r / WHALO_W, ww = r - hh * WHALO_W;
+            if (i < n_x) {
+                const unsigned short bits = (unsigned short)(pack_bf16(px_[j], 0.f) & 0xffffu); // round to nearest even
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) { // copy kx holds halo columns kx .. kx + 31 at positions 0 .. 31
+                    const int col = ww - kx;
+                    if (col >= 0 && col < WT_W) xs[((cc * WHALO_H + hh) * 3 + kx) * SW_XROW + col] = bits;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GP; j++) {
+            const int i = tid + j * 256;
+            *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = pg_[j];
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
+        stem_wrw_steps<0>(acc, ga, xa);
+    }
+    // D[m = co][n = column]: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (c < Cin * 9 && (long)blockIdx.x < n_tiles) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            atomicAdd(dw + co * (Cin * 9) + c, acc[reg]);
+        }
+    }
+}
+
+} // namespace
+
+// dw: float32 [64 co][Cin][3][3] contiguous, ADDED to (zero it first); x float32 planar [N][Cin <= 7][H][W] (strides in elements,
+// rows contiguous), dy bf16 channels-last [N][H][W][64]
+extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *dy, float *dw,
+                                         int64_t N, int Cin, int H, int W, void *hip_stream)
+{
+    if (!x || !dy || !dw || N <= 0 || Cin <= 0 || Cin > 7 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        return -1;
+    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles); // persistent, five per CU (30 KB of LDS each)
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
+                       (long)x_channel_stride, (const unsigned short *)dy, dw, (int)N, Cin, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}

@@ -320,7 +320,8 @@ def test_stem_conv_kernel_matches_torch():
         y.backward(gy)
         wref = conv.weight.detach().clone().requires_grad_(True)
         F.conv2d(xr, wref.to(torch.bfloat16).float(), padding=1).backward(gy.float())
-        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=2e-2, atol=2e-2 * float(wref.grad.abs().max()))
+        wtol = 2e-3 if cin <= 7 else 2e-2          # own kernel (float32 accumulation of the same bf16 operands) | MIOpen
+        torch.testing.assert_close(conv.weight.grad, wref.grad, rtol=wtol, atol=wtol * float(wref.grad.abs().max()))
         bn.eval(); conv.eval()
         with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
             fused = nn_ops.conv_bn_act(conv, bn, x)
