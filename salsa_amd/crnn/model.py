@@ -60,10 +60,11 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         y = avg_pool2x2(x) if self.stride == 2 else x
-        out = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p)   # dropout(relu(bn1(conv1(y)))), training only
-        if self.short_conv is not None:
-            x = self.short_bn(conv1x1(self.short_conv, y))
-        return conv_bn_act(self.conv2, self.bn2, out, residual=x)          # relu(bn2(conv2(out)) + shortcut)
+        # dropout(relu(bn1(conv1(y)))), training only; ys is y for the shortcut branch (in training routed through conv1's
+        # autograd node: the branch's gradient is added inside conv1's data-gradient kernel, not by a separate pass)
+        out, ys = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p, skip=True)
+        sc = self.short_bn(conv1x1(self.short_conv, ys)) if self.short_conv is not None else ys
+        return conv_bn_act(self.conv2, self.bn2, out, residual=sc)          # relu(bn2(conv2(out)) + shortcut)
 
 
 class Encoder(nn.Module):

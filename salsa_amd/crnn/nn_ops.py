@@ -200,12 +200,28 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         return y
 
 
-def _conv64(x, w):
-    """salsa_nn_conv3x3_c64: x (N,64,H,W) bf16 channels-last, w (64,64,3,3) bf16 channels-last -> (N,64,H,W)."""
+_ZERO_SHIFT = {}
+
+
+def _zero_shift(n, device):
+    """n float32 zeros on `device` (the `shift` operand of the convolution epilogues when only the residual add is wanted)"""
+    key = (n, device)
+    if key not in _ZERO_SHIFT:
+        _ZERO_SHIFT[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZERO_SHIFT[key]
+
+
+def _conv64(x, w, add=None):
+    """salsa_nn_conv3x3_c64: x (N,64,H,W) bf16 channels-last, w (64,64,3,3) bf16 channels-last -> (N,64,H,W); ``add`` (same
+    shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding."""
     N, _, H, W = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = _lib.load().salsa_nn_conv3x3_c64(_ptr(x), _ptr(w), _ptr(y), N, H, W, _stream(x))
+        if add is None:
+            rc = _lib.load().salsa_nn_conv3x3_c64(_ptr(x), _ptr(w), _ptr(y), N, H, W, _stream(x))
+        else:
+            rc = _lib.load().salsa_nn_conv3x3_c64_bias_act(_ptr(x), _ptr(w), _ptr(_zero_shift(64, x.device)), _ptr(add), _ptr(y), 0,
+                                                           N, H, W, _stream(x))
     if rc:
         raise RuntimeError('salsa_nn_conv3x3_c64 failed (%d)' % rc)
     return y
@@ -216,37 +232,48 @@ class _Conv3x3C64(torch.autograd.Function):
     kernel with the flipped / transposed filter) and weight gradient (float32, straight into the float32 parameter's grad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, wb=None, wbt=None):
-        # wb / wbt: the bf16 filter and its flipped / transposed twin from the model's ConvFilterBank, when there is one
+    def forward(ctx, x, weight, wb=None, wbt=None, skip=False):
+        # wb / wbt: the bf16 filter and its flipped / transposed twin from the model's ConvFilterBank, when there is one.
+        # skip: also return x itself (an alias) for the residual branch, so that the branch's gradient comes back INTO this
+        # node and is added in the data-gradient kernel's epilogue instead of by a separate autograd add over the tensor
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ctx.save_for_backward(x, wb, wbt)
-        return _conv64(x, wb)
+        return (_conv64(x, wb), x) if skip else _conv64(x, wb)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, wb, wbt = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv64(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+            if gskip is not None:
+                gskip = gskip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gx = _conv64(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last),
+                         add=gskip)
         if ctx.needs_input_grad[1]:
             N, _, H, W = x.shape
-            gw = torch.zeros((64, 64, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+            # (Cout, Cin, 3, 3) with channels-last memory, zeroed in place: zeros(...).contiguous(channels_last) is a fill + a copy
+            gw = torch.zeros((64, 3, 3, 64), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
             with torch.cuda.device(x.device):
                 rc = _lib.load().salsa_nn_conv3x3_c64_wrw(_ptr(x), _ptr(gy), _ptr(gw), N, H, W, _stream(x))
             if rc:
                 raise RuntimeError('salsa_nn_conv3x3_c64_wrw failed (%d)' % rc)
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
-def _conv_wide(x, w):
-    """salsa_nn_conv3x3_wide: x (N,Cin,H,W) bf16 channels-last, w (Cout,Cin,3,3) bf16 channels-last -> (N,Cout,H,W)."""
+def _conv_wide(x, w, add=None):
+    """salsa_nn_conv3x3_wide: x (N,Cin,H,W) bf16 channels-last, w (Cout,Cin,3,3) bf16 channels-last -> (N,Cout,H,W); ``add``
+    (the output's shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding."""
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = _lib.load().salsa_nn_conv3x3_wide(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, _stream(x))
+        if add is None:
+            rc = _lib.load().salsa_nn_conv3x3_wide(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, _stream(x))
+        else:
+            rc = _lib.load().salsa_nn_conv3x3_wide_bias_act(_ptr(x), _ptr(w), _ptr(_zero_shift(Cout, x.device)), _ptr(add), _ptr(y), 0,
+                                                            N, H, W, Cin, Cout, _stream(x))
     if rc:
         raise RuntimeError('salsa_nn_conv3x3_wide failed (%d)' % rc)
     return y
@@ -278,7 +305,7 @@ def _conv_wide_wrw(x, gy):
     N, Cin, H, W = x.shape
     Cout = gy.shape[1]
     vpos, inv, tb = _wide_tables(N, H, W, x.device)
-    gw = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    gw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)   # channels-last memory
     with torch.cuda.device(x.device):
         rc = _lib.load().salsa_nn_conv3x3_wide_wrw(_ptr(x), _ptr(gy), _ptr(gw), _ptr(vpos), _ptr(inv), _ptr(tb), N, H, W, Cin, Cout,
                                                    _stream(x))
@@ -293,14 +320,14 @@ class _Conv3x3Wide(torch.autograd.Function):
     gradient (transposing LDS reads, float32 result); shapes a kernel does not take fall back to torch / MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, wb=None, wbt=None):
+    def forward(ctx, x, weight, wb=None, wbt=None, skip=False):
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ctx.save_for_backward(x, wb, wbt)
-        return _conv_wide(x, wb)
+        return (_conv_wide(x, wb), x) if skip else _conv_wide(x, wb)       # (skip: see _Conv3x3C64)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, wb, wbt = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
@@ -308,7 +335,10 @@ class _Conv3x3Wide(torch.autograd.Function):
         # the data gradient is a Cout -> Cin convolution: the kernel takes it when Cin is a multiple of 64 (always in the CRNN)
         own_dgrad = ctx.needs_input_grad[0] and bool(_lib.load().salsa_nn_conv3x3_wide_supported(N, H, W, wb.shape[0], Cin))
         if own_dgrad:
-            gx = _conv_wide(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+            if gskip is not None:
+                gskip = gskip.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gx = _conv_wide(gy, wbt if wbt is not None else wb.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last),
+                            add=gskip)
         own_wrw = (ctx.needs_input_grad[1] and USE_HIP_CONV_WIDE_WRW
                    and bool(_lib.load().salsa_nn_conv3x3_wide_wrw_supported(N, H, W, Cin, wb.shape[0])))
         if own_wrw:
@@ -318,7 +348,9 @@ class _Conv3x3Wide(torch.autograd.Function):
             r = torch.ops.aten.convolution_backward(gy, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             gx = r[0] if need[0] else gx
             gw = r[1].float() if need[1] else gw
-        return gx, gw, None, None
+            if need[0] and gskip is not None:
+                gx = gx + gskip
+        return gx, gw, None, None, None
 
 
 def _planar_rows(x):
@@ -458,14 +490,28 @@ class Conv1x1(torch.nn.Conv2d):
 
 USE_FILTER_BANK = os.environ.get('SALSA_FILTER_BANK', '1') != '0'
 
+# Cached derivatives of parameters (the filter bank, the folded inference filters) must notice every parameter update.  The
+# tensors' version counters are NOT enough: the fused optimizers (torch.optim.Adam(fused=True), which the trainer uses) update
+# parameters in place without bumping them.  A global optimizer hook counts the steps of ANY optimizer; the caches compare
+# this epoch (and the version counters, for updates made without an optimizer, and the storage pointers).
+_PARAM_EPOCH = [0]
+
+
+def _bump_param_epoch(*_):
+    _PARAM_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+_register_step_hook(_bump_param_epoch)
+
 
 class ConvFilterBank:
     """bf16 working copies of the hand-written 3x3 convolutions' float32 master filters -- the forward kernels' channels-last
     layout and the data-gradient kernels' flipped / transposed one -- produced for ALL layers by one launch
     (salsa_nn_conv_filter_bank) instead of four small torch kernels per layer per step (autocast's cast, the channels-last
     copy, flip, transpose copy).  A layer asking for its filters compares its weight's version counter (every in-place update,
-    e.g. the optimizer step, bumps it) with the one recorded at the last refresh; the first stale layer refreshes the whole
-    bank.  The views handed out alias the bank: a refresh between a forward and its backward (a weight modified in place
+    bumps it) and the global count of optimizer steps (``_PARAM_EPOCH``: fused optimizers do not bump version counters) with
+    the ones recorded at the last refresh; the first stale layer refreshes the whole bank.  The views handed out alias the bank: a refresh between a forward and its backward (a weight modified in place
     mid-graph, which autograd itself rejects) would change what that backward reads."""
 
     def __init__(self, convs):
@@ -474,7 +520,7 @@ class ConvFilterBank:
                       and c.in_channels % 32 == 0 and c.out_channels % 32 == 0 and c.groups == 1]
         for i, c in enumerate(self.convs):
             c._bank = (self, i)
-        self._ptrs = None
+        self._ptrs, self._epoch = None, -1
 
     def _build(self):
         dev = self.convs[0].weight.device
@@ -502,11 +548,13 @@ class ConvFilterBank:
         if rc:
             raise RuntimeError('salsa_nn_conv_filter_bank failed (%d)' % rc)
         self._versions = [c.weight._version for c in self.convs]
+        self._epoch = _PARAM_EPOCH[0]
 
     def filters(self, i):
         """(forward filter, data-gradient filter) of layer i as bf16 channels-last views, refreshed if its weight changed."""
         w = self.convs[i].weight
-        if self._ptrs is None or self._versions[i] != w._version or self._ptrs[i] != w.data_ptr():
+        if (self._ptrs is None or self._epoch != _PARAM_EPOCH[0] or self._versions[i] != w._version
+                or self._ptrs[i] != w.data_ptr()):
             self.refresh()
         return self._fwd[i], self._bwd[i]
 
@@ -518,6 +566,9 @@ def _bank_filters(conv):
     if bank is None or not USE_FILTER_BANK or not w.is_cuda or w.dtype != torch.float32:
         return None, None
     return bank[0].filters(bank[1])
+
+
+USE_FUSED_SKIP = os.environ.get('SALSA_FUSED_SKIP', '1') != '0'
 
 
 class Conv3x3(torch.nn.Conv2d):
@@ -547,6 +598,16 @@ class Conv3x3(torch.nn.Conv2d):
                 and self.groups == 1 and not (self.in_channels == 64 and self.out_channels == 64)
                 and _lib.load().salsa_nn_conv3x3_wide_supported(x.shape[0], x.shape[2], x.shape[3], self.in_channels,
                                                                 self.out_channels))
+
+    def forward_skip(self, x):
+        """(conv(x), x'): x' is x routed through the convolution's autograd node, for a residual / shortcut branch that forks
+        off x -- the branch's gradient is then added inside the data-gradient kernel (training, MFMA kernels only; otherwise
+        x' is x and autograd adds as usual)."""
+        if USE_FUSED_SKIP and torch.is_grad_enabled() and x.requires_grad and (self._hip_eligible(x) or self._wide_eligible(x)):
+            fn = _Conv3x3C64 if self._hip_eligible(x) else _Conv3x3Wide
+            with torch.autocast('cuda', enabled=False):
+                return fn.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight, *_bank_filters(self), True)
+        return self.forward(x), x
 
     def forward(self, x):
         if self._hip_eligible(x):
@@ -582,11 +643,12 @@ def conv1x1(conv, x):
 def _folded(conv, bn, stem=False):
     """(filter, shift) of an eval-mode conv + BatchNorm pair folded for the kernels' epilogue: filter = w * gamma / sigma in
     bf16 (channels-last, or the stem kernel's layout), shift = beta - mean * gamma / sigma in float32.  Cached on the conv
-    module and keyed on the version counters of the five tensors involved (an optimizer step, load_state_dict or a training
-    forward bumps them), so repeated inference calls do not re-run the seven small kernels per layer."""
+    module and keyed on the version counters of the five tensors involved, the global optimizer-step count (fused optimizers
+    do not bump version counters) and the BatchNorm's statistics serial, so repeated inference calls do not re-run the seven
+    small kernels per layer."""
     srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     # (_stats_serial: the fused training kernels update the running statistics through raw pointers, invisible to torch's counters)
-    key = tuple((t.data_ptr(), t._version) for t in srcs) + (float(bn.eps), stem, getattr(bn, '_stats_serial', 0))
+    key = tuple((t.data_ptr(), t._version) for t in srcs) + (float(bn.eps), stem, getattr(bn, '_stats_serial', 0), _PARAM_EPOCH[0])
     hit = getattr(conv, '_fold_cache', None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
@@ -601,7 +663,18 @@ def _folded(conv, bn, stem=False):
     return wf, shift
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
+def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False, skip=False):
+    """``_conv_bn_act`` below; with ``skip=True`` returns (result, x'): x' is x for a branch that forks off x (residual,
+    shortcut) -- in training on the MFMA kernels routed through the convolution's autograd node (Conv3x3.forward_skip)."""
+    if not skip:
+        return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool)
+    if isinstance(conv, Conv3x3) and bn.training and torch.is_grad_enabled() and not pool:
+        c, xs = conv.forward_skip(x)
+        return bn(c, residual=residual, relu=relu, dropout_p=dropout_p), xs
+    return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool), x
+
+
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
     """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
     residual add and the ReLU -- before its single rounding: the normalised activation never makes a round trip to HBM.

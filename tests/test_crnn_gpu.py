@@ -575,6 +575,15 @@ def test_conv_filter_bank_matches_torch_casts_and_tracks_weight_updates():
     check()
     convs[1].weight.data = torch.randn_like(convs[1].weight)              # re-allocated parameter storage
     check()
+    # a FUSED optimizer updates the parameters in place WITHOUT bumping their version counters (torch 2.10): the bank must
+    # notice through the global optimizer-step hook -- left stale, the convolutions would train on their initial weights
+    opt = torch.optim.Adam([c.weight for c in convs], lr=0.05, fused=True)
+    for c in convs:
+        c.weight.grad = torch.randn_like(c.weight)
+    before = [c.weight.detach().clone() for c in convs]
+    opt.step()
+    assert all(not torch.equal(b, c.weight) for b, c in zip(before, convs))
+    check()
 
 
 def test_folded_filter_cache_follows_parameter_and_statistics_updates():
@@ -610,6 +619,11 @@ def test_folded_filter_cache_follows_parameter_and_statistics_updates():
     assert conv._fold_cache[1] is not first
     with torch.no_grad():
         conv.weight.mul_(0.5)
+    torch.testing.assert_close(fused_eval(), reference(), **tol)
+    opt = torch.optim.Adam(list(conv.parameters()) + list(bn.parameters()), lr=0.2, fused=True)   # no version bumps (see the bank test)
+    for p_ in list(conv.parameters()) + list(bn.parameters()):
+        p_.grad = torch.randn_like(p_)
+    opt.step()
     torch.testing.assert_close(fused_eval(), reference(), **tol)
 
 
@@ -660,3 +674,26 @@ def test_conv1x1_kernels_match_torch_forward_and_gradients():
         torch.testing.assert_close(xa.grad.float(), xb.grad, rtol=2.0 ** -7, atol=2e-3 * float(xb.grad.abs().max()))
         assert conv.weight.grad.dtype == torch.float32
         torch.testing.assert_close(conv.weight.grad, wb.grad, rtol=1e-3, atol=1e-3 * float(wb.grad.abs().max()))
+
+
+def test_training_trajectory_with_cached_filters_matches_uncached():
+    """End-to-end guard for everything that caches a function of the parameters (ConvFilterBank, the 1x1 kernels' filters):
+    30 fused-Adam steps on a fixed batch with the caches on must follow the same loss curve as with them off.  (A bank that
+    misses the fused optimizer's updates -- they do not bump version counters -- still passes every per-kernel test while the
+    convolutions silently keep their initial weights; the loss at step 30 then lags by 12 %.)"""
+    from salsa_amd.crnn import nn_ops
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+    x, sed, doa = synthetic_batch(8, 'cuda:0', seed=1)
+    losses = {}
+    saved = nn_ops.USE_FILTER_BANK
+    try:
+        for bank in (True, False):
+            nn_ops.USE_FILTER_BANK = bank
+            torch.manual_seed(0)
+            tr = Trainer('cuda:0')
+            for _ in range(30):
+                loss = tr.train_step(x, sed, doa)[0]
+            losses[bank] = float(loss)
+    finally:
+        nn_ops.USE_FILTER_BANK = saved
+    assert losses[True] < 1.08 and abs(losses[True] - losses[False]) < 0.03 * losses[False], losses
