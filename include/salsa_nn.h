@@ -73,6 +73,11 @@ int64_t salsa_nn_conv3x3_wide_tile_count(int64_t N, int H, int W);
 int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos_host, int *inv_host, int *tile_bounds_host);
 int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, const int *d_tile_bounds,
                               int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
+/* Training forward of the 64 -> 64 layer that ALSO leaves the per-channel sum and sum of squares of its (bf16-rounded) output as
+ * per-workgroup float64 rows stats_part[salsa_nn_conv3x3_c64_stats_blocks(N, H, W)][2][64], accumulated in its epilogue: the
+ * BatchNorm that follows (salsa_nn_bn_train_fwd / _pool: stats_part, stats_blocks) then makes no statistics pass over y. */
+int salsa_nn_conv3x3_c64_stats_blocks(int64_t N, int H, int W);
+int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y, double *stats_part, int64_t N, int H, int W, void *hip_stream);
 /* weight gradient of the (Cin <= 7) -> 64 first layer: dw float32 [64 co][Cin][3][3] contiguous += sum_pixels dy[p][co] *
  * x[ci][p + tap] (zero it first); x float32 planar as in salsa_nn_conv3x3_stem, dy bf16 channels-last [N][H][W][64] */
 int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *dy, float *dw, int64_t N,
@@ -89,6 +94,9 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                           float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
                           int64_t *batches_tracked /* nn.BatchNorm2d.num_batches_tracked (device), += 1; may be NULL */,
+                          const double *stats_part, int stats_blocks /* per-workgroup [2][C] float64 sum / sum-of-squares rows left
+                          by the convolution that produced x (salsa_nn_conv3x3_c64_stats): the statistics pass over x is
+                          skipped; NULL / 0: the call computes them itself */,
                           void *hip_stream);
 int salsa_nn_bn_eval_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                          const float *beta, const float *mean, const float *invstd, int relu, void *hip_stream);
@@ -102,7 +110,8 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
  * one rounding); the full-resolution activation is never written.  Backward from the POOLED gradient, ReLU mask recomputed from x. */
 int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked, void *hip_stream);
+                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+                               const double *stats_part, int stats_blocks, void *hip_stream);
 int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                          const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
                          double *sums_ws, float *coef_ws, void *hip_stream);

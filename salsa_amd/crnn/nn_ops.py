@@ -74,7 +74,8 @@ class _BnAct(torch.autograd.Function):
     """y = [dropout]( [relu]( batch_norm(x) [+ residual] ) ) in training mode (salsa_nn_bn_train_fwd / salsa_nn_bn_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, drop_p=0.0, batches_tracked=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, drop_p=0.0, batches_tracked=None,
+                stats_part=None):
         N, Cn, H, W = x.shape
         M = N * H * W
         y = torch.empty_like(x, memory_format=torch.channels_last)
@@ -86,7 +87,8 @@ class _BnAct(torch.autograd.Function):
             rc = _lib.load().salsa_nn_bn_train_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight),
                                                    _ptr(bias), float(eps), float(momentum), _ptr(running_mean),
                                                    _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu),
-                                                   float(drop_p), seed, _ptr(batches_tracked), _stream(x))
+                                                   float(drop_p), seed, _ptr(batches_tracked), _ptr(stats_part),
+                                                   0 if stats_part is None else stats_part.numel() // (2 * Cn), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
         # the ReLU mask comes from y only when something was added before the ReLU; otherwise the backward recomputes it from x
@@ -110,7 +112,7 @@ class _BnAct(torch.autograd.Function):
                                              _ptr(dwb[1]), _ptr(ws), _ptr(coef), ctx.drop[0], ctx.drop[1], _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, dres, None, None, None, None, None, None
 
 
 class _BnReluPool(torch.autograd.Function):
@@ -118,7 +120,7 @@ class _BnReluPool(torch.autograd.Function):
     tail; the full-resolution activation is neither written in the forward nor its gradient in the backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None, stats_part=None):
         N, Cn, H, W = x.shape
         y = torch.empty((N, Cn, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
@@ -126,7 +128,8 @@ class _BnReluPool(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
                                                         float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
-                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _stream(x))
+                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _ptr(stats_part),
+                                                        0 if stats_part is None else stats_part.numel() // (2 * Cn), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd_pool failed (%d)' % rc)
         ctx.save_for_backward(x, weight, bias, save)
@@ -147,7 +150,7 @@ class _BnReluPool(torch.autograd.Function):
                                                   _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd_pool failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None, None
 
 
 USE_HIP_BN_POOL = os.environ.get('SALSA_HIP_BN_POOL', '1') != '0'
@@ -159,17 +162,18 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
     dropout_p=0.0)``.  Channels-last CUDA bf16 / float32 inputs run the fused HIP kernels; anything else runs torch's
     batch_norm + add + relu + dropout.  ``relu_pool(x)`` = avg_pool2x2(relu(bn(x))), one kernel pass in training."""
 
-    def relu_pool(self, x):
+    def relu_pool(self, x, stats_part=None):
+        """stats_part: per-workgroup [2][C] float64 partial sums of x left by the convolution that produced it (training)"""
         if (USE_HIP_BN and USE_HIP_BN_POOL and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
                 and self.track_running_stats and self.momentum is not None and x.shape[2] >= 2 and x.shape[3] >= 2
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
             self._stats_serial = getattr(self, '_stats_serial', 0) + 1
             return _BnReluPool.apply(x, self.weight.float(), self.bias.float(), self.running_mean, self.running_var, self.momentum,
-                                     self.eps, self.num_batches_tracked)   # (the kernel counts the batch: no add_ launch)
+                                     self.eps, self.num_batches_tracked, stats_part)   # (the kernel counts the batch: no add_ launch)
         return avg_pool2x2(self.forward(x, relu=True))
 
-    def forward(self, x, residual=None, relu=False, dropout_p=0.0):
+    def forward(self, x, residual=None, relu=False, dropout_p=0.0, stats_part=None):
         if not self.training:
             dropout_p = 0.0
         fused = (USE_HIP_BN and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine and self.track_running_stats
@@ -188,7 +192,7 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         if self.training:
             self._stats_serial = getattr(self, '_stats_serial', 0) + 1
             return _BnAct.apply(x, w, b, self.running_mean, self.running_var, residual, self.momentum, self.eps, relu, float(dropout_p),
-                                self.num_batches_tracked)                  # (the kernel counts the batch: no add_ launch)
+                                self.num_batches_tracked, stats_part)      # (the kernel counts the batch: no add_ launch)
         N, Cn, H, W = x.shape
         y = torch.empty_like(x, memory_format=torch.channels_last)
         invstd = torch.rsqrt(self.running_var + self.eps)
@@ -211,13 +215,16 @@ def _zero_shift(n, device):
     return _ZERO_SHIFT[key]
 
 
-def _conv64(x, w, add=None):
+def _conv64(x, w, add=None, stats_part=None):
     """salsa_nn_conv3x3_c64: x (N,64,H,W) bf16 channels-last, w (64,64,3,3) bf16 channels-last -> (N,64,H,W); ``add`` (same
-    shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding."""
+    shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding; ``stats_part`` (float64,
+    salsa_nn_conv3x3_c64_stats_blocks x 128) receives the output's per-channel partial sums for the BatchNorm that follows."""
     N, _, H, W = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        if add is None:
+        if stats_part is not None:
+            rc = _lib.load().salsa_nn_conv3x3_c64_stats(_ptr(x), _ptr(w), _ptr(y), _ptr(stats_part), N, H, W, _stream(x))
+        elif add is None:
             rc = _lib.load().salsa_nn_conv3x3_c64(_ptr(x), _ptr(w), _ptr(y), N, H, W, _stream(x))
         else:
             rc = _lib.load().salsa_nn_conv3x3_c64_bias_act(_ptr(x), _ptr(w), _ptr(_zero_shift(64, x.device)), _ptr(add), _ptr(y), 0,
@@ -232,14 +239,16 @@ class _Conv3x3C64(torch.autograd.Function):
     kernel with the flipped / transposed filter) and weight gradient (float32, straight into the float32 parameter's grad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, wb=None, wbt=None, skip=False):
+    def forward(ctx, x, weight, wb=None, wbt=None, skip=False, stats_part=None):
         # wb / wbt: the bf16 filter and its flipped / transposed twin from the model's ConvFilterBank, when there is one.
+        # stats_part: a float64 buffer the kernel fills with its output's per-channel partial sums (not differentiated).
         # skip: also return x itself (an alias) for the residual branch, so that the branch's gradient comes back INTO this
         # node and is added in the data-gradient kernel's epilogue instead of by a separate autograd add over the tensor
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ctx.save_for_backward(x, wb, wbt)
-        return (_conv64(x, wb), x) if skip else _conv64(x, wb)
+        y = _conv64(x, wb, stats_part=stats_part)
+        return (y, x) if skip else y
 
     @staticmethod
     def backward(ctx, gy, gskip=None):
@@ -259,7 +268,7 @@ class _Conv3x3C64(torch.autograd.Function):
                 rc = _lib.load().salsa_nn_conv3x3_c64_wrw(_ptr(x), _ptr(gy), _ptr(gw), N, H, W, _stream(x))
             if rc:
                 raise RuntimeError('salsa_nn_conv3x3_c64_wrw failed (%d)' % rc)
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 def _conv_wide(x, w, add=None):
@@ -569,6 +578,7 @@ def _bank_filters(conv):
 
 
 USE_FUSED_SKIP = os.environ.get('SALSA_FUSED_SKIP', '1') != '0'
+USE_CONV_STATS = os.environ.get('SALSA_CONV_STATS', '1') != '0'   # BatchNorm statistics from the 64 -> 64 convolution's epilogue
 
 
 class Conv3x3(torch.nn.Conv2d):
@@ -599,21 +609,31 @@ class Conv3x3(torch.nn.Conv2d):
                 and _lib.load().salsa_nn_conv3x3_wide_supported(x.shape[0], x.shape[2], x.shape[3], self.in_channels,
                                                                 self.out_channels))
 
-    def forward_skip(self, x):
+    def stats_buffer(self, x):
+        """A float64 buffer for the output's per-channel partial sums when this call will run the 64 -> 64 MFMA kernel in
+        training (salsa_nn_conv3x3_c64_stats), else None: pass it to forward / forward_skip and on to the BatchNorm."""
+        if not (USE_CONV_STATS and torch.is_grad_enabled() and self._hip_eligible(x)):
+            return None
+        nb = _lib.load().salsa_nn_conv3x3_c64_stats_blocks(x.shape[0], x.shape[2], x.shape[3])
+        return torch.empty(nb * 128, dtype=torch.float64, device=x.device) if nb > 0 else None
+
+    def forward_skip(self, x, stats_part=None):
         """(conv(x), x'): x' is x routed through the convolution's autograd node, for a residual / shortcut branch that forks
         off x -- the branch's gradient is then added inside the data-gradient kernel (training, MFMA kernels only; otherwise
         x' is x and autograd adds as usual)."""
         if USE_FUSED_SKIP and torch.is_grad_enabled() and x.requires_grad and (self._hip_eligible(x) or self._wide_eligible(x)):
-            fn = _Conv3x3C64 if self._hip_eligible(x) else _Conv3x3Wide
             with torch.autocast('cuda', enabled=False):
-                return fn.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight, *_bank_filters(self), True)
-        return self.forward(x), x
+                xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                if self._hip_eligible(x):
+                    return _Conv3x3C64.apply(xb, self.weight, *_bank_filters(self), True, stats_part)
+                return _Conv3x3Wide.apply(xb, self.weight, *_bank_filters(self), True)
+        return self.forward(x, stats_part), x
 
-    def forward(self, x):
+    def forward(self, x, stats_part=None):
         if self._hip_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3C64.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
-                                         *_bank_filters(self))
+                                         *_bank_filters(self), False, stats_part)
         if self._wide_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3Wide.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
@@ -669,8 +689,10 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
     if not skip:
         return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool)
     if isinstance(conv, Conv3x3) and bn.training and torch.is_grad_enabled() and not pool:
-        c, xs = conv.forward_skip(x)
-        return bn(c, residual=residual, relu=relu, dropout_p=dropout_p), xs
+        part = conv.stats_buffer(x) if isinstance(bn, BatchNormAct2d) else None
+        c, xs = conv.forward_skip(x, part)
+        return (bn(c, residual=residual, relu=relu, dropout_p=dropout_p, stats_part=part) if part is not None
+                else bn(c, residual=residual, relu=relu, dropout_p=dropout_p)), xs
     return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool), x
 
 
@@ -716,7 +738,11 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
         wq, shift = _folded(conv, bn, stem=True)
         y = _conv_stem(x, wq, shift, relu)
         return avg_pool2x2(y) if pool else y
+    part = (conv.stats_buffer(x) if isinstance(conv, Conv3x3) and isinstance(bn, BatchNormAct2d) and bn.training else None)
     if pool and relu and residual is None and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d):
-        return bn.relu_pool(conv(x))
-    y = bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)
+        return bn.relu_pool(conv(x, part), part) if part is not None else bn.relu_pool(conv(x))
+    if part is not None:
+        y = bn(conv(x, part), residual=residual, relu=relu, dropout_p=dropout_p, stats_part=part)
+    else:
+        y = bn(conv(x), residual=residual, relu=relu, dropout_p=dropout_p)
     return avg_pool2x2(y) if pool else y

@@ -113,6 +113,52 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
     }
 }
 
+// Training: per-channel sum and sum of squares of the tile's bf16-ROUNDED outputs (what the BatchNorm that follows would read
+// back from HBM in its own statistics pass).  A lane holds 16 channels x 2 rows of ONE pixel column.  No LDS in the tile loop
+// -- LDS float atomics, even pre-reduced to 4-way conflicts, DOUBLED the kernel (0.45 -> 0.96 ms at 32 x 640 x 200) -- and no
+// 32 running sums per lane either (the filter owns the register file): two DPP swaps sum each quad of neighbouring pixel
+// columns, after which all four lanes of the quad hold the same 16 totals, and lane q of the quad keeps the running sums of
+// channel group q only: 8 registers.  The quads are combined once, after the last tile.
+__device__ __forceinline__ float dpp_xor1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void conv64_stats(const f32x16 (&acc)[RPW], float (&rs)[4], float (&rq)[4], int th, int tw, int H, int W,
+                                             int px, int rg)
+{
+    const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
+    float m[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) m[rr] = (h0 + rr < H && wcol < W) ? 1.f : 0.f;
+    const int quad = px & 3;
+#pragma unroll
+    for (int g = 0; g < 4; g++) { // accumulator elements 4 g .. 4 g + 3 = channels 8 g + j (+ the lane's base); 8 temporaries live
+        float t[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++) {
+                const unsigned u = pack_bf16(acc[rr][4 * g + 2 * k], acc[rr][4 * g + 2 * k + 1]);
+                const float r0 = __uint_as_float(u << 16), r1 = __uint_as_float(u & 0xffff0000u);
+                const float a0 = r0 * m[rr], a1 = r1 * m[rr];
+                t[2 * k] += a0; t[2 * k + 1] += a1;
+                q[2 * k] = fmaf(a0, r0, q[2 * k]); q[2 * k + 1] = fmaf(a1, r1, q[2 * k + 1]);
+            }
+        const float keep = quad == g ? 1.f : 0.f; // lane `quad` of each quad keeps channel group g = quad
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[j] += dpp_xor1(t[j]); q[j] += dpp_xor1(q[j]);
+            t[j] += dpp_xor2(t[j]); q[j] += dpp_xor2(q[j]);
+            rs[j] = fmaf(keep, t[j], rs[j]);
+            rq[j] = fmaf(keep, q[j], rq[j]);
+        }
+    }
+}
+
 // The WHOLE filter lives in registers (72 A fragments per lane: a wave per SIMD may use all 512 VGPR+AGPR), so LDS only
 // serves the input tile: one 16-byte B read per two MFMAs.  The next tile's halo is prefetched into registers while the
 // current tile is multiplied.
@@ -121,7 +167,8 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
                                                               const unsigned short *__restrict__ w,
                                                               unsigned short *__restrict__ y, int N, int H, int W,
                                                               const float *__restrict__ shift,
-                                                              const unsigned short *__restrict__ residual, int relu)
+                                                              const unsigned short *__restrict__ residual, int relu,
+                                                              double *__restrict__ /* statistics: the LDS-direct kernel only */)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xl[HALO_H * HALO_W * ROW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -313,15 +360,19 @@ __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&
     }
 }
 
-template <bool POOL>
+template <bool POOL, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const unsigned short *__restrict__ x,
                                                                        const unsigned short *__restrict__ w,
                                                                        unsigned short *__restrict__ y, int N, int H, int W,
                                                                        const float *__restrict__ shift,
-                                                                       const unsigned short *__restrict__ residual, int relu)
+                                                                       const unsigned short *__restrict__ residual, int relu,
+                                                                       double *__restrict__ stats_part)
 {
     static_assert(RPW == 2, "row sharing below is written for two rows per wave");
+    static_assert(!(POOL && STATS), "statistics are a training feature, the fused pool an inference one");
     __shared__ __attribute__((aligned(16))) unsigned short xl[NBUF * ABUF];
+    __shared__ float lstats[STATS ? 2 * 128 : 1]; // [row-group wave][sum | sum of squares][64 channels], used once after the last tile
+    float rs[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f}; // STATS: this lane's running sums (conv64_stats)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = lane & 31, khalf = lane >> 5, kh = khalf * 8;
     const int mb = wv & 1, rg = wv >> 1;
@@ -333,7 +384,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     float4 shv[4]; // the lane's 16 folded-BatchNorm shifts (inference), loaded once: ordinary loads inside the tile loop would
                    // make the compiler drain every load in flight, the next tiles' included
 #pragma unroll
-    for (int g = 0; g < 4; g++) shv[g] = shift ? *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 4; g++)
+        shv[g] = (!STATS && shift) ? *(const float4 *)(shift + 32 * mb + 4 * (lane >> 5) + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+
     // the filter has landed BEFORE the tile loop: left to its first use, the compiler's wait for these ordinary loads sits in
     // front of the loop's first MFMA as vmcnt(0) and drains the LDS-direct loads in flight with it, every tile
 #pragma unroll
@@ -442,9 +495,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        conv64_epilogue<POOL>(acc, y, shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
+        conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
+        if (STATS) conv64_stats(acc, rs, rq, th, tw, H, W, px, rg);
     }
 #undef WAIT_ALL_BUT_LAST_FETCH
+    if (STATS) { // this workgroup's partial sums: [2][64] float64, row blockIdx.x of the BatchNorm kernels' partial table
+        // the 8 quads of a half-wave hold the same channel groups: three butterfly steps over pixel columns +4, +8, +16 (once per
+        // launch; LDS atomics here cost 16 us of a 110-us launch), then the two row-group waves of a channel half meet in LDS
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int d = 4; d <= 16; d <<= 1) {
+                rs[j] += __shfl_xor(rs[j], d);
+                rq[j] += __shfl_xor(rq[j], d);
+            }
+        if (px < 4) {
+            const int cbase = rg * 128 + 32 * mb + 4 * khalf + 8 * px;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lstats[cbase + j] = rs[j];
+                lstats[cbase + 64 + j] = rq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) stats_part[(long)blockIdx.x * 128 + tid] = (double)lstats[tid] + (double)lstats[128 + tid];
+    }
 }
 
 #ifndef CONV_ASYNC
@@ -469,7 +544,31 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
     const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
-                       (const unsigned short *)nullptr, 0);
+                       (const unsigned short *)nullptr, 0, (double *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* number of partial rows ([2][64] float64 each) salsa_nn_conv3x3_c64_stats writes = its workgroup count */
+extern "C" int salsa_nn_conv3x3_c64_stats_blocks(int64_t N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH || !CONV_ASYNC) return 0;
+    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (int)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
+}
+
+// training: the plain convolution, which also leaves the per-channel sum / sum of squares of its (bf16-rounded) output as
+// per-workgroup float64 partial rows stats_part[blocks][2][64] -- the BatchNorm that follows then needs no statistics pass
+// over the tensor (salsa_nn_bn_train_fwd's stats_part / stats_blocks)
+extern "C" int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y, double *stats_part, int64_t N, int H, int W,
+                                          void *hip_stream)
+{
+    if (!x || !w || !y || !stats_part || x == y || !salsa_nn_conv3x3_c64_stats_blocks(N, H, W)) return -1;
+    const unsigned nb = (unsigned)salsa_nn_conv3x3_c64_stats_blocks(N, H, W);
+#if CONV_ASYNC
+    hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
+                       (const unsigned short *)nullptr, 0, stats_part);
+#endif
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -481,7 +580,8 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu,
+                       (double *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -495,7 +595,8 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, 
     const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu,
+                       (double *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

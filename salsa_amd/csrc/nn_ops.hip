@@ -606,16 +606,22 @@ size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
 int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                           float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
-                          int64_t *batches_tracked, void *hip_stream)
+                          int64_t *batches_tracked, const double *stats_part, int stats_blocks, void *hip_stream)
 {
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C) || drop_p < 0.f ||
         drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32))
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
-    double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
-    NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
+    const double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
+    int nparts = (int)nblk;
+    if (stats_part && stats_blocks > 0) { // the producing convolution already left them (salsa_nn_conv3x3_c64_stats)
+        part = stats_part;
+        nparts = stats_blocks;
+    } else {
+        NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, sums_ws + 2 * C);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nparts, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
               (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed));
@@ -678,16 +684,23 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
  * x [N][H][W][C] -> y [N][H/2][W/2][C]; statistics over all N*H*W rows like salsa_nn_bn_train_fwd. */
 int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked, void *hip_stream)
+                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+                               const double *stats_part, int stats_blocks, void *hip_stream)
 {
     const int64_t M = N * H * W;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
-    double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
-    NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, eps, momentum, save_mean,
+    const double *part = sums_ws + 2 * C; // [nblk][2][C] float64 partial sums
+    int nparts = (int)nblk;
+    if (stats_part && stats_blocks > 0) { // the producing convolution already left them (salsa_nn_conv3x3_c64_stats)
+        part = stats_part;
+        nparts = stats_blocks;
+    } else {
+        NN_LAUNCH(bn_stats_kernel, dim3(nblk), dim3(256), (const char *)x, (long)M, C, sums_ws + 2 * C);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nparts, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     const long n_vec = (long)N * (H / 2) * (W / 2) * (C / (dtype == 1 ? 8 : 4));
     NN_LAUNCH(bn_apply_pool_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), (const char *)x, (char *)y, n_vec, H, W, C,

@@ -697,3 +697,43 @@ def test_training_trajectory_with_cached_filters_matches_uncached():
     finally:
         nn_ops.USE_FILTER_BANK = saved
     assert losses[True] < 1.08 and abs(losses[True] - losses[False]) < 0.03 * losses[False], losses
+
+
+def test_conv_epilogue_statistics_feed_the_batchnorm():
+    """salsa_nn_conv3x3_c64_stats: the training forward of a 64 -> 64 layer leaves the per-channel sum / sum of squares of its
+    bf16-rounded output as per-workgroup partial rows; summed they must equal the sums of the stored tensor (ragged sizes:
+    tiles that hang over the image must not contribute), and conv -> BatchNorm(+ReLU)(+pool) fed from them must match the same
+    layers with BatchNorm's own statistics pass: outputs, running statistics, every gradient."""
+    from salsa_amd import _lib
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(31)
+    for n, h, w in ((2, 40, 70), (1, 9, 33), (3, 17, 5), (4, 320, 100)):
+        x = torch.randn((n, 64, h, w), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = (torch.randn((64, 64, 3, 3), device=dev, generator=g) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        nb = _lib.load().salsa_nn_conv3x3_c64_stats_blocks(n, h, w)
+        part = torch.full((nb * 128,), float('nan'), dtype=torch.float64, device=dev)
+        y = nn_ops._conv64(x, wb, stats_part=part)
+        assert torch.equal(y, nn_ops._conv64(x, wb))                       # the same output as the plain kernel
+        tot = part.view(nb, 2, 64).sum(0)
+        yf = y.double()
+        torch.testing.assert_close(tot[0], yf.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(tot[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    saved = nn_ops.USE_CONV_STATS
+    try:
+        for pool in (False, True):
+            res = {}
+            for use in (True, False):
+                nn_ops.USE_CONV_STATS = use
+                torch.manual_seed(3)
+                conv, bn = nn_ops.Conv3x3(64, 64, 3, padding=1, bias=False).to(dev), nn_ops.BatchNormAct2d(64).to(dev)
+                xx = torch.randn((3, 64, 24, 36), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = nn_ops.conv_bn_act(conv, bn, xx, pool=pool)
+                out.float().square().mean().backward()
+                res[use] = (out.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), xx.grad.float(),
+                            conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+            for a, b in zip(res[True], res[False]):
+                torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-6)
+    finally:
+        nn_ops.USE_CONV_STATS = saved
