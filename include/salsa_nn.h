@@ -82,6 +82,12 @@ int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y, double *st
  * x[ci][p + tap] (zero it first); x float32 planar as in salsa_nn_conv3x3_stem, dy bf16 channels-last [N][H][W][64] */
 int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *dy, float *dw, int64_t N,
                               int Cin, int H, int W, void *hip_stream);
+/* The same with the BatchNorm (+ ReLU) behind the first layer differentiated on the fly: g = gradient of the BatchNorm's OUTPUT,
+ * x1 = the BatchNorm's input (= the first layer's output), coef = the [7][64] table salsa_nn_bn_bwd leaves in coef_ws.  Call
+ * salsa_nn_bn_bwd with dx = NULL (it then only produces dgamma, dbeta and coef_ws): dx's only reader is this weight gradient,
+ * so the full-resolution dx is neither written nor read. */
+int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *g, const void *x1,
+                                 const float *coef, int relu, float *dw, int64_t N, int Cin, int H, int W, void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

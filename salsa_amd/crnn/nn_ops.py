@@ -497,6 +497,56 @@ class Conv1x1(torch.nn.Conv2d):
         return super().forward(x)
 
 
+USE_STEM_FUSED_BWD = os.environ.get('SALSA_STEM_FUSED_BWD', '1') != '0'
+
+
+class _StemConvBnRelu(torch.autograd.Function):
+    """relu(batch_norm(conv7x64(x))) of the network's first layer in training, as ONE autograd node, so that its backward can
+    skip the BatchNorm backward's apply pass: dx (the gradient of the convolution's output) has a single reader, this layer's
+    weight gradient, which forms it on the fly from (g, conv output, coefficients) while staging its tiles
+    (salsa_nn_conv3x3_stem_wrw_bn) -- the 524-MB dx is neither written nor read."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, bn_w, bn_b, running_mean, running_var, momentum, eps, batches_tracked):
+        L = _lib.load()
+        x1 = _conv_stem(x, _stem_filter(conv_w))
+        N, Cn, H, W = x1.shape
+        M = N * H * W
+        y = torch.empty_like(x1, memory_format=torch.channels_last)
+        save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.salsa_nn_bn_workspace_bytes(1, M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.salsa_nn_bn_train_fwd(_ptr(x1), _ptr(y), None, 1, M, Cn, _ptr(bn_w), _ptr(bn_b), float(eps), float(momentum),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), 1, 0.0, 0,
+                                         _ptr(batches_tracked), None, 0, _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
+        ctx.save_for_backward(x, x1, bn_w, bn_b, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, x1, bn_w, bn_b, save = ctx.saved_tensors
+        L = _lib.load()
+        N, Cn, H, W = x1.shape
+        M, Cin = N * H * W, x.shape[1]
+        g = g.contiguous(memory_format=torch.channels_last)
+        dwb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.salsa_nn_bn_workspace_bytes(1, M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
+        gw = torch.zeros((64, Cin, 3, 3), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.salsa_nn_bn_bwd(_ptr(g), None, _ptr(x1), None, None, 1, M, Cn, _ptr(bn_w), _ptr(bn_b), _ptr(save[0]), _ptr(save[1]),
+                                   1, _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef), 0.0, 0, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_bn_bwd (coefficients only) failed (%d)' % rc)
+            rc = L.salsa_nn_conv3x3_stem_wrw_bn(_ptr(x), x.stride(0), x.stride(1), _ptr(g), _ptr(x1), _ptr(coef), 1, _ptr(gw), N, Cin,
+                                                H, W, _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_conv3x3_stem_wrw_bn failed (%d)' % rc)
+        return None, gw, dwb[0], dwb[1], None, None, None, None, None
+
+
 USE_FILTER_BANK = os.environ.get('SALSA_FILTER_BANK', '1') != '0'
 
 # Cached derivatives of parameters (the filter bank, the folded inference filters) must notice every parameter update.  The
@@ -738,6 +788,14 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
         wq, shift = _folded(conv, bn, stem=True)
         y = _conv_stem(x, wq, shift, relu)
         return avg_pool2x2(y) if pool else y
+    if (USE_STEM_FUSED_BWD and USE_HIP_STEM_WRW and USE_HIP_BN and isinstance(conv, Conv3x3) and isinstance(bn, BatchNormAct2d)
+            and bn.training and torch.is_grad_enabled() and relu and residual is None and dropout_p == 0.0 and not pool
+            and conv._stem_eligible(x) and x.shape[1] <= 7 and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and conv.weight.requires_grad and _lib.load().salsa_nn_bn_supported(1, x.shape[0] * x.shape[2] * x.shape[3], 64)):
+        bn._stats_serial = getattr(bn, '_stats_serial', 0) + 1
+        with torch.autocast('cuda', enabled=False):
+            return _StemConvBnRelu.apply(x, conv.weight, bn.weight.float(), bn.bias.float(), bn.running_mean, bn.running_var,
+                                         bn.momentum, bn.eps, bn.num_batches_tracked)
     part = (conv.stats_buffer(x) if isinstance(conv, Conv3x3) and isinstance(bn, BatchNormAct2d) and bn.training else None)
     if pool and relu and residual is None and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d):
         return bn.relu_pool(conv(x, part), part) if part is not None else bn.relu_pool(conv(x))

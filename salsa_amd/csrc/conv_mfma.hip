@@ -924,12 +924,23 @@ __device__ __forceinline__ void stem_wrw_steps(f32x16 &acc, const unsigned ga, c
     }
 }
 
+// BN: dy is not the gradient of the convolution's output but of the BatchNorm (+ ReLU) output behind it, and x1 that
+// BatchNorm's input (= this convolution's output): the tile's dx = a (g masked - b - (x1 - mean) k) -- the BatchNorm backward's
+// apply pass, coefficients from salsa_nn_bn_bwd(dx = NULL) -- is formed while the tile goes into LDS, rounded to bf16 exactly
+// as the separate pass would have stored it.  This layer's weight gradient is dx's ONLY reader (the network input needs no
+// gradient), so the 524-MB dx is never written or read: 4 tensor passes become 2.
+template <bool BN>
 __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
                                                                const unsigned short *__restrict__ dy, float *__restrict__ dw,
-                                                               int N, int Cin, int H, int W)
+                                                               int N, int Cin, int H, int W,
+                                                               const unsigned short *__restrict__ x1, const float *__restrict__ coef,
+                                                               int relu)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xs[SW_XS];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
+    __shared__ float cf[BN ? 7 * CH : 1]; // a, b, mean, k, invstd, beta, gamma per channel (bn_bwd_finalize_kernel's table)
+    if (BN)
+        for (int i = threadIdx.x; i < 7 * CH; i += 256) cf[i] = coef[i];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mb = wv & 1, nb = wv >> 1; // this wave: co 32*mb.., columns 32*nb..
     const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
     constexpr int GP = WT_H * WT_W * 8 / 256;
     const int n_x = Cin * WHALO_H * WHALO_W;
     float px_[SW_XPF];
-    uint4 pg_[GP];
+    uint4 pg_[GP], pq_[BN ? GP : 1];
     auto fetch = [&](long tile) {
         const int tw = (int)(tile % tiles_w);
         const int th = (int)((tile / tiles_w) % tiles_h);
@@ -965,13 +976,31 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
             const int hh = p / WT_W, ww = p - hh * WT_W;
             const int h = h0 + hh, wc = w0 + ww;
             pg_[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (h < H && wc < W) pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
+            if (BN) pq_[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (h < H && wc < W) {
+                pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
+                if (BN) pq_[j] = *(const uint4 *)(x1 + (((n * H + h) * W + wc) * CH + piece * 8));
+            }
         }
+    };
+    // one bf16 pair of the tile: BatchNorm-backward apply on (g, x1) -> dx, rounded to bf16 (a pixel outside the image has
+    // g = x1 = 0 and would give -a (b - mean k): the caller zeroes those pieces instead)
+    auto bn_pair = [&](const unsigned g2, const unsigned q2, const int c) -> unsigned {
+        float r[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float g = __uint_as_float(e ? (g2 & 0xffff0000u) : (g2 << 16)), xv = __uint_as_float(e ? (q2 & 0xffff0000u) : (q2 << 16));
+            const int ch = c + e;
+            const float xc = xv - cf[2 * CH + ch];
+            const bool zero = relu && !((xc * cf[4 * CH + ch]) * cf[6 * CH + ch] + cf[5 * CH + ch] > 0.f);
+            r[e] = cf[ch] * ((zero ? 0.f : g) - cf[CH + ch] - xc * cf[3 * CH + ch]);
+        }
+        return pack_bf16(r[0], r[1]);
     };
     long tile = blockIdx.x;
     if (tile < n_tiles) fetch(tile);
     for (; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads(); // the previous tile's LDS reads (and, the first time, the zero fill) are done
+        __syncthreads(); // the previous tile's LDS reads (and, the first time, the zero fill and the coefficient table) are done
 #pragma unroll
         for (int j = 0; j < SW_XPF; j++) {
             const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), r = i - cc * (WHALO_H * WHALO_W);
@@ -988,7 +1017,17 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
 #pragma unroll
         for (int j = 0; j < GP; j++) {
             const int i = tid + j * 256;
-            *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = pg_[j];
+            uint4 v = pg_[j];
+            if (BN) {
+                const int tw = (int)(tile % tiles_w), th = (int)((tile / tiles_w) % tiles_h), p = i >> 3;
+                const bool inside = th * WT_H + p / WT_W < H && tw * WT_W + p % WT_W < W;
+                const int c = (i & 7) * 8;
+                v.x = inside ? bn_pair(pg_[j].x, pq_[j].x, c) : 0u;
+                v.y = inside ? bn_pair(pg_[j].y, pq_[j].y, c + 2) : 0u;
+                v.z = inside ? bn_pair(pg_[j].z, pq_[j].z, c + 4) : 0u;
+                v.w = inside ? bn_pair(pg_[j].w, pq_[j].w, c + 6) : 0u;
+            }
+            *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = v;
         }
         __syncthreads();
         if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
@@ -1016,7 +1055,25 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles); // persistent, five per CU (30 KB of LDS each)
-    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
-                       (long)x_channel_stride, (const unsigned short *)dy, dw, (int)N, Cin, H, W);
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
+                       (long)x_channel_stride, (const unsigned short *)dy, dw, (int)N, Cin, H, W, (const unsigned short *)nullptr,
+                       (const float *)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// The same with the BatchNorm (+ ReLU) that follows the first layer differentiated on the fly: g = gradient of the BatchNorm's
+// OUTPUT, x1 = its input (the first layer's output), both bf16 channels-last; coef = the [7][64] table salsa_nn_bn_bwd leaves in
+// coef_ws (call it with dx = NULL: it then skips its apply pass, whose only reader would have been this kernel).
+extern "C" int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *g,
+                                            const void *x1, const float *coef, int relu, float *dw, int64_t N, int Cin, int H, int W,
+                                            void *hip_stream)
+{
+    if (!x || !g || !x1 || !coef || !dw || N <= 0 || Cin <= 0 || Cin > 7 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        return -1;
+    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles);
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
+                       (long)x_channel_stride, (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, coef, relu);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

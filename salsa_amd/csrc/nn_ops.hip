@@ -645,7 +645,9 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
     const int mask_from_x = relu && !y_or_null;
     const DropArgs drop = drop_args(drop_p, drop_seed);
     if (drop_p < 0.f || drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32)) return -1;
-    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
+    // dx == NULL: only dgamma, dbeta and the coefficient table coef_ws[7][C] are produced, for a consumer that forms dx on the fly
+    // (salsa_nn_conv3x3_stem_wrw_bn: the first layer's weight gradient is dx's only reader)
+    if (!dy || !x || (!dx && dres_or_null) || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
         !bn_geometry_ok(dtype, M, C))
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
@@ -675,8 +677,9 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
 #undef BN_REDUCE
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
-    NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
-              (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x, drop);
+    if (dx)
+        NN_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)dy, (const char *)y_or_null,
+                  (const char *)x, (char *)dx, (char *)dres_or_null, (long)M, C, coef_ws, mask_from_x, drop);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

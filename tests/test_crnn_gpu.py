@@ -737,3 +737,35 @@ def test_conv_epilogue_statistics_feed_the_batchnorm():
                 torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-6)
     finally:
         nn_ops.USE_CONV_STATS = saved
+
+
+def test_first_layer_backward_without_the_batchnorm_apply_pass():
+    """_StemConvBnRelu: relu(bn(conv7->64(x))) as one autograd node whose backward hands (g, conv output, BatchNorm
+    coefficients) to the weight-gradient kernel instead of materialising the BatchNorm's input gradient
+    (salsa_nn_bn_bwd with dx = NULL + salsa_nn_conv3x3_stem_wrw_bn).  Must match the two-node path (conv -> BatchNormAct2d):
+    output, running statistics and the gradients of the filter, gamma and beta; ragged sizes."""
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    saved = nn_ops.USE_STEM_FUSED_BWD
+    try:
+        for n, cin, h, w in ((2, 7, 40, 70), (1, 7, 9, 33), (3, 4, 17, 5), (4, 7, 64, 200)):
+            res = {}
+            for fused in (True, False):
+                nn_ops.USE_STEM_FUSED_BWD = fused
+                torch.manual_seed(5)
+                conv, bn = nn_ops.Conv3x3(cin, 64, 3, padding=1, bias=False).to(dev), nn_ops.BatchNormAct2d(64).to(dev)
+                with torch.no_grad():
+                    bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+                x = torch.randn((n, cin, h, w), device=dev)
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = nn_ops.conv_bn_act(conv, bn, x)
+                assert isinstance(out.grad_fn, nn_ops._StemConvBnRelu._backward_cls) == fused
+                gy = torch.randn(out.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                out.backward(gy)
+                res[fused] = (out.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked),
+                              conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+            assert res[True][3] == res[False][3] == 1
+            for a, b in zip(res[True][:3] + res[True][4:], res[False][:3] + res[False][4:]):
+                torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-6)
+    finally:
+        nn_ops.USE_STEM_FUSED_BWD = saved
