@@ -111,16 +111,19 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
                     float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, float drop_p, uint32_t drop_seed,
                     void *hip_stream);
 
-/* BatchNorm (training statistics) + ReLU + the 2x2 average pool that follows them in the upstream stem (models/model_utils.py:
- * 187-228), one pass over x: x [N][H][W][C] -> y [N][H/2][W/2][C] (normalise + ReLU each of the four pixels, average in float32,
- * one rounding); the full-resolution activation is never written.  Backward from the POOLED gradient, ReLU mask recomputed from x. */
-int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
-                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+/* BatchNorm (training statistics) [+ residual] + ReLU + the 2x2 average pool that follows them -- in the upstream stem
+ * (models/model_utils.py:187-228) and, with the block's shortcut as `residual`, at the end of every residual block whose
+ * successor starts with the stride-2 pool (:312-367) -- one pass over x: x [N][H][W][C] -> y [N][H/2][W/2][C] (normalise, add,
+ * ReLU each of the four pixels, average in float32, one rounding); the full-resolution activation is never written.  Backward
+ * from the POOLED gradient: dx, and dres (the residual's gradient) when there was one; the ReLU mask is recomputed from x (and
+ * the residual), the same float32 operations in the same order as the forward. */
+int salsa_nn_bn_train_fwd_pool(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
+                               const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
                                const double *stats_part, int stats_blocks, void *hip_stream);
-int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
-                         const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
-                         double *sums_ws, float *coef_ws, void *hip_stream);
+int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, const void *residual, void *dx, void *dres, int dtype, int64_t N, int H,
+                         int W, int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                         float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream);
 
 /* The 1x1 / stride 1 convolutions of the residual shortcuts (models/model_utils.py:340-349) over the flattened pixel axis
  * (salsa_amd/csrc/conv_1x1.hip): x bf16 [M][Cin] (channels-last pixels, M = N*H*W), w bf16 [Cout][Cin], y bf16 [M][Cout];

@@ -92,9 +92,9 @@ def load():
     L.salsa_nn_bn_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int]
     L.salsa_nn_bn_train_fwd.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp,
                                         vp, C.c_int, C.c_float, C.c_uint32, vp, vp, C.c_int, vp]
-    L.salsa_nn_bn_train_fwd_pool.argtypes = [vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp,
+    L.salsa_nn_bn_train_fwd_pool.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp,
                                              vp, vp, vp, vp, vp, C.c_int, vp]
-    L.salsa_nn_bn_bwd_pool.argtypes = [vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.salsa_nn_bn_bwd_pool.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.salsa_nn_conv_filter_bank.argtypes = [vp, C.c_int, C.c_int, vp]
     L.salsa_nn_conv3x3_c64_stats_blocks.argtypes = [C.c_int64, C.c_int, C.c_int]
     L.salsa_nn_conv3x3_c64_stats.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]

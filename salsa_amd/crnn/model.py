@@ -51,6 +51,9 @@ class ResBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
         self.stride, self.dropout_p = stride, 0.1
+        # set by the Encoder: this block's output is only ever read by the NEXT block's stride-2 average pool, so the pool is
+        # taken here, fused into the last BatchNorm + add + ReLU (pool_out), and the next block skips its own (pre_pooled)
+        self.pool_out, self.pre_pooled = False, False
         self.conv1, self.bn1 = _conv(cin, cout, 3), BatchNormAct2d(cout)
         self.conv2, self.bn2 = _conv(cout, cout, 3), BatchNormAct2d(cout)
         nn.init.zeros_(self.bn2.weight)
@@ -59,12 +62,12 @@ class ResBlock(nn.Module):
             self.short_conv, self.short_bn = _conv(cin, cout, 1), BatchNormAct2d(cout)
 
     def forward(self, x):
-        y = avg_pool2x2(x) if self.stride == 2 else x
+        y = avg_pool2x2(x) if (self.stride == 2 and not self.pre_pooled) else x
         # dropout(relu(bn1(conv1(y)))), training only; ys is y for the shortcut branch (in training routed through conv1's
         # autograd node: the branch's gradient is added inside conv1's data-gradient kernel, not by a separate pass)
         out, ys = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p, skip=True)
         sc = self.short_bn(conv1x1(self.short_conv, ys)) if self.short_conv is not None else ys
-        return conv_bn_act(self.conv2, self.bn2, out, residual=sc)          # relu(bn2(conv2(out)) + shortcut)
+        return conv_bn_act(self.conv2, self.bn2, out, residual=sc, pool=self.pool_out)   # relu(bn2(conv2(out)) + shortcut) [-> pool]
 
 
 class Encoder(nn.Module):
@@ -80,6 +83,9 @@ class Encoder(nn.Module):
         for cout, stride in ((64, 1), (128, 2), (256, 2), (512, 2)):
             blocks += [ResBlock(cin, cout, stride), ResBlock(cout, cout, 1)]
             cin = cout
+        for prev, nxt in zip(blocks[:-1], blocks[1:]):
+            if nxt.stride == 2:
+                prev.pool_out, nxt.pre_pooled = True, True
         self.stages = nn.Sequential(*blocks)
         # one kernel per step makes the bf16 working copies of all 3x3 filters (not a module, parameter or buffer: no state)
         self._filter_bank = ConvFilterBank([m for m in self.modules() if isinstance(m, (Conv3x3, Conv1x1))])

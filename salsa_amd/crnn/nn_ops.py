@@ -120,40 +120,43 @@ class _BnReluPool(torch.autograd.Function):
     tail; the full-resolution activation is neither written in the forward nor its gradient in the backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None, stats_part=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None, stats_part=None, residual=None):
         N, Cn, H, W = x.shape
         y = torch.empty((N, Cn, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
+            rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
                                                         float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
                                                         _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _ptr(stats_part),
                                                         0 if stats_part is None else stats_part.numel() // (2 * Cn), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd_pool failed (%d)' % rc)
-        ctx.save_for_backward(x, weight, bias, save)
+        ctx.save_for_backward(x, weight, bias, save, residual)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias, save = ctx.saved_tensors
+        x, weight, bias, save, residual = ctx.saved_tensors
         N, Cn, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if residual is not None else None
         dwb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
         coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_bn_bwd_pool(_ptr(gy), _ptr(x), _ptr(dx), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
+            rc = _lib.load().salsa_nn_bn_bwd_pool(_ptr(gy), _ptr(x), _ptr(residual), _ptr(dx), _ptr(dres), _DT[x.dtype][0], N, H, W, Cn,
+                                                  _ptr(weight), _ptr(bias),
                                                   _ptr(save[0]), _ptr(save[1]), _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef),
                                                   _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd_pool failed (%d)' % rc)
-        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None, None
+        return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None, None, dres
 
 
 USE_HIP_BN_POOL = os.environ.get('SALSA_HIP_BN_POOL', '1') != '0'
+USE_HIP_BN_RES_POOL = os.environ.get('SALSA_HIP_BN_RES_POOL', '1') != '0'   # ... with a residual: the blocks before a stride-2 block
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
@@ -162,16 +165,19 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
     dropout_p=0.0)``.  Channels-last CUDA bf16 / float32 inputs run the fused HIP kernels; anything else runs torch's
     batch_norm + add + relu + dropout.  ``relu_pool(x)`` = avg_pool2x2(relu(bn(x))), one kernel pass in training."""
 
-    def relu_pool(self, x, stats_part=None):
-        """stats_part: per-workgroup [2][C] float64 partial sums of x left by the convolution that produced it (training)"""
+    def relu_pool(self, x, stats_part=None, residual=None):
+        """avg_pool2x2(relu(bn(x) [+ residual])).  stats_part: per-workgroup [2][C] float64 partial sums of x left by the
+        convolution that produced it (training)"""
         if (USE_HIP_BN and USE_HIP_BN_POOL and self.training and x.is_cuda and x.dim() == 4 and x.dtype in _DT and self.affine
                 and self.track_running_stats and self.momentum is not None and x.shape[2] >= 2 and x.shape[3] >= 2
                 and x.is_contiguous(memory_format=torch.channels_last)
+                and (residual is None or (residual.dtype == x.dtype and residual.shape == x.shape
+                                          and residual.is_contiguous(memory_format=torch.channels_last)))
                 and _lib.load().salsa_nn_bn_supported(_DT[x.dtype][0], x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
             self._stats_serial = getattr(self, '_stats_serial', 0) + 1
             return _BnReluPool.apply(x, self.weight.float(), self.bias.float(), self.running_mean, self.running_var, self.momentum,
-                                     self.eps, self.num_batches_tracked, stats_part)   # (the kernel counts the batch: no add_ launch)
-        return avg_pool2x2(self.forward(x, relu=True))
+                                     self.eps, self.num_batches_tracked, stats_part, residual)   # (the kernel counts the batch)
+        return avg_pool2x2(self.forward(x, residual=residual, relu=True))
 
     def forward(self, x, residual=None, relu=False, dropout_p=0.0, stats_part=None):
         if not self.training:
@@ -797,8 +803,8 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
             return _StemConvBnRelu.apply(x, conv.weight, bn.weight.float(), bn.bias.float(), bn.running_mean, bn.running_var,
                                          bn.momentum, bn.eps, bn.num_batches_tracked)
     part = (conv.stats_buffer(x) if isinstance(conv, Conv3x3) and isinstance(bn, BatchNormAct2d) and bn.training else None)
-    if pool and relu and residual is None and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d):
-        return bn.relu_pool(conv(x, part), part) if part is not None else bn.relu_pool(conv(x))
+    if pool and relu and dropout_p == 0.0 and isinstance(bn, BatchNormAct2d) and (residual is None or USE_HIP_BN_RES_POOL):
+        return (bn.relu_pool(conv(x, part), part, residual) if part is not None else bn.relu_pool(conv(x), None, residual))
     if part is not None:
         y = bn(conv(x, part), residual=residual, relu=relu, dropout_p=dropout_p, stats_part=part)
     else:

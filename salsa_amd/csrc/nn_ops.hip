@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
 template <typename V, int L>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const char *__restrict__ x, char *__restrict__ y, long n_vec, int H, int W,
                                                             int C, const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                            const float *__restrict__ gamma, const float *__restrict__ beta)
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const char *__restrict__ res /* like x, added before the ReLU; or NULL */)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_vec) return;
@@ -329,12 +330,20 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const char *__restri
     vec_io<V, L>::load(p + (long)cv * 16, v[1]);
     vec_io<V, L>::load(p + (long)W * cv * 16, v[2]);
     vec_io<V, L>::load(p + ((long)W * cv + cv) * 16, v[3]);
+    float rv[4][L];
+    if (res) {
+        const char *q = res + (p - x);
+        vec_io<V, L>::load(q, rv[0]);
+        vec_io<V, L>::load(q + (long)cv * 16, rv[1]);
+        vec_io<V, L>::load(q + (long)W * cv * 16, rv[2]);
+        vec_io<V, L>::load(q + ((long)W * cv + cv) * 16, rv[3]);
+    }
 #pragma unroll
     for (int k = 0; k < L; k++) {
         const float mu = mean[c * L + k], is = invstd[c * L + k], ga = gamma[c * L + k], be = beta[c * L + k];
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc += fmaxf(((v[q][k] - mu) * is) * ga + be, 0.f);
+        for (int q = 0; q < 4; q++) acc += fmaxf(((v[q][k] - mu) * is) * ga + be + (res ? rv[q][k] : 0.f), 0.f); // (same order as the backward's mask)
         o[k] = acc * 0.25f;
     }
     vec_io<V, L>::store(y + i * 16, o);
@@ -357,8 +366,9 @@ __device__ __forceinline__ void pooled_grad(const char *__restrict__ gp, long r,
 }
 
 // g = dy * (y > 0) ; sums[0][C] += sum g (= dbeta) ; sums[1][C] += sum g * xhat (= dgamma)
-// MASK: 0 no ReLU, 1 ReLU mask from the stored output y, 2 recomputed from x; DROP: fused dropout (compile-time, so the
-// element loop has no branches)
+// MASK: 0 no ReLU, 1 ReLU mask from the stored output y, 2 recomputed from x, 3 recomputed from x and the residual that was
+// added (passed in y's place: the fused-pool layers store no full-resolution output); DROP: fused dropout (compile-time, so
+// the element loop has no branches)
 template <typename V, int L, int MASK, bool DROP, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                             const char *__restrict__ x, long M, int C,
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                 if (POOL) pooled_grad<V, L>(dy, ok[u] ? r : M - 1, cv, cx, PH, PW, g[u]); // dy = the pooled gradient
                 else vec_io<V, L>::load(dy + vec[u] * 16, g[u]);
                 vec_io<V, L>::load(x + vec[u] * 16, xv[u]);
-                if (MASK == 1) vec_io<V, L>::load(y + vec[u] * 16, yv[u]);
+                if (MASK == 1 || MASK == 3) vec_io<V, L>::load(y + vec[u] * 16, yv[u]); // (MASK 3: y is the RESIDUAL that was added)
             }
 #pragma unroll
             for (int u = 0; u < BN_BATCH; u++) {
@@ -407,6 +417,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                     bool live = ok[u];
                     if (MASK == 1) live = live && yv[u][k] > 0.f;
                     if (MASK == 2) live = live && xh * ga[k] + be[k] > 0.f;
+                    if (MASK == 3) live = live && xh * ga[k] + be[k] + yv[u][k] > 0.f;
                     if (DROP && MASK != 1) live = live && keep[k];
                     const float gk = live ? (DROP ? g[u][k] * drop.scale : g[u][k]) : 0.f;
                     db[k] += gk;
@@ -477,14 +488,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         if (y) vec_io<V, L>::load(y + off, yv);
         if (drop.thresh) {
             bool keep[L];
-            if (!y) drop_keep<L>((r * cv + cx) * L, drop, keep);
+            if (!y || mask_from_x == 2) drop_keep<L>((r * cv + cx) * L, drop, keep);
 #pragma unroll
-            for (int k = 0; k < L; k++) g[k] = (y || keep[k]) ? g[k] * drop.scale : 0.f;
+            for (int k = 0; k < L; k++) g[k] = ((y && mask_from_x != 2) || keep[k]) ? g[k] * drop.scale : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < L; k++) {
             const float xc = xv[k] - mu[k];
-            const bool zero = y ? !(yv[k] > 0.f) : (mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f));
+            const bool zero = mask_from_x == 2 ? !((xc * is[k]) * ga[k] + be[k] + yv[k] > 0.f) // y = the residual that was added
+                                               : y ? !(yv[k] > 0.f) : (mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f));
             if (zero) g[k] = 0.f;
             xv[k] = a[k] * (g[k] - b[k] - xc * kk[k]);
         }
@@ -685,9 +697,9 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
 
 /* BatchNorm (training) + ReLU + 2x2 average pool in one pass over x (the stem's tail, models/model_utils.py:187-228):
  * x [N][H][W][C] -> y [N][H/2][W/2][C]; statistics over all N*H*W rows like salsa_nn_bn_train_fwd. */
-int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int H, int W, int C, const float *gamma,
-                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+int salsa_nn_bn_train_fwd_pool(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
+                               const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
                                const double *stats_part, int stats_blocks, void *hip_stream)
 {
     const int64_t M = N * H * W;
@@ -707,39 +719,45 @@ int salsa_nn_bn_train_fwd_pool(const void *x, void *y, int dtype, int64_t N, int
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     const long n_vec = (long)N * (H / 2) * (W / 2) * (C / (dtype == 1 ? 8 : 4));
     NN_LAUNCH(bn_apply_pool_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), (const char *)x, (char *)y, n_vec, H, W, C,
-              save_mean, save_invstd, gamma, beta);
+              save_mean, save_invstd, gamma, beta, (const char *)residual);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
-/* its backward: dy_pooled [N][H/2][W/2][C] -> dx [N][H][W][C] (+ dgamma, dbeta); the ReLU mask is recomputed from x */
-int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, void *dx, int dtype, int64_t N, int H, int W, int C, const float *gamma,
-                         const float *beta, const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
-                         double *sums_ws, float *coef_ws, void *hip_stream)
+/* its backward: dy_pooled [N][H/2][W/2][C] -> dx [N][H][W][C] (+ dres, the residual's gradient, when one was added; + dgamma,
+ * dbeta); the ReLU mask is recomputed from x (and the residual) */
+int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, const void *residual, void *dx, void *dres, int dtype, int64_t N, int H,
+                         int W, int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                         float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
 {
     const int64_t M = N * H * W;
     if (!dy_pooled || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
-        N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
+        (residual && !dres) || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
     float *part = (float *)(sums_ws + 2 * C);
     const DropArgs drop = drop_args(0.f, 0u);
-    if (dtype == 1)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16x8, 8, 2, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled,
-                           (const char *)nullptr, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W);
-    else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<f32x4, 4, 2, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled,
-                           (const char *)nullptr, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W);
+#define BN_POOL_REDUCE(V, L, MASK)                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, L, MASK, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled, \
+                       (const char *)residual, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W)
+    if (dtype == 1) {
+        if (residual) BN_POOL_REDUCE(bf16x8, 8, 3);
+        else BN_POOL_REDUCE(bf16x8, 8, 2);
+    } else {
+        if (residual) BN_POOL_REDUCE(f32x4, 4, 3);
+        else BN_POOL_REDUCE(f32x4, 4, 2);
+    }
+#undef BN_POOL_REDUCE
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     if (dtype == 1)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16x8, 8, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
-                           (const char *)dy_pooled, (const char *)nullptr, (const char *)x, (char *)dx, (char *)nullptr, (long)M, C,
-                           coef_ws, 1, drop, H, W);
+                           (const char *)dy_pooled, (const char *)residual, (const char *)x, (char *)dx, (char *)dres, (long)M, C,
+                           coef_ws, residual ? 2 : 1, drop, H, W);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<f32x4, 4, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
-                           (const char *)dy_pooled, (const char *)nullptr, (const char *)x, (char *)dx, (char *)nullptr, (long)M, C,
-                           coef_ws, 1, drop, H, W);
+                           (const char *)dy_pooled, (const char *)residual, (const char *)x, (char *)dx, (char *)dres, (long)M, C,
+                           coef_ws, residual ? 2 : 1, drop, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -769,3 +769,38 @@ def test_first_layer_backward_without_the_batchnorm_apply_pass():
                 torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-6)
     finally:
         nn_ops.USE_STEM_FUSED_BWD = saved
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_batchnorm_residual_relu_avgpool_matches_torch(dtype):
+    """BatchNormAct2d.relu_pool with a residual (the tail of a residual block whose successor starts with the stride-2 pool):
+    avg_pool2x2(relu(bn(x) + r)) against nn.BatchNorm2d + add + ReLU + F.avg_pool2d in float32 -- output, the gradients of x,
+    r, gamma and beta, running statistics; even and odd extents (80 x 25 -> 40 x 12 drops a column)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from salsa_amd.crnn.nn_ops import BatchNormAct2d, _BnReluPool
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(17)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    for n, c, h, w in ((2, 256, 16, 25), (3, 64, 9, 7), (2, 128, 6, 10)):
+        ref, fus = nn.BatchNorm2d(c).to(dev), BatchNormAct2d(c).to(dev)
+        with torch.no_grad():
+            ref.weight.copy_(torch.rand(c, device=dev, generator=g) + 0.5)
+            ref.bias.copy_(torch.randn(c, device=dev, generator=g))
+        fus.load_state_dict(ref.state_dict())
+        x = (torch.randn((n, c, h, w), device=dev, generator=g) * 2 + 0.5).to(dtype).contiguous(memory_format=torch.channels_last)
+        r = torch.randn((n, c, h, w), device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+        xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        xb, rb = x.float().clone().requires_grad_(True), r.float().clone().requires_grad_(True)
+        ya = fus.relu_pool(xa, None, ra)
+        yb = F.avg_pool2d(F.relu(ref(xb) + rb), 2)
+        assert isinstance(ya.grad_fn, _BnReluPool._backward_cls) and ya.shape == yb.shape
+        torch.testing.assert_close(ya.float(), yb, **(tol if dtype == torch.float32 else dict(rtol=2.0 ** -8, atol=2e-3)))
+        gy = torch.randn(ya.shape, device=dev, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+        ya.backward(gy)
+        yb.backward(gy.float())
+        torch.testing.assert_close(xa.grad.float(), xb.grad, **tol)
+        torch.testing.assert_close(ra.grad.float(), rb.grad, **tol)
+        torch.testing.assert_close(fus.weight.grad, ref.weight.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+        torch.testing.assert_close(fus.bias.grad, ref.bias.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
+        torch.testing.assert_close(fus.running_var, ref.running_var, rtol=1e-4, atol=1e-5)

@@ -10,6 +10,7 @@ run SALSA_FUSED_SKIP=0
 run SALSA_HIP_BN_POOL=0
 run SALSA_CONV_STATS=0
 run SALSA_STEM_FUSED_BWD=0
-run SALSA_FILTER_BANK=0 SALSA_HIP_CONV_1X1=0 SALSA_HIP_STEM_WRW=0 SALSA_FUSED_SKIP=0 SALSA_HIP_BN_POOL=0 SALSA_CONV_STATS=0 SALSA_STEM_FUSED_BWD=0
-run SALSA_FILTER_BANK=0 SALSA_HIP_CONV_1X1=0 SALSA_HIP_STEM_WRW=0 SALSA_FUSED_SKIP=0 SALSA_HIP_BN_POOL=0 SALSA_CONV_STATS=0 SALSA_STEM_FUSED_BWD=0 SALSA_HIP_CONV_WIDE_WRW=0
+run SALSA_HIP_BN_RES_POOL=0
+run SALSA_FILTER_BANK=0 SALSA_HIP_CONV_1X1=0 SALSA_HIP_STEM_WRW=0 SALSA_FUSED_SKIP=0 SALSA_HIP_BN_POOL=0 SALSA_CONV_STATS=0 SALSA_STEM_FUSED_BWD=0 SALSA_HIP_BN_RES_POOL=0
+run SALSA_FILTER_BANK=0 SALSA_HIP_CONV_1X1=0 SALSA_HIP_STEM_WRW=0 SALSA_FUSED_SKIP=0 SALSA_HIP_BN_POOL=0 SALSA_CONV_STATS=0 SALSA_STEM_FUSED_BWD=0 SALSA_HIP_BN_RES_POOL=0 SALSA_HIP_CONV_WIDE_WRW=0
 run A=1
