@@ -938,9 +938,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
 {
     __shared__ __attribute__((aligned(16))) unsigned short xs[SW_XS];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
-    __shared__ float cf[BN ? 7 * CH : 1]; // a, b, mean, k, invstd, beta, gamma per channel (bn_bwd_finalize_kernel's table)
-    if (BN)
-        for (int i = threadIdx.x; i < 7 * CH; i += 256) cf[i] = coef[i];
+
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mb = wv & 1, nb = wv >> 1; // this wave: co 32*mb.., columns 32*nb..
     const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
@@ -984,16 +982,27 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
         }
     };
     // one bf16 pair of the tile: BatchNorm-backward apply on (g, x1) -> dx, rounded to bf16 (a pixel outside the image has
-    // g = x1 = 0 and would give -a (b - mean k): the caller zeroes those pieces instead)
-    auto bn_pair = [&](const unsigned g2, const unsigned q2, const int c) -> unsigned {
+    // g = x1 = 0 and would give -a (b - mean k): the caller zeroes those pieces instead).  A thread's pieces always cover the
+    // same 8 channels (piece index = tid & 7), so their 56 coefficients live in registers (a table in LDS cost seven LDS reads
+    // per element: 0.43 ms for this kernel); the arithmetic is bn_bwd_apply_kernel's, operation for operation.
+    float c_a[8], c_b[8], c_mu[8], c_k[8], c_is[8], c_be[8], c_ga[8];
+    if (BN) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int ch = (tid & 7) * 8 + e;
+            c_a[e] = coef[ch]; c_b[e] = coef[CH + ch]; c_mu[e] = coef[2 * CH + ch]; c_k[e] = coef[3 * CH + ch];
+            c_is[e] = coef[4 * CH + ch]; c_be[e] = coef[5 * CH + ch]; c_ga[e] = coef[6 * CH + ch];
+        }
+    }
+    auto bn_pair = [&](const unsigned g2, const unsigned q2, const int e0) -> unsigned {
         float r[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float g = __uint_as_float(e ? (g2 & 0xffff0000u) : (g2 << 16)), xv = __uint_as_float(e ? (q2 & 0xffff0000u) : (q2 << 16));
-            const int ch = c + e;
-            const float xc = xv - cf[2 * CH + ch];
-            const bool zero = relu && !((xc * cf[4 * CH + ch]) * cf[6 * CH + ch] + cf[5 * CH + ch] > 0.f);
-            r[e] = cf[ch] * ((zero ? 0.f : g) - cf[CH + ch] - xc * cf[3 * CH + ch]);
+            const int ch = e0 + e;
+            const float xc = xv - c_mu[ch];
+            const bool zero = relu && !((xc * c_is[ch]) * c_ga[ch] + c_be[ch] > 0.f);
+            r[e] = c_a[ch] * ((zero ? 0.f : g) - c_b[ch] - xc * c_k[ch]);
         }
         return pack_bf16(r[0], r[1]);
     };
@@ -1021,11 +1030,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
             if (BN) {
                 const int tw = (int)(tile % tiles_w), th = (int)((tile / tiles_w) % tiles_h), p = i >> 3;
                 const bool inside = th * WT_H + p / WT_W < H && tw * WT_W + p % WT_W < W;
-                const int c = (i & 7) * 8;
-                v.x = inside ? bn_pair(pg_[j].x, pq_[j].x, c) : 0u;
-                v.y = inside ? bn_pair(pg_[j].y, pq_[j].y, c + 2) : 0u;
-                v.z = inside ? bn_pair(pg_[j].z, pq_[j].z, c + 4) : 0u;
-                v.w = inside ? bn_pair(pg_[j].w, pq_[j].w, c + 6) : 0u;
+                v.x = inside ? bn_pair(pg_[j].x, pq_[j].x, 0) : 0u;
+                v.y = inside ? bn_pair(pg_[j].y, pq_[j].y, 2) : 0u;
+                v.z = inside ? bn_pair(pg_[j].z, pq_[j].z, 4) : 0u;
+                v.w = inside ? bn_pair(pg_[j].w, pq_[j].w, 6) : 0u;
             }
             *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = v;
         }

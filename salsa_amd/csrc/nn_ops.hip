@@ -524,9 +524,11 @@ __global__ __launch_bounds__(256) void conv_filter_bank_kernel(const long long *
     const int Cout = (int)d[3], Cin = (int)d[4], taps = (int)d[10], rw = 32 * taps; // taps = 9 or 1
     const long s_co = d[5], s_ci = d[6], s_ky = d[7], s_kx = d[8];
     const int t = (int)(blockIdx.x - d[9]), tiles_ci = Cin / 32, co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
-    for (int e = threadIdx.x; e < 32 * rw; e += 256) {
-        const int co = e / rw, r = e % rw, ci = r / taps, tap = r % taps;
-        tile[co][r] = src[(co0 + co) * s_co + (ci0 + ci) * s_ci + (tap / 3) * s_ky + (tap % 3) * s_kx];
+    for (int e = threadIdx.x; e < 32 * rw; e += 256) { // consecutive threads walk the source's contiguous axis: ci when the
+        // master filter is channels-last (s_ci == 1), the taps when it is torch's default (co, ci, ky, kx)
+        const int co = e / rw, q = e % rw;
+        const int ci = s_ci == 1 ? q % 32 : q / taps, tap = s_ci == 1 ? q / 32 : q % taps;
+        tile[co][ci * taps + tap] = src[(co0 + co) * s_co + (ci0 + ci) * s_ci + (tap / 3) * s_ky + (tap % 3) * s_kx];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 32 * rw; e += 256) {
