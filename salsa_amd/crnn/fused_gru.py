@@ -34,6 +34,45 @@ def _scan_inference(gi, whh, bhh):
     return hs
 
 
+_ONES = {}
+LEAN = os.environ.get('SALSA_GRU_LEAN', '1') != '0'   # GEMM / GEMV forms of the projection and bias gradients (0: einsum + reductions)
+
+
+def _ones(n, device):
+    key = (n, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+class _InputProjection(torch.autograd.Function):
+    """gi[t, b, d] = W_ih[d] x[b, t] + b_ih[d] for both directions (D, 3H, In): the einsum + bias of the scan's input, with
+    the bias gradient as a ones-row GEMV instead of autograd's reduction over (t, b)."""
+
+    @staticmethod
+    def forward(ctx, x, wih, bih):
+        ctx.save_for_backward(x, wih)
+        B, T, In = x.shape
+        D, G, _ = wih.shape
+        gi = torch.addmm(bih.reshape(1, D * G), x.reshape(B * T, In), wih.reshape(D * G, In).t())      # (B*T, D*3H)
+        return gi.view(B, T, D, G).transpose(0, 1).contiguous()                                        # (T, B, D, 3H)
+
+    @staticmethod
+    def backward(ctx, dgi):
+        x, wih = ctx.saved_tensors
+        B, T, In = x.shape
+        D, G, _ = wih.shape
+        g2 = dgi.transpose(0, 1).reshape(B * T, D * G)                                                 # (B*T, D*3H), rows as in x
+        dx = dwih = dbih = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g2, wih.reshape(D * G, In)).view(B, T, In)
+        if ctx.needs_input_grad[1]:
+            dwih = torch.mm(g2.t(), x.reshape(B * T, In)).view(D, G, In)
+        if ctx.needs_input_grad[2]:
+            dbih = torch.mv(g2.t(), _ones(B * T, x.device)).view(D, G)
+        return dx, dwih, dbih
+
+
 class _GruScan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gi, whh, bhh, half_weights=False):
@@ -76,12 +115,24 @@ class _GruScan(torch.autograd.Function):
                       C.c_void_p(saved.data_ptr()), C.c_void_p(dgi.data_ptr()), C.c_void_p(dgh.data_ptr()), T, B, D, H, _stream(hs))
         if rc:
             raise RuntimeError('salsa_gru_scan_bwd failed (%d)' % rc)
-        hprev = torch.zeros_like(hs)                       # h before each step, per direction's scan order
-        hprev[1:, :, 0] = hs[:-1, :, 0]
-        if D > 1:
-            hprev[:-1, :, 1] = hs[1:, :, 1]
-        dwhh = torch.einsum('tbdr,tbdk->drk', dgh, hprev)  # one GEMM per direction
-        dbhh = dgh.sum(dim=(0, 1))
+        # dW_hh[d] = sum_t dgh[t, :, d]^T h_before[t, :, d]: h before step t is hs[t - 1] in the forward direction and hs[t + 1] in
+        # the reverse one (zero at the scan's first step), so each direction is ONE GEMM on shifted, strided VIEWS of dgh and hs --
+        # no zero-filled shifted copy of hs; the bias gradient is a ones-row GEMV (torch's reduce over the two leading axes of
+        # a 4-D tensor took 21 us per call, the GEMV takes a few)
+        if not LEAN:
+            hprev = torch.zeros_like(hs)                   # h before each step, per direction's scan order
+            hprev[1:, :, 0] = hs[:-1, :, 0]
+            if D > 1:
+                hprev[:-1, :, 1] = hs[1:, :, 1]
+            return dgi, torch.einsum('tbdr,tbdk->drk', dgh, hprev), dgh.sum(dim=(0, 1)), None
+        dwhh = torch.empty((D, 3 * H, H), dtype=torch.float32, device=hs.device)
+        if T > 1:
+            torch.mm(dgh[1:, :, 0].reshape(-1, 3 * H).t(), hs[:-1, :, 0].reshape(-1, H), out=dwhh[0])
+            if D > 1:
+                torch.mm(dgh[:-1, :, 1].reshape(-1, 3 * H).t(), hs[1:, :, 1].reshape(-1, H), out=dwhh[1])
+        else:
+            dwhh.zero_()
+        dbhh = torch.mv(dgh.view(T * B, D * 3 * H).t(), _ones(T * B, hs.device)).view(D, 3 * H)
         return dgi, dwhh, dbhh, None
 
 
@@ -101,8 +152,8 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weigh
         bhh = torch.stack([getattr(gru, 'bias_hh' + n) for n in names])
         if layer > 0 and training and gru.dropout > 0:
             out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
-        gi = torch.einsum('bti,dgi->tbdg', out, wih) + bih                          # (T,B,D,3H)
-        gi = gi.contiguous()
+        gi = _InputProjection.apply(out.contiguous(), wih, bih) if (out.is_cuda and LEAN) else \
+            (torch.einsum('bti,dgi->tbdg', out, wih) + bih).contiguous()           # (T,B,D,3H)
         no_grad = not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad))
         if REGISTER_WEIGHTS and half_weights and whh.shape[2] == 256 and no_grad:
             hs = _scan_inference(gi, whh, bhh)                                      # W_hh (float16) resident in registers
