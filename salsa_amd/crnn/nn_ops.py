@@ -775,7 +775,7 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
             raise RuntimeError('salsa_nn_conv3x3_c64_bias_act%s failed (%d)' % ('_pool' if fuse_pool else '', rc))
         return y if fuse_pool or not pool else avg_pool2x2(y)
     if (isinstance(conv, Conv3x3) and conv._wide_eligible(x) and not bn.training and not torch.is_grad_enabled()
-            and bn.track_running_stats and bn.affine and not pool
+            and bn.track_running_stats and bn.affine
             and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == conv.out_channels
                                       and residual.is_contiguous(memory_format=torch.channels_last)))):
         # the wide layers at inference: the same folding on conv_wide.hip's epilogue
@@ -788,7 +788,7 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
                                                             Cin, conv.out_channels, _stream(xb))
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_wide_bias_act failed (%d)' % rc)
-        return y
+        return avg_pool2x2(y) if pool else y      # (pool: the last layer of a block before a stride-2 block)
     if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
             and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
         wq, shift = _folded(conv, bn, stem=True)
