@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void avgpool2x2_bwd_kernel(const char *__restr
 // ------------------------------------------------------------------------------------------------ BatchNorm2d (+ add) (+ ReLU)
 // x: [M][C] channels-last (M = N*H*W).  A thread owns one column group of L channels (16 bytes); a 256-thread block is
 // (256/cv) rows x cv column groups, cv = C / L, and walks BN_ROWS_PER_THREAD rows per thread.  Reductions: float32
-// per-thread partials -> LDS tree over the block's rows -> ONE float64 atomic per channel per block.
+// per-thread partials -> LDS tree over the block's rows -> one partial row per block (no atomics: thousands of blocks would
+// serialise on 2*C addresses), summed in float64 by the finalize kernels.
 #ifndef BN_RPT
 #define BN_RPT 32
 #endif
