@@ -78,6 +78,11 @@ int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const in
  * BatchNorm that follows (salsa_nn_bn_train_fwd / _pool: stats_part, stats_blocks) then makes no statistics pass over y. */
 int salsa_nn_conv3x3_c64_stats_blocks(int64_t N, int H, int W);
 int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y, double *stats_part, int64_t N, int H, int W, void *hip_stream);
+/* Training forward of the first layer from a persistent launch that also leaves the per-channel partial sums of its output
+ * (see salsa_nn_conv3x3_c64_stats): stats_part[salsa_nn_conv3x3_stem_stats_blocks(N, H, W)][2][64] float64. */
+int salsa_nn_conv3x3_stem_stats_blocks(int64_t N, int H, int W);
+int salsa_nn_conv3x3_stem_stats(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *wq, void *y,
+                                double *stats_part, int64_t N, int Cin, int H, int W, void *hip_stream);
 /* weight gradient of the (Cin <= 7) -> 64 first layer: dw float32 [64 co][Cin][3][3] contiguous += sum_pixels dy[p][co] *
  * x[ci][p + tap] (zero it first); x float32 planar as in salsa_nn_conv3x3_stem, dy bf16 channels-last [N][H][W][64] */
 int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *dy, float *dw, int64_t N,

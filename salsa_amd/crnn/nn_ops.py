@@ -515,7 +515,19 @@ class _StemConvBnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, conv_w, bn_w, bn_b, running_mean, running_var, momentum, eps, batches_tracked):
         L = _lib.load()
-        x1 = _conv_stem(x, _stem_filter(conv_w))
+        N, Cin, H, W = x.shape
+        nb = L.salsa_nn_conv3x3_stem_stats_blocks(N, H, W) if USE_CONV_STATS else 0
+        part = None
+        if nb > 0:  # the persistent launch that also leaves the BatchNorm's statistics (no statistics pass over the 524 MB)
+            x1 = torch.empty((N, 64, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            part = torch.empty(nb * 128, dtype=torch.float64, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = L.salsa_nn_conv3x3_stem_stats(_ptr(x), x.stride(0), x.stride(1), _ptr(_stem_filter(conv_w)), _ptr(x1), _ptr(part),
+                                                   N, Cin, H, W, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_conv3x3_stem_stats failed (%d)' % rc)
+        else:
+            x1 = _conv_stem(x, _stem_filter(conv_w))
         N, Cn, H, W = x1.shape
         M = N * H * W
         y = torch.empty_like(x1, memory_format=torch.channels_last)
@@ -524,7 +536,7 @@ class _StemConvBnRelu(torch.autograd.Function):
         with torch.cuda.device(x.device):
             rc = L.salsa_nn_bn_train_fwd(_ptr(x1), _ptr(y), None, 1, M, Cn, _ptr(bn_w), _ptr(bn_b), float(eps), float(momentum),
                                          _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), 1, 0.0, 0,
-                                         _ptr(batches_tracked), None, 0, _stream(x))
+                                         _ptr(batches_tracked), _ptr(part), nb if part is not None else 0, _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
         ctx.save_for_backward(x, x1, bn_w, bn_b, save)

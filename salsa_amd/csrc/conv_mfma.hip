@@ -616,9 +616,14 @@ namespace {
 #endif
 constexpr int STH = 8, SHALO_H = STH + 2; // stem tile: 8 rows x TW pixels, wave w owns rows 2w, 2w+1 and all 64 output channels
 
+// STATS (training): the launch is persistent (a workgroup walks tiles blockIdx.x, + gridDim.x, ...) and also leaves the
+// per-channel sum / sum of squares of its bf16-rounded outputs as one float64 row [2][64] per workgroup for the BatchNorm that
+// follows, accumulated like the 64 -> 64 kernel's (conv64_stats: DPP quad sums, lane q of a quad keeps channel group q).
+template <bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__restrict__ x, const unsigned short *__restrict__ wq,
                                                                unsigned short *__restrict__ y, int N, int Cin, int H, int W, long x_batch_stride,
-                                                               long x_channel_stride, const float *__restrict__ shift, int relu)
+                                                               long x_channel_stride, const float *__restrict__ shift, int relu,
+                                                               double *__restrict__ stats_part)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xs[SHALO_H * HALO_W * 8];
     __shared__ __attribute__((aligned(16))) unsigned short ys[4 * TW * ROW]; // per wave: one output row, [pixel][ROW]
@@ -630,7 +635,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) af[ks][mt] = *(const bf16x8 *)(wq + ((mt * 32 + px) * 10 + 2 * ks + khalf) * 8);
     const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + STH - 1) / STH;
-    const long tile = blockIdx.x;
+    const long n_tiles = (long)N * tiles_h * tiles_w;
+    float rs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, rq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tile != (long)blockIdx.x) __syncthreads(); // the previous tile's reads of xs are done
     const int tw = (int)(tile % tiles_w);
     const int th = (int)((tile / tiles_w) % tiles_h);
     const long n = tile / ((long)tiles_w * tiles_h);
@@ -705,9 +713,65 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next row overwrites the strip
     }
+    if (STATS) { // the wave's rows 8 th + 2 wv + {0, 1} = conv64_stats' rows (4 th' + 2 rg + rr) with th' = 2 th + wv / 2, rg = wv & 1
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const f32x16 a2[2] = {acc[0][mt], acc[1][mt]};
+            conv64_stats(a2, rs[mt], rq[mt], 2 * th + (wv >> 1), tw, H, W, px, wv & 1);
+        }
+    }
+    } // tile loop
+    if (STATS) {
+        float *lstats = (float *)ys; // [wave][sum | sum of squares][64]: the strips are free now
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int d = 4; d <= 16; d <<= 1) {
+                    rs[mt][j] += __shfl_xor(rs[mt][j], d);
+                    rq[mt][j] += __shfl_xor(rq[mt][j], d);
+                }
+        if (px < 4) {
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    lstats[wv * 128 + 32 * mt + 4 * khalf + 8 * px + j] = rs[mt][j];
+                    lstats[wv * 128 + 64 + 32 * mt + 4 * khalf + 8 * px + j] = rq[mt][j];
+                }
+        }
+        __syncthreads();
+        if (tid < 128)
+            stats_part[(long)blockIdx.x * 128 + tid] = (double)lstats[tid] + (double)lstats[128 + tid] + (double)lstats[256 + tid] + (double)lstats[384 + tid];
+    }
 }
 
 } // namespace
+
+/* number of partial rows salsa_nn_conv3x3_stem_stats writes (= its persistent workgroup count) */
+extern "C" int salsa_nn_conv3x3_stem_stats_blocks(int64_t N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return 0;
+    const long tiles = (long)N * ((H + STH - 1) / STH) * ((W + TW - 1) / TW);
+    return (int)(tiles >= 1024 ? 1024 : tiles);
+}
+
+// training: the plain first-layer convolution from a persistent launch that also leaves its output's per-channel partial sums
+// (float64 rows stats_part[blocks][2][64]) for the BatchNorm that follows -- see salsa_nn_conv3x3_c64_stats
+extern "C" int salsa_nn_conv3x3_stem_stats(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *wq, void *y,
+                                           double *stats_part, int64_t N, int Cin, int H, int W, void *hip_stream)
+{
+    if (!x || !wq || !y || !stats_part || N <= 0 || Cin <= 0 || Cin > 8 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        return -1;
+    const unsigned nb = (unsigned)salsa_nn_conv3x3_stem_stats_blocks(N, H, W);
+    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (const unsigned short *)wq,
+                       (unsigned short *)y, (int)N, Cin, H, W, (long)x_batch_stride, (long)x_channel_stride, (const float *)nullptr, 0,
+                       stats_part);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
 
 // x float32 planar [N][Cin][H][W] (Cin <= 8; rows contiguous, batch / channel strides in elements, so a time-cropped view of
 // the extractor's output needs no copy), wq bf16 [64][10][8] = w[co][tap][ci] zero-padded (tap 9 and ci >= Cin zero),
@@ -720,9 +784,9 @@ extern "C" int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int
         return -1;
     const long tiles = (long)N * ((H + STH - 1) / STH) * ((W + TW - 1) / TW);
     if (tiles >= INT32_MAX) return -1;
-    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)hip_stream, x,
+    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)hip_stream, x,
                        (const unsigned short *)wq, (unsigned short *)y, (int)N, Cin, H, W, (long)x_batch_stride, (long)x_channel_stride,
-                       shift, relu);
+                       shift, relu, (double *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -804,3 +804,27 @@ def test_fused_batchnorm_residual_relu_avgpool_matches_torch(dtype):
         torch.testing.assert_close(fus.weight.grad, ref.weight.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
         torch.testing.assert_close(fus.bias.grad, ref.bias.grad, rtol=tol['rtol'], atol=tol['atol'] * (n * h * w) ** 0.5)
         torch.testing.assert_close(fus.running_var, ref.running_var, rtol=1e-4, atol=1e-5)
+
+
+def test_first_layer_statistics_epilogue_matches_the_stored_tensor():
+    """salsa_nn_conv3x3_stem_stats (persistent first-layer forward that also leaves the BatchNorm's partial sums): same output
+    as the plain launch, and the partial rows add up to the per-channel sum / sum of squares of the stored bf16 tensor --
+    ragged sizes, a strided (time-cropped) input, more tiles than workgroups."""
+    from salsa_amd import _lib
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    L = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(41)
+    for n, cin, h, w in ((2, 7, 40, 70), (1, 7, 9, 33), (3, 4, 17, 5), (16, 7, 640, 200)):
+        x = torch.randn((n, cin, h + 1, w), device=dev, generator=g)[:, :, :h]
+        wq = nn_ops._stem_filter(torch.randn((64, cin, 3, 3), device=dev, generator=g) * 0.2)
+        ref = nn_ops._conv_stem(x, wq)
+        nb = L.salsa_nn_conv3x3_stem_stats_blocks(n, h, w)
+        part = torch.full((nb * 128,), float('nan'), dtype=torch.float64, device=dev)
+        y = torch.empty_like(ref)
+        rc = L.salsa_nn_conv3x3_stem_stats(nn_ops._ptr(x), x.stride(0), x.stride(1), nn_ops._ptr(wq), nn_ops._ptr(y), nn_ops._ptr(part), n, cin,
+                                           h, w, nn_ops._stream(x))
+        assert rc == 0 and torch.equal(y, ref)
+        tot, yf = part.view(nb, 2, 64).sum(0), y.double()
+        torch.testing.assert_close(tot[0], yf.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(tot[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
