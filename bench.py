@@ -79,6 +79,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-crnn', action='store_true', help='skip the CRNN-training half of the metric')
     ap.add_argument('--no-infer', action='store_true', help='skip the batched-inference leg (BASELINE config 5)')
+    ap.add_argument('--no-config4', action='store_true', help='skip the on-the-fly SALSA-MIC + augmentation training leg (BASELINE config 4)')
+    ap.add_argument('--tolerate-crnn-failure', action='store_true', help='exit 0 even if a CRNN-side leg (crnn / config4 / inference) failed')
+    ap.add_argument('--infer-steps', type=int, default=20)
     ap.add_argument('--crnn-steps', type=int, default=20)
     ap.add_argument('--crnn-warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=1, help='extra leg: K steps round-robin over this many HIP streams / plans (reported as pipelined, never `value`)')
@@ -151,13 +154,16 @@ def main():
     pcie = None
     pipelined = None
     if rank == 0:
-        ex.set_timing(True)                          # (timing mode issues the kernels back to back on one stream)
-        tot, cnt, n_t = {}, {}, max(3, min(args.steps, 10))
-        for _ in range(n_t):
-            ex.extract(audio, out=out)
-            for name, ms in ex.read_timing():
-                tot[name] = tot.get(name, 0.0) + ms
-                cnt[name] = cnt.get(name, 0) + 1
+        # K launches of each kernel back to back between ONE event pair on the launch stream (inputs left in place by the
+        # full extract calls above; every kernel is idempotent on them): per launch = elapsed / K, no event between launches,
+        # so the per-kernel figures add up to the step
+        n_t = max(3, min(args.steps, 10))
+        ex.set_timing(n_t)
+        tot, cnt = {}, {}
+        ex.extract(audio, out=out)
+        for name, ms in ex.read_timing():
+            tot[name] = tot.get(name, 0.0) + ms * n_t
+            cnt[name] = cnt.get(name, 0) + n_t
         ex.set_timing(False)
         ab = algorithmic_bytes(args.batch, n_samples, T, F)
         if args.feature != 'salsa':
@@ -173,12 +179,13 @@ def main():
         # measured HBM bytes and VALU utilisation per launch (rocprofv3 PMC, collected offline by tools/pmc_round.sh +
         # tools/pmc_traffic.py: counters cannot be sampled from inside this process); only valid for the batch size and
         # kernel version they were taken at (profiles/traffic.json names both)
-        traffic, valu = {}, {}
+        traffic, valu, traffic_src = {}, {}, None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
             if tj.get('batch_clips_per_launch') == args.batch and args.feature == 'salsa' and abs(args.seconds - 60) < 1e-9:
                 traffic = {k: v['hbm_bytes'] for k, v in tj['kernels'].items()}
                 valu = {k: v.get('valu_util') for k, v in tj['kernels'].items()}
+                traffic_src = 'offline PMC: profiles/traffic.json (%s), rocprofv3 --pmc passes of the same kernels on another run' % tj.get('source', 'tools/pmc_round.sh')
         except Exception:
             pass
         for k in kernels:
@@ -207,6 +214,9 @@ def main():
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4),
                     'traffic': int(sum(tr_known)) if len(tr_known) == len(kernels) and tr_known else None,
+                    'traffic_source': traffic_src,
+                    'kernel_ms_sum': round(sum(t_of(k) for k in kernels), 4),
+                    'kernel_timing': '%d back-to-back launches of each kernel between one HIP event pair on the launch stream' % n_t,
                     'scope': 'whole step: algorithmic bytes of the path (%d) / median wall time per step' % pipe_bytes,
                     'algorithmic_bytes': pipe_bytes, 'ms': round(step_ms, 4),
                     'peak_measured': round(copy_gbs, 1), 'frac_of_measured': round(achieved / copy_gbs, 4),
@@ -270,36 +280,52 @@ def main():
             del pipe
 
     # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the DDP run)
-    del ex, audio, out
+    infer_audio = audio if (args.feature == 'salsa' and fmt == 'foa' and args.batch == 32 and abs(args.seconds - 60) < 1e-9) else None
+    del ex, out
+    if infer_audio is None:
+        del audio
     torch.cuda.empty_cache()
-    crnn = None
-    if not args.no_crnn and args.feature == 'salsa':
+    failures = []
+
+    def leg(name, fn):
+        """One of the CRNN-side legs; a failure is recorded in the line AND makes the process exit non-zero (unless
+        --tolerate-crnn-failure): the CRNN number is half of BASELINE.json's metric."""
         try:
-            crnn = train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup)
-        except Exception as e:                                   # the feature line must survive a CRNN failure
-            if world > 1:
-                raise
-            crnn = {'error': '%s: %s' % (type(e).__name__, e)}
-    # ---- BASELINE config 5 (reported, not part of the metric): 32 x 60-s clips per GPU per step through SALSA + CRNN forward
-    infer = None
-    if not args.no_infer and not args.no_crnn and args.feature == 'salsa':
-        try:
-            from types import SimpleNamespace
-            from salsa_amd.crnn.train import Trainer
-            torch.cuda.empty_cache()
-            infer = infer_bench(SimpleNamespace(clips=32, sub_batch=32, steps=5, warmup=3), rank, world, dev, Trainer(dev, ddp=False))
+            return fn()
         except Exception as e:
             if world > 1:
                 raise
-            infer = {'error': '%s: %s' % (type(e).__name__, e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
+            failures.append(name)
+            return {'error': '%s: %s' % (type(e).__name__, e)}
+
+    crnn = config4 = infer = None
+    if not args.no_crnn and args.feature == 'salsa':
+        crnn = leg('crnn', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup))
+        # ---- BASELINE config 4: raw 8-s MIC chunks -> SALSA-MIC on device -> the reference's augmentation -> training step
+        if not args.no_config4:
+            torch.cuda.empty_cache()
+            config4 = leg('config4', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup,
+                                                         on_the_fly=True, augment=True))
+        # ---- BASELINE config 5 (reported, not part of the metric): 32 x 60-s clips per GPU per step through SALSA + CRNN forward
+        if not args.no_infer:
+            def _infer():
+                from types import SimpleNamespace
+                from salsa_amd.crnn.train import Trainer
+                torch.cuda.empty_cache()
+                return infer_bench(SimpleNamespace(clips=32, sub_batch=32, steps=args.infer_steps, warmup=3), rank, world, dev,
+                                   Trainer(dev, ddp=False), audio=infer_audio)
+            infer = leg('inference', _infer)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
+    # CPU baseline: rank 0 only, for every N (after the process group is gone, so the other ranks are not kept waiting on a
+    # collective); the same bounded sample at every N
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
+
     audio_s = world * args.batch * args.seconds * args.steps
     line = {
         'metric': 'SALSA feat-extract audio-s/s',
@@ -327,13 +353,19 @@ def main():
         'roofline': roofline,
         'cpu_baseline': cpu,
         'crnn': crnn,
+        'config4': config4,
         'inference': infer,
     }
+    if failures:
+        line['status'] = 'partial: %s failed' % ', '.join(failures)
     if pcie:
         line['pcie_inclusive'] = pcie
     if pipelined:
         line['pipelined'] = pipelined
     print(json.dumps(line))
+    if failures and not args.tolerate_crnn_failure:
+        sys.stdout.flush()
+        sys.exit(3)
 
 
 if __name__ == '__main__':

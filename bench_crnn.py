@@ -39,16 +39,23 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARC
 GFLOP_PER_CHUNK_FWD = 44.74 + 0.19       # conv + GRU forward per 8-s chunk (probed)
 
 
-def infer_bench(args, rank, world, dev, tr):
+def infer_bench(args, rank, world, dev, tr, audio=None):
     """Batched inference (config 5): per step, `clips` 60-s FOA clips per GPU go raw audio -> SALSA features (HIP) ->
     normalise-on-load (fused into the extraction) -> CRNN forward (bf16) -> SED probabilities + xyz at label rate, all on device.  Clips are
-    sharded over ranks, no collective.  Latency = wall time of one sub-batch (default 32 clips, SURVEY config 5) end to end."""
+    sharded over ranks, no collective.  `audio`: this rank's [clips][4][N] device tensor (bench.py hands over its seeded
+    synth_clip batch, the config-2 clips: bursts that pass the noise gate, unlike white noise); None -> synthesised here.
+    Latency: a clip's result exists when its sub-batch (default 32 clips, SURVEY config 5) has gone through extraction + forward,
+    so per-clip latency = wall time of its sub-batch, measured with a synchronize on both sides in a separate pass of
+    `steps` steps (never inside the throughput region)."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from salsa_amd.extractor import SalsaExtractor
     ex = SalsaExtractor(audio_format='foa', fmax_doa=9000, device=dev)
-    g = torch.Generator(dev).manual_seed(rank)
-    audio = 0.1 * torch.randn(args.clips, 4, 60 * 24000, device=dev, generator=g)
+    if audio is None:
+        from salsa_amd.synth import synth_clip
+        audio = torch.from_numpy(np.stack([synth_clip(2021 + rank * args.clips + i, 60 * 24000) for i in range(args.clips)])).to(dev)
+    assert audio.shape[0] == args.clips
     mean = torch.full((4, 1, 200), -60.0, device=dev)
     std = torch.full((4, 1, 200), 12.0, device=dev)
     ex.set_scaler(mean, std)                                  # normalise-on-load fused into the extraction kernel
@@ -73,14 +80,17 @@ def infer_bench(args, rank, world, dev, tr):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    step(timed=True)
+    for _ in range(args.steps):
+        step(timed=True)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -88,32 +98,47 @@ def infer_bench(args, rank, world, dev, tr):
     if rank != 0:
         return None
     lat.sort()
+    p50 = 1e3 * lat[len(lat) // 2]
     return ({
         'metric': 'SALSA+CRNN inference clips/s', 'value': round(world * args.clips * args.steps / elapsed, 2),
         'unit': '60-s clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 (features)', 'data': 'synthetic',
-        'p50_latency_ms_per_%dclip_subbatch' % sub: round(1e3 * lat[len(lat) // 2], 2),
+        'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 (features)', 'data': 'synthetic (seeded synth_clip bursts + noise, the config-2 clips)',
+        'p50_latency_ms_per_clip': round(p50, 2),
+        'p90_latency_ms_per_clip': round(1e3 * lat[min(len(lat) - 1, (9 * len(lat)) // 10)], 2),
+        'latency_samples': len(lat),
+        'latency_note': 'a clip is answered when its %d-clip sub-batch is: per-clip latency = sub-batch wall time (amortised: %.3f ms per clip)' % (sub, p50 / sub),
         'config': {'workload': 'batched inference: %d x 60-s 4-ch clips per GPU per step, SALSA-FOA + CRNN forward, '
                                'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}})
 
 
-def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False):
+def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False,
+                n_frames=640, amp_dtype='default'):
     """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
     `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 torch DDP = bucketed gradient all-reduce on RCCL
     overlapped with the backward.  The process group must already be initialised for world > 1.  Every rank calls this;
-    rank 0 gets the result dict, the others None."""
+    rank 0 gets the result dict, the others None.  `n_frames` / `amp_dtype` / a CPU `dev` exist for the world-size-2 gloo test
+    of this very function (tests/test_crnn_cpu.py): the DDP branch, the barrier / max-over-ranks timing and the result dict are
+    the ones the GPU run uses."""
     import torch
     import torch.distributed as dist
     from salsa_amd.crnn.train import Trainer, synthetic_batch
 
-    tr = Trainer(dev, bf16_grad_allreduce=not fp32_grads)
-    x, sed, doa = synthetic_batch(batch, dev, seed=2021 + rank)
+    dev = torch.device(dev)
+    on_gpu = dev.type == 'cuda'
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    kw = {} if amp_dtype == 'default' else {'amp_dtype': amp_dtype}
+    tr = Trainer(dev, bf16_grad_allreduce=not fp32_grads, **kw)
+    x, sed, doa = synthetic_batch(batch, dev, seed=2021 + rank, n_frames=n_frames)
     ex, audio = None, None
     if on_the_fly:
         from salsa_amd.extractor import SalsaExtractor
         ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
-        audio = 0.1 * torch.randn(batch, 4, 8 * 24000, device=dev, generator=torch.Generator(dev).manual_seed(rank))
+        # normalise-on-load (dataset/database.py:197-202) fused into the extraction, as the precomputed path's loader does
+        ex.set_scaler(torch.full((4, 1, 200), -60.0, device=dev), torch.full((4, 1, 200), 12.0, device=dev))
+        import numpy as np
+        from salsa_amd.synth import synth_clip                        # seeded 8-s chunks (bursts + noise), 32 per rank
+        audio = torch.from_numpy(np.stack([synth_clip(4021 + rank * batch + i, 8 * 24000) for i in range(batch)])).to(dev)
     aug_gen = torch.Generator().manual_seed(2021 + rank)
 
     def step():
@@ -127,17 +152,17 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()[0]
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     ranks = 1
     if world > 1:
@@ -153,10 +178,10 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
     tflops = 3 * GFLOP_PER_CHUNK_FWD * cps / 1e3                     # fwd + bwd ~ 3x forward
     return {
         'metric': 'CRNN train clips/s', 'value': round(cps, 1), 'unit': '8-s chunks/s', 'n_gpus': world,
-        'rccl_ranks': ranks, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
+        'rccl_ranks': ranks, 'backend': (dist.get_backend() if world > 1 else None), 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,640,200), batch %d per GPU, Adam'
-                               % ('on-the-fly extracted MIC' if on_the_fly else 'precomputed-FOA-shaped', batch)
+        'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,%d,200), batch %d per GPU, Adam'
+                               % ('on-the-fly extracted MIC (raw [B][4][192000] audio -> SALSA-MIC on device, scaler fused)' if on_the_fly else 'precomputed-FOA-shaped', n_frames, batch)
                                + (' + device augmentation' if augment else ''),
                    'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if fp32_grads else 'bf16'},
         'roofline': {'bound': 'mfma', 'achieved': round(tflops / world, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',

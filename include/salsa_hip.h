@@ -149,8 +149,12 @@ int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_c
                         const float *d_uval, const float *d_minmax, void *hip_stream);
 
 /* Per-kernel timing of salsa_extract_batch with HIP events recorded on the call's stream (for roofline reporting).
- * enable != 0 brackets each kernel with events; salsa_plan_read_timing synchronises on them and returns the
- * milliseconds of the last call's launches in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */
+ * enable == 1 brackets each launch with an event pair.  enable = K > 1 launches every kernel of the call K times back to
+ * back between ONE event pair (each kernel is idempotent on the audio / spill / mask buffers, so the results are those of
+ * a plain call) and reports elapsed / K: the per-launch average without an event between launches, which is what a
+ * rocprofv3 kernel trace of the plain call shows (an event pair around a single launch inflates it by ~12 %).
+ * salsa_plan_read_timing synchronises on the events and returns the milliseconds per launch of the last call's kernels
+ * in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */
 #define SALSA_MAX_KERNELS 32
 int salsa_plan_set_timing(salsa_plan *plan, int enable);
 int salsa_plan_read_timing(salsa_plan *plan, float *ms, const char **names, int *n_out);

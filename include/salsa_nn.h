@@ -1,7 +1,8 @@
 /*
  * salsa_nn.h -- C ABI of the layers of the SELD CRNN consumer that are hand-written for MI355X: average pools, fused
- * BatchNorm, and the 3x3 convolutions' forward / data gradient on the matrix cores (weight gradients: 64 -> 64 only; the rest
- * and the 1x1 shortcuts stay with MIOpen).  Tensors are channels-last ([N][H][W][C], C fastest), device pointers, caller-owned;
+ * BatchNorm, and EVERY convolution of the training step on the matrix cores -- forward, data gradient and weight gradient of
+ * the first layer (salsa_nn_conv3x3_stem*), the 64 -> 64 layers (salsa_nn_conv3x3_c64*), the 128 / 256 / 512-channel layers
+ * (salsa_nn_conv3x3_wide*) and the 1x1 shortcuts (salsa_nn_conv1x1*); nothing of the step is left on MIOpen.  Tensors are channels-last ([N][H][W][C], C fastest), device pointers, caller-owned;
  * dtype: 0 = float32, 1 = bfloat16; asynchronous on the given HIP stream.
  *
  *   salsa_nn_avgpool2x2_{fwd,bwd}: F.avg_pool2d(x, 2) of the upstream model (models/model_utils.py:187-228 ConvBlock,

@@ -45,6 +45,35 @@ def host_cpu():
     return model, (len(phys) or logical), logical
 
 
+def effective_cpus():
+    """-> dict: the CPUs this process may actually use.  os.cpu_count() reports the host's logical CPUs even inside a
+    container whose cgroup grants a fraction of them: the scheduler affinity mask and the cgroup CPU quota (v2 cpu.max, v1
+    cfs_quota_us / cfs_period_us) say what this process really gets."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota, quota_src = None, None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        quota_src = 'cgroup v2 cpu.max = %s %s' % (q, per)
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            quota_src = 'cgroup v1 cfs_quota_us / cfs_period_us = %d / %d' % (q, per)
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = affinity if quota is None else max(1, min(affinity, int(quota)))
+    return {'effective_cores': eff, 'affinity_cpus': affinity, 'cgroup_cpu_quota': quota, 'cgroup_source': quota_src,
+            'os_cpu_count': logical}
+
+
 def _timed_pool(workers, jobs, feature, fmt, fmax):
     import multiprocessing as mp
     with mp.get_context('spawn').Pool(workers) as pool:
@@ -57,15 +86,17 @@ def _timed_pool(workers, jobs, feature, fmt, fmax):
 
 def run(feature, fmt, fmax, n_samples, workers=None):
     """-> dict for bench.py's cpu_baseline.  Bounded samples of the same workload, one 60-s clip per single-threaded worker
-    process, at three occupancies of the host: every logical CPU, every physical core, and 32 workers (round 1's figure).
-    `value` / `cores` are the FASTEST of them (on the 2 x 64-core EPYC of the GPU boxes the all-CPU run is memory-bound and
-    slower than 32 workers); every configuration is listed under `configs`.  Rates are clips x seconds / the slowest
-    worker's time."""
+    process, at up to three occupancies: every CPU this process may use (scheduler affinity and cgroup quota -- NOT
+    os.cpu_count(), which reports the host even inside a container that owns a fraction of it), every physical core, and 32
+    workers (round 1's figure), each capped at the effective count.  `value` / `cores` are the FASTEST of them; every
+    configuration is listed under `configs`.  Rates are clips x seconds / the slowest worker's time."""
     from oracle import oracle as orc
     orc.build()
     model, phys, logical = host_cpu()
     secs = n_samples / 24000.0
-    counts = [workers] if workers else sorted({logical, phys, max(1, min(logical, 32))}, reverse=True)
+    eff = effective_cpus()
+    cap = eff['effective_cores']
+    counts = [workers] if workers else sorted({max(1, min(logical, cap)), max(1, min(phys, cap)), max(1, min(cap, 32))}, reverse=True)
     configs = []
     for w in counts:
         jobs = [(2021 + i, n_samples, feature, fmt, fmax) for i in range(w)]
@@ -75,6 +106,8 @@ def run(feature, fmt, fmax, n_samples, workers=None):
     best = max(configs, key=lambda c: c['value'])
     return {'value': best['value'], 'unit': 'audio-seconds/s', 'cores': best['cores'], 'kind': 'port',
             'cpu_model': model, 'physical_cores': phys, 'logical_cpus': logical,
+            'effective_cores': cap, 'affinity_cpus': eff['affinity_cpus'], 'cgroup_cpu_quota': eff['cgroup_cpu_quota'],
+            'cgroup_source': eff['cgroup_source'],
             'sample': '%d x %.0f-s clips (seeds 2021..), one single-threaded process per worker running oracle/salsa_oracle.c '
                       '(float64 C restatement of the reference) concurrently; slowest clip %.2f s, %.1f core-s total; '
                       'fastest of the occupancies in `configs`' % (best['cores'], secs, best['slowest_clip_s'], best['core_s_total']),

@@ -41,6 +41,8 @@ LEAN = os.environ.get('SALSA_GRU_LEAN', '1') != '0'   # GEMM / GEMV forms of the
 def _ones(n, device):
     key = (n, device)
     if key not in _ONES:
+        if len(_ONES) >= 16:                 # bounded: variable batch sizes / sequence lengths must not accumulate forever
+            _ONES.clear()
         _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
     return _ONES[key]
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act
+from .nn_ops import BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, invalidate_conv_caches
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -89,8 +89,12 @@ class Encoder(nn.Module):
         self.stages = nn.Sequential(*blocks)
         # one kernel per step makes the bf16 working copies of all 3x3 filters (not a module, parameter or buffer: no state)
         self._filter_bank = ConvFilterBank([m for m in self.modules() if isinstance(m, (Conv3x3, Conv1x1))])
+        # load_state_dict copies into the parameters under no_grad: the cached bf16 / folded filters must not survive it
+        self.register_load_state_dict_post_hook(lambda module, incompatible: invalidate_conv_caches())
 
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            self._filter_bank.mark_stale()                     # training: the bank is rebuilt every forward, unconditionally
         x = self.stem(x)
         x = F.dropout(x, p=self.p_dropout, training=self.training)
         return self.stages(x)
@@ -183,3 +187,14 @@ class SeldCRNN(nn.Module):
     def forward(self, x):
         out = self.decoder(self.encoder(x))
         return {k: interpolate_tensor(v, self.ratio) for k, v in out.items()}
+
+    def load_reference_state_dict(self, sd, strict: bool = True):
+        """Load weights trained with the reference (``torch.load(ckpt)`` or its ``['state_dict']``, experiments/inference.py:
+        115-116): see salsa_amd/crnn/checkpoint.py."""
+        from .checkpoint import load_reference_state_dict
+        return load_reference_state_dict(self, sd, strict)
+
+    def reference_state_dict(self):
+        """This model's state dict under the reference's key names."""
+        from .checkpoint import reference_state_dict
+        return reference_state_dict(self)

@@ -294,7 +294,9 @@ def _conv_wide(x, w, add=None):
     return y
 
 
-_WIDE_TABLES = {}
+import collections  # noqa: E402
+_WIDE_TABLES = collections.OrderedDict()     # LRU, at most _WIDE_TABLES_MAX map shapes (ragged last batches / variable chunk
+_WIDE_TABLES_MAX = 12                        # lengths would otherwise grow device memory without bound); 3 shapes per model
 USE_HIP_CONV_WIDE_WRW = os.environ.get('SALSA_HIP_CONV_WIDE_WRW', '1') != '0'
 
 
@@ -312,6 +314,9 @@ def _wide_tables(N, H, W, device):
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_wide_tables failed (%d)' % rc)
         _WIDE_TABLES[key] = tuple(torch.from_numpy(a).to(device) for a in (vpos, inv, tb))
+        while len(_WIDE_TABLES) > _WIDE_TABLES_MAX:
+            _WIDE_TABLES.popitem(last=False)
+    _WIDE_TABLES.move_to_end(key)
     return _WIDE_TABLES[key]
 
 
@@ -579,7 +584,17 @@ def _bump_param_epoch(*_):
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
-_register_step_hook(_bump_param_epoch)
+_register_step_hook(_bump_param_epoch)   # (an import side effect: a process-global hook on EVERY optimizer's step())
+
+
+def invalidate_conv_caches(model=None):
+    """Declare every cached derivative of the convolution / BatchNorm parameters stale (the bf16 filter bank, the folded
+    inference filters): the next forward rebuilds them.  The caches notice optimizer steps (any torch optimizer),
+    ``load_state_dict`` (a post-hook on the encoder), in-place tensor operations that bump version counters and moved storages
+    by themselves.  What they CANNOT see is an update that goes through none of those: ``p.data.copy_(...)`` / ``p.data.mul_``
+    (``.data`` has its own version counter), an EMA weight swap written that way, or a raw-pointer / custom-kernel updater.
+    Call this after such an update.  ``model`` is accepted for symmetry with torch APIs; the epoch is process-global."""
+    _bump_param_epoch()
 
 
 class ConvFilterBank:
@@ -626,6 +641,12 @@ class ConvFilterBank:
             raise RuntimeError('salsa_nn_conv_filter_bank failed (%d)' % rc)
         self._versions = [c.weight._version for c in self.convs]
         self._epoch = _PARAM_EPOCH[0]
+
+    def mark_stale(self):
+        """Force a refresh at the next request (the encoder calls this at the start of every TRAINING forward: one ~10-us launch
+        per step buys independence from any invalidation protocol where it matters most -- a bank that silently stayed on old
+        weights trains on them with no error)."""
+        self._epoch = -1
 
     def filters(self, i):
         """(forward filter, data-gradient filter) of layer i as bf16 channels-last views, refreshed if its weight changed."""

@@ -1,4 +1,5 @@
-"""Training step of the SELD CRNN on PyTorch-ROCm: bf16 autocast, channels-last convolutions (MIOpen), Adam with the
+"""Training step of the SELD CRNN on PyTorch-ROCm: bf16 autocast, channels-last activations, every convolution / BatchNorm /
+pool / GRU scan on the hand-written HIP kernels of salsa_amd/csrc (MIOpen only if they are switched off), Adam with the
 reference's piecewise-linear learning-rate schedule (utilities/learning_utils.py:17-52, experiments/configs/seld.yml:
 37-52), and data parallelism as one process per GPU with torch DDP = bucketed gradient all-reduce on RCCL over xGMI,
 overlapped with the backward pass (the reference only has Lightning's implicit ddp_spawn, experiments/train.py:98).

@@ -180,8 +180,10 @@ class SalsaExtractor:
         return (out, gate) if return_gate else out
 
     # ------------------------------------------------------------------------------------------------ timing
-    def set_timing(self, enable: bool):
-        self.L.salsa_plan_set_timing(self._plan, int(bool(enable)))
+    def set_timing(self, enable):
+        """False / 0: off.  True / 1: an event pair around every launch.  K > 1: every kernel of a call is launched K times back
+        to back between one event pair and read_timing() reports elapsed / K (no event between launches)."""
+        self.L.salsa_plan_set_timing(self._plan, int(enable))
 
     def set_scaler(self, mean=None, std=None):
         """Attach (or detach with None) the feature scaler: extract() then returns the spectrogram channels already

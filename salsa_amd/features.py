@@ -19,6 +19,9 @@ import yaml
 
 from . import io as sio
 
+import logging  # noqa: E402
+_log = logging.getLogger('salsa_amd.features')
+
 
 def _torch():
     import torch
@@ -87,7 +90,7 @@ class MagStftExtractor:
 def compute_scaler(feature_dir: str, audio_format: str) -> None:
     """Mean / std of the 4 spectrogram channels over ALL files of <audio_format>_dev -> <audio_format>_feature_scaler
     (datasets 'mean', 'std', shape (4,1,F) float32).  Mirrors :204-262 (StandardScaler.partial_fit: population std)."""
-    print('============> Start calculating scaler')
+    _log.info('scaler: streaming mean / std over %s_dev', audio_format)
     start_time = timer()
     train_feature_dir = os.path.join(feature_dir, audio_format + '_dev')
     feature_fn_list = sio.feature_files(train_feature_dir)
@@ -107,9 +110,8 @@ def compute_scaler(feature_dir: str, audio_format: str) -> None:
     feature_std = np.sqrt(np.maximum(ss / n - (s / n) ** 2, 0.0))[:, None, :]
     scaler_path = os.path.join(feature_dir, audio_format + '_feature_scaler.h5')
     written = sio.save_arrays(scaler_path, mean=feature_mean, std=feature_std)
-    print('Features shape: {}'.format(afeature.shape))
-    print('Scaler path: {}'.format(written))
-    print('Elapsed time: {:.3f} s'.format(timer() - start_time))
+    _log.info('scaler: %d files x %s -> %s', len(feature_fn_list), afeature.shape, written)
+    _log.info('scaler: %.3f s', timer() - start_time)
 
 
 def _parse(data_config):
@@ -145,7 +147,7 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
         feats = ex.extract(torch.from_numpy(batch).cuda()).cpu().numpy()
         for (count, fn, _), f in zip(items, feats):
             sio.save_arrays(os.path.join(feature_dir, feature_name(fn)), feature=f)
-            print('{}, {}, {}'.format(count, fn, f.shape))
+            _log.debug('clip %d %s -> %s', count, fn, f.shape)
 
     for count, audio_fn in todo:
         audio_input = sio.load_audio(os.path.join(audio_dir, audio_fn), sr=fs)
@@ -185,19 +187,19 @@ def extract_features(data_config: str = 'configs/tnsse2021_salsa_feature_config.
         splits = ['mic_dev', 'mic_eval']
     else:
         raise ValueError('Unknown audio format {}'.format(audio_format))
-    print('Feature description: {}'.format(feature_description))
+    _log.info('feature directory name: %s', feature_description)
     if task in ['feature_scaler', 'feature']:
         from .extractor import SalsaExtractor
         ex = SalsaExtractor(fs=fs, n_fft=n_fft, hop_len=hop_length, win_len=win_length, fmin_doa=fmin_doa,
                             fmax_doa=fmax_doa, cond_num=cond_num, n_hopframes=n_hopframes, is_tracking=is_tracking,
                             is_compress_high_freq=is_compress_high_freq, audio_format=audio_format)
         for split in splits:
-            print('============> Start extracting features for {} split'.format(split))
+            _log.info('split %s: extracting on %s', split, ex.device)
             start_time = timer()
             audio_dir = os.path.join(cfg['data_dir'], split)
             feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description, split)
             _extract_split(ex, audio_dir, feature_dir, fs, batch_size)
-            print('Extracting feature finished! Elapsed time: {:.3f} s'.format(timer() - start_time))
+            _log.info('split %s: done in %.3f s', split, timer() - start_time)
     if task in ['feature_scaler', 'scaler']:
         feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
         compute_scaler(feature_dir=feature_dir, audio_format=audio_format)
@@ -214,4 +216,5 @@ def _cli(fn, argv):
 
 
 if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO, format='%(message)s')      # progress lines on the console, as a CLI should
     _cli(extract_features, sys.argv[1:])

@@ -9,6 +9,9 @@ import numpy as np
 
 from .features import _cli, _extract_split, _parse, compute_scaler
 
+import logging  # noqa: E402
+_log = logging.getLogger('salsa_amd.features')
+
 
 def extract_features(data_config: str = 'configs/tnsse2021_salsa_lite_feature_config.yml',
                      feature_type: str = 'salsa_lite',
@@ -18,7 +21,7 @@ def extract_features(data_config: str = 'configs/tnsse2021_salsa_lite_feature_co
     cfg, audio_format, fs, n_fft, hop_length, win_length, fmin_doa, fmax_doa = _parse(data_config)
     fmax_doa = int(np.min((fmax_doa, fs // 2)))
     feature_description = '{}fs_{}nfft_{}nhop_{}fmaxdoa'.format(fs, n_fft, hop_length, int(fmax_doa))
-    print('Feature description: {}'.format(feature_description))
+    _log.info('feature directory name: %s', feature_description)
     assert audio_format == 'mic', 'SALSA-Lite and SALSA-IPD are only for MIC format!'
     splits = ['mic_dev', 'mic_eval']
     if task in ['feature_scaler', 'feature']:
@@ -26,16 +29,17 @@ def extract_features(data_config: str = 'configs/tnsse2021_salsa_lite_feature_co
         ex = SalsaExtractor(fs=fs, n_fft=n_fft, hop_len=hop_length, win_len=win_length, fmin_doa=fmin_doa,
                             fmax_doa=fmax_doa, audio_format='mic', feature_type=feature_type)
         for split in splits:
-            print('============> Start extracting features for {} split'.format(split))
+            _log.info('split %s: extracting on %s', split, ex.device)
             start_time = timer()
             audio_dir = os.path.join(cfg['data_dir'], split)
             feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description, split)
             _extract_split(ex, audio_dir, feature_dir, fs, batch_size)
-            print('Extracting feature finished! Elapsed time: {:.3f} s'.format(timer() - start_time))
+            _log.info('split %s: done in %.3f s', split, timer() - start_time)
     if task in ['feature_scaler', 'scaler']:
         feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
         compute_scaler(feature_dir=feature_dir, audio_format=audio_format)
 
 
 if __name__ == '__main__':
+    logging.basicConfig(level=logging.INFO, format='%(message)s')      # progress lines on the console, as a CLI should
     _cli(extract_features, sys.argv[1:])

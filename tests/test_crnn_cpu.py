@@ -35,6 +35,62 @@ def test_forward_matches_reference_model():
     assert out['event_frame_logit'].shape == (2, 8, 12)              # 64 frames -> /16 -> x2 (label rate)
 
 
+def test_reference_checkpoint_round_trip():
+    """Weights under the REFERENCE's key names (fixture g14: the reference SeldModel's own state-dict keys and shapes) load
+    into SeldCRNN through the product loader -- as the whole Lightning-style checkpoint dict the reference reads at
+    experiments/inference.py:115-116 -- and reproduce the reference model's outputs (g9); strict both ways."""
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn.testing import seeded_fill
+    meta, a = load_golden('g9_crnn')
+    ref_keys, _ = load_golden('g14_ref_state_dict_keys')
+    src = SeldCRNN()
+    seeded_fill(src, meta['weight_seed'])
+    sd = src.reference_state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == ref_keys['keys']            # exactly the reference's keys and shapes
+    dst = SeldCRNN()
+    missing, unexpected = dst.load_reference_state_dict({'state_dict': {k: v.clone() for k, v in sd.items()}, 'epoch': 3})
+    assert missing == [] and unexpected == []
+    dst.eval()
+    x = torch.randn(*meta['input_shape'], generator=torch.Generator().manual_seed(meta['input_seed']))
+    with torch.no_grad():
+        out = dst(x)
+    np.testing.assert_allclose(out['event_frame_logit'].numpy(), a['event_frame_logit'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out['doa_frame_output'].numpy(), a['doa_frame_output'], rtol=1e-4, atol=1e-5)
+    # strict both ways: a key of ours left uncovered, a key we do not know, a wrong shape
+    short = dict(sd)
+    short.pop('encoder.conv_block1.conv1.weight')
+    with pytest.raises(RuntimeError, match='missing'):
+        SeldCRNN().load_reference_state_dict(short)
+    extra = dict(sd, **{'encoder.fc.weight': torch.zeros(3)})
+    with pytest.raises(RuntimeError, match='unexpected'):
+        SeldCRNN().load_reference_state_dict(extra)
+    wrong = dict(sd, **{'decoder.event_fc_2.bias': torch.zeros(13)})
+    with pytest.raises(RuntimeError, match='shape'):
+        SeldCRNN().load_reference_state_dict(wrong)
+    m, u = SeldCRNN().load_reference_state_dict(extra, strict=False)
+    assert m == [] and u == ['encoder.fc.weight']
+    # DDP / LightningModule-wrapped checkpoints: a common prefix is stripped
+    SeldCRNN().load_reference_state_dict({'module.' + k: v for k, v in sd.items()})
+
+
+def test_conv_cache_invalidation_hooks():
+    """load_state_dict bumps the cache epoch (post-hook on the encoder) and invalidate_conv_caches() is the explicit handle for
+    updates nothing can observe (p.data.copy_, raw-pointer updaters)."""
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn import nn_ops
+    m = SeldCRNN()
+    e0 = nn_ops._PARAM_EPOCH[0]
+    m.load_state_dict(m.state_dict())
+    assert nn_ops._PARAM_EPOCH[0] > e0
+    e1 = nn_ops._PARAM_EPOCH[0]
+    nn_ops.invalidate_conv_caches(m)
+    assert nn_ops._PARAM_EPOCH[0] > e1
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    e2 = nn_ops._PARAM_EPOCH[0]
+    opt.step()
+    assert nn_ops._PARAM_EPOCH[0] > e2
+
+
 def test_training_chunk_shapes():
     from salsa_amd.crnn import SeldCRNN
     m = SeldCRNN().eval()
@@ -179,3 +235,58 @@ def test_two_rank_sharded_inference_matches_single_process(tmp_path):
     featurize = lambda group: torch.stack([torch.randn(7, 128, 200, generator=torch.Generator().manual_seed(int(n[4:]))) for n in group])
     solo = infer_clips_sharded(sorted(r0), featurize, forward, 0, 1, sub_batch=5, sed_threshold=0.5, n_label_frames=16)
     assert solo == r0 and any(len(v) > 0 for v in solo.values())
+
+
+def test_self_spawn_builds_the_launcher_command(monkeypatch):
+    """`python bench.py --gpus 2 ...` with no torch.distributed environment re-executes itself under torch.distributed.run: the
+    argv must be the driver's own launch line (one rank per GPU, loopback rendezvous) with the script's arguments preserved;
+    inside a launcher (WORLD_SIZE set) or at --gpus 1 it must return without spawning."""
+    import bench_crnn
+    calls = []
+    monkeypatch.setattr(os, 'execv', lambda exe, argv: calls.append((exe, list(argv))))
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3'])
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        monkeypatch.delenv(k, raising=False)
+    script = os.path.join(ROOT, 'bench.py')
+    bench_crnn.self_spawn(2, script)
+    assert len(calls) == 1
+    exe, argv = calls[0]
+    assert exe == sys.executable and argv[0] == sys.executable and argv[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in argv and argv[argv.index('--nproc-per-node') + 1] == '2'
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1'
+    port = int(argv[argv.index('--master-port') + 1])
+    assert 1024 <= port < 65536
+    i = argv.index(script)
+    assert argv[i + 1:] == ['--gpus', '2', '--steps', '3']                  # the script's own flags, untouched
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'              # dmabuf IPC for RCCL on this host driver
+    calls.clear()
+    bench_crnn.self_spawn(1, script)                                          # single GPU: nothing to spawn
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    bench_crnn.self_spawn(2, script)                                          # already a rank of a launcher
+    assert calls == []
+
+
+def _train_bench_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench_crnn
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    line = bench_crnn.train_bench(rank, world, 'cpu', batch=2, steps=2, warmup=1, n_frames=64, amp_dtype=None, fp32_grads=True)
+    torch.save(line, os.path.join(tmp, 'line%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_bench_ddp_branch_under_gloo(tmp_path):
+    """bench.py's CRNN leg itself (bench_crnn.train_bench) at world size 2 on gloo: the DDP wrap without the bf16 compression
+    hook, the barrier-bracketed timed region, MAX over ranks, and the rank-0-only result line with the aggregate rate."""
+    port = _free_port()
+    mp.spawn(_train_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    l0, l1 = torch.load(tmp_path / 'line0.pt'), torch.load(tmp_path / 'line1.pt')
+    assert l1 is None                                                         # only rank 0 reports
+    assert l0['n_gpus'] == 2 and l0['rccl_ranks'] == 2 and l0['backend'] == 'gloo' and l0['scaling'] == 'weak'
+    assert l0['config']['parallelism'] == 'dp2' and l0['config']['grad_allreduce'] == 'fp32'
+    assert l0['value'] > 0 and np.isfinite(l0['final_loss'])
+    assert abs(l0['value'] - 2 * 2 * 2 / (l0['ms_per_step'] * 2 / 1e3)) / l0['value'] < 1e-2   # whole-job chunks / max-rank time

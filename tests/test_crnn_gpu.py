@@ -1,5 +1,6 @@
-"""GPU tests of the CRNN consumer (MIOpen / rocBLAS through torch): forward against the reference-model golden, and a
-few bf16 training steps that must reduce the loss on a fixed batch."""
+"""GPU tests of the CRNN consumer (hand-written HIP layers behind include/salsa_nn.h / salsa_gru.h; torch supplies autograd,
+the decoder GEMMs and the optimizer): forward against the reference-model golden, every kernel against float32 torch
+operators incl. gradients, and bf16 training steps that must reduce the loss on a fixed batch."""
 import numpy as np
 import pytest
 import torch
@@ -488,7 +489,7 @@ def test_register_resident_gru_training_scan_gradients():
 def test_wide_conv_kernel_matches_torch_forward_and_gradients():
     """salsa_nn_conv3x3_wide (flattened-pixel implicit GEMM, conv_wide.hip) against float32 F.conv2d on the bf16-rounded
     operands: every channel pairing of the residual stages, map widths 50 / 25 / 12, batches whose 512-pixel tiles straddle
-    image boundaries and end ragged; forward and data gradient (the weight gradient is MIOpen's)."""
+    image boundaries and end ragged; forward, data gradient and the hand-written weight gradient (salsa_nn_conv3x3_wide_wrw)."""
     import torch.nn.functional as F
     from salsa_amd.crnn import nn_ops
     dev = torch.device('cuda:0')

@@ -79,6 +79,50 @@ def test_on_the_fly_mic_chunks_against_oracle(dev, oracle):
         _check(feats[i].cpu().numpy(), ref, aux['margin'])
 
 
+def test_config4_on_the_fly_augmented_training_leg(dev, oracle):
+    """BASELINE config 4's per-step path, link by link (reference: SeldDataset.__getitem__ dataset/dataloader.py:37-62 under
+    datamodule.py:137-142 into training_step models/seld_models.py:68-76), exactly as bench.py's `config4` leg runs it:
+    (1) raw 8-s MIC chunks -> SALSA-MIC on device, each chunk equal to the oracle, and with the scaler attached equal to the
+        oracle's features normalised on load (database.py:197-202);
+    (2) the 640-frame crop (a strided view, no copy) -> augment_batch with a fixed generator: the one-pass HIP kernel equals
+        the torch-operator composite of the same draws bit for bit, and so do the targets;
+    (3) ten optimizer steps on that fixed augmented batch reduce the loss."""
+    from salsa_amd.augment import apply_augment_torch, augment_batch, draw_augment
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+    B = 4
+    ys = np.stack([synth_clip(4021 + i, 8 * 24000) for i in range(B)])
+    ex = _extractor(audio_format='mic', fmax_doa=4000)
+    a = torch.from_numpy(ys).to(dev)
+    raw = ex.extract(a).clone()
+    refs = []
+    for i in range(B):
+        ref, aux = oracle.extract_salsa(ys[i], fmax_doa=4000, audio_format='mic', return_aux=True)
+        _check(raw[i].cpu().numpy(), ref, aux['margin'])
+        refs.append(ref)
+    mean = torch.full((4, 1, 200), -60.0, device=dev)
+    std = torch.full((4, 1, 200), 12.0, device=dev)
+    ex.set_scaler(mean, std)
+    feats = ex.extract(a)
+    assert feats.shape == (B, 7, 641, 200)
+    want = raw.clone()
+    want[:, :4] = (raw[:, :4] - mean) / std
+    np.testing.assert_allclose(feats.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    x = feats[:, :, :640]                                                  # the trainer's crop: a view with its own strides
+    assert not x.is_contiguous()
+    _, sed, doa = synthetic_batch(B, dev, seed=7)
+    # (2) same generator state -> same draws -> the kernel must equal the torch composite
+    xa, sa, da = augment_batch(x, sed, doa, 'mic', gen=torch.Generator().manual_seed(99))
+    d = draw_augment(B, 640, 200, 'mic', torch.Generator().manual_seed(99))
+    xt, dt = apply_augment_torch(x.contiguous(), doa, d, 'mic')
+    assert torch.equal(xa, xt) and torch.equal(da, dt) and torch.equal(sa, sed)
+    assert not torch.equal(xa, x.contiguous())                             # the draws did something
+    assert bool((d['h'] > 0).any()) and bool((d['m'] > 0).any() or (d['shift'] > 0).any())
+    # (3) the step itself
+    tr = Trainer(dev, total_steps=100)
+    losses = [float(tr.train_step(xa, sa, da)[0]) for _ in range(10)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 def test_decibel_conversion_error_bound(dev):
     """10*log10(max(1e-10, p)) in the STFT kernel is 3.0103 * v_log_f32(p): sweep EVERY float32 exponent with a dense
     mantissa grid (plus the neighbours of 1.0 and of the 1e-10 clamp) against float64.  Bar: the reference's own float32

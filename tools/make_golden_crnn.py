@@ -57,3 +57,13 @@ path = os.path.join(ROOT, 'tests', 'golden', 'g9_crnn.npz')
 np.savez_compressed(path, meta=np.array(json.dumps({'weight_seed': 7, 'input_seed': 11, 'input_shape': [2, 7, 64, 200]})),
                     event_frame_logit=ev.numpy(), doa_frame_output=doa.numpy())
 print(path, ev.shape, doa.shape, float(ev.abs().mean()), float(doa.abs().mean()))
+
+# the reference model's own state-dict keys and shapes (names only -- data, not source): pins salsa_amd/crnn/checkpoint.py's
+# key map to what a reference checkpoint (experiments/inference.py:115-116, checkpoint['state_dict']) really contains
+ref_keys = {}
+for prefix, mod in (('encoder.', enc), ('decoder.', dec)):
+    for k, v in mod.state_dict().items():
+        ref_keys[prefix + k] = list(v.shape)
+kpath = os.path.join(ROOT, 'tests', 'golden', 'g14_ref_state_dict_keys.npz')
+np.savez_compressed(kpath, meta=np.array(json.dumps({'keys': ref_keys, 'source': 'PannResNet22(n_input_channels=7) + SeldDecoder(512, 12, reg_xyz, bigru, avg, 256) state_dict() under the SeldModel attribute names encoder / decoder'})))
+print(kpath, len(ref_keys), 'keys')
