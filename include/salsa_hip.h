@@ -153,6 +153,9 @@ int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_c
  * back between ONE event pair (each kernel is idempotent on the audio / spill / mask buffers, so the results are those of
  * a plain call) and reports elapsed / K: the per-launch average without an event between launches, which is what a
  * rocprofv3 kernel trace of the plain call shows (an event pair around a single launch inflates it by ~12 %).
+ * enable = -1 / -2 (measurement only, no events): salsa_extract_batch issues only a PREFIX of the path -- the STFT launch
+ * alone / STFT + tracker -- on the buffers a full call left behind, so a caller can time prefixes of the real launch
+ * sequence with its own clock and attribute the step to its kernels by differences that add up to the step exactly.
  * salsa_plan_read_timing synchronises on the events and returns the milliseconds per launch of the last call's kernels
  * in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */
 #define SALSA_MAX_KERNELS 32

@@ -681,14 +681,18 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     // :111-112 the coherence test only gates when tracking -- except in contrib, whose test always gates (:352-354)
     const bool ungated = !kp.tracking && !kp.flex;
     auto solve_emit = [&](const salsa::herm4<double> &R, int t, int bin) {
-        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, ungated);
+        const bool foa = kp.format == SALSA_FORMAT_FOA;
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, ungated, !foa);
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || ungated) {
             const int k = bin + kp.lower;
             // delta*k (:121-123); contrib divides by a float32 frequency vector with [0] = 1 (:188-190)
             const double den = kp.flex ? (double)((float)(k == 0 ? 1 : k) * (float)kp.delta) : kp.delta * (double)k;
-            if (kp.format == SALSA_FORMAT_FOA) salsa::normalise_foa(er.u, e, ungated);
+            if (er.col0) { // gated fast path: column 0 of the adjugate, real pivot (salsa_math.h)
+                if (foa) salsa::normalise_foa_col0(er.u, e);
+                else salsa::normalise_mic_col0(er.u, den, e);
+            } else if (foa) salsa::normalise_foa(er.u, e, ungated);
             else salsa::normalise_mic(er.u, den, e);
             g = 2;
         } else if (FEAT && kp.flex && !kp.tracking) {
@@ -1097,6 +1101,7 @@ struct salsa_plan {
     cplx<double> *d_tw;
     const float *sc_mean, *sc_std; // caller-owned device arrays set by salsa_plan_set_scaler (or NULL)
     int timing;
+    int stop_after; // measurement only: 1 = issue the STFT launch alone, 2 = STFT + tracker, 0 = the whole path (salsa_plan_set_timing(plan, -1 | -2))
     int n_kernels;
     hipEvent_t ev0[SALSA_MAX_KERNELS], ev1[SALSA_MAX_KERNELS]; // start/stop of each launch (timing mode only)
     const char *names[SALSA_MAX_KERNELS];
@@ -1459,7 +1464,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         int rc = SALSA_OK;
         for (int r = 0; r < reps && !rc; r++) rc = launch_stft(pl, gp, a, o, xs, s1);
         mark_end(pl, s1, m);
-        if (rc || !full) return rc;
+        if (rc || !full || pl->stop_after == 1) return rc;
         if (s1 != s2) {
             HIP_TRY(hipEventRecord(after_first, s1));
             HIP_TRY(hipStreamWaitEvent(s2, after_first, 0));
@@ -1484,6 +1489,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
             mark_end(pl, s2, m);
             HIP_TRY(hipGetLastError());
         }
+        if (pl->stop_after == 2) return SALSA_OK;
         if (two && s1 != s2) HIP_TRY(hipStreamWaitEvent(s2, after_second, 0));
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
@@ -1499,7 +1505,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         return SALSA_OK;
     };
-    const bool piped = full && !pl->timing && kp.nd > 0 && (pl->n_groups > 1 || (pl->pipe_flags & SALSA_PIPE_SPLIT_PAIRS));
+    const bool piped = full && !pl->timing && !pl->stop_after && kp.nd > 0 && (pl->n_groups > 1 || (pl->pipe_flags & SALSA_PIPE_SPLIT_PAIRS));
     if (!piped) return run_group(0, batch, s, s, nullptr, nullptr, false);
     const int G = batch < pl->n_groups ? batch : pl->n_groups;
     const bool split = (pl->pipe_flags & SALSA_PIPE_SPLIT_PAIRS) != 0;
@@ -1675,6 +1681,7 @@ int salsa_plan_set_timing(salsa_plan *pl, int enable)
 {
     if (!pl) return fail(SALSA_EINVAL, "salsa_plan_set_timing: NULL plan%s");
     pl->timing = enable > 0 ? enable : 0; // 1: an event pair around every launch; K > 1: K launches per event pair
+    pl->stop_after = enable < 0 ? (enable >= -2 ? -enable : 0) : 0; // -1 / -2: plain issue of a PREFIX of the path (no events)
     pl->n_kernels = 0;
     return SALSA_OK;
 }

@@ -276,6 +276,7 @@ template <typename T> struct eig_result {
     bool rank1;      // coherence test s0 > s1*cond (salsa_feature_extraction.py:106)
     T margin;        // diagnostic: q(mu1/cond) (negative = exactly one root above the threshold)
     cplx<T> u[4];    // principal eigenvector (arbitrary scale and phase); valid when computed
+    bool col0;       // u is column 0 of adj(A - mu1 I): u[0] is REAL (its imaginary part is exactly 0)
 };
 
 // Gate + principal eigenvector of a Hermitian PSD 4x4 R (any positive scale).
@@ -290,10 +291,26 @@ template <typename T> struct eig_result {
 // is exactly one.
 // Eigenvector: a column of adj(A - mu1 I) = prod_{i>=2}(mu_i - mu1) u u^H (again from 2x2 minors), taking the column
 // with the largest diagonal cofactor.  Exact for any spectral gap (also with tracking off, where nothing gates it).
-template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, bool need_vector_always)
+//
+// Gated fast path (round 3).  A bin that passed the gate has a simple mu1 with gap mu1 - mu2 > (1 - 1/cond) mu1, so
+// adj(A - mu1 I) = prod_{i>=2}(mu_i - mu1) u u^H is a well-scaled rank-1 matrix and ANY column whose pivot u_j is not tiny
+// is an accurate eigenvector.  Column 0 needs one real and three complex cofactors (6 of the 12 shifted minors) instead of
+// four diagonal cofactors, an arg-max and six complex cofactors folded through selects; its pivot adj_00 = prod * |u_0|^2 is
+// REAL, which the FOA / MIC normalisations use (Re(u_i conj(u_0)) = adj_00 Re(u_i)).  Taken when |adj_00| >= SALSA_COL0_MIN
+// on the trace-1..2 scale (relative error of the column <~ 1e-15 / |adj_00|); smaller pivots (u_0 ~ 0: the FOA feature is
+// ill-conditioned there anyway) and the ungated mode (no gap guarantee) take the general arg-max path below, unchanged.
+#ifndef SALSA_COL0_MIN
+#define SALSA_COL0_MIN 1e-6
+#endif
+#ifndef SALSA_COL0
+#define SALSA_COL0 1
+#endif
+template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, bool need_vector_always,
+                                                               bool want_imag = true)
 {
     eig_result<T> res;
     res.rank1 = false;
+    res.col0 = false;
     res.margin = 0;
     res.u[0] = {(T)1, (T)0};
     res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
@@ -362,6 +379,33 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     herm4<T> B = A;
 #pragma unroll
     for (int i = 0; i < 4; i++) B.d[i] -= mu1;
+    if (SALSA_COL0 && !need_vector_always) {
+        const cplx<T> a01 = A.o[0], a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4], a23 = A.o[5];
+        const T c5 = B.d[2] * B.d[3] - (a23.re * a23.re + a23.im * a23.im);
+        const cplx<T> c4 = {m.c4.re - mu1 * a12.re, m.c4.im + mu1 * a12.im}; // conj(a12) (a33-mu) - a31 a23
+        const cplx<T> c3 = {m.c3.re + mu1 * a13.re, m.c3.im - mu1 * a13.im}; // a21 a32 - conj(a13) (a22-mu)
+        const T p00 = B.d[1] * c5 - re_mul(a12, c4) + re_mul(a13, c3);       // adj_00 = b11 c5 - b12 c4 + b13 c3
+        if (fabs(p00) >= (T)SALSA_COL0_MIN) {
+            const cplx<T> s3 = {m.s3.re + mu1 * a02.re, m.s3.im + mu1 * a02.im}; // a01 a12 - (a11-mu) a02
+            const cplx<T> s4 = {m.s4.re + mu1 * a03.re, m.s4.im + mu1 * a03.im}; // a01 a13 - (a11-mu) a03
+            const cplx<T> s5 = m.s5;
+            // adj_0b (b = 1..3), as in the general path; column 0 is u_b = adj_b0 = conj(adj_0b)
+            //   adj_01 = -b01 c5 + b02 c4 - b03 c3 ; adj_02 = conj(b13) s5 - conj(b23) s4 + b33 s3 ; adj_03 = b22 s4 - conj(b12) s5 - b23 s3
+            res.u[0] = {p00, (T)0};
+            res.u[1].re = re_mul(a02, c4) - c5 * a01.re - re_mul(a03, c3);
+            res.u[2].re = re_mul(cconj(a13), s5) - re_mul(cconj(a23), s4) + B.d[3] * s3.re;
+            res.u[3].re = B.d[2] * s4.re - re_mul(cconj(a12), s5) - re_mul(a23, s3);
+            if (want_imag) { // -Im(adj_0b)
+                res.u[1].im = -((a02.re * c4.im + a02.im * c4.re) - c5 * a01.im - (a03.re * c3.im + a03.im * c3.re));
+                res.u[2].im = -((a13.re * s5.im - a13.im * s5.re) - (a23.re * s4.im - a23.im * s4.re) + B.d[3] * s3.im);
+                res.u[3].im = -(B.d[2] * s4.im - (a12.re * s5.im - a12.im * s5.re) - (a23.re * s3.im + a23.im * s3.re));
+            } else {
+                res.u[1].im = res.u[2].im = res.u[3].im = (T)0;
+            }
+            res.col0 = true;
+            return res;
+        }
+    }
     minors4<T> n = m;
     {
         const cplx<T> a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4];
@@ -431,6 +475,25 @@ template <typename T> SALSA_HD void normalise_foa(const cplx<T> *u, T *e, bool r
     const T inv = (T)refined_rsqrt((double)ss);
 #pragma unroll
     for (int i = 0; i < 3; i++) e[i] = e[i] * inv;
+}
+
+// FOA from a column-0 eigenvector (eig_result::col0): u_0 = adj_00 is real, so Re(u_i conj(u_0)) = adj_00 Re(u_i) and the
+// unit vector is sign(adj_00) Re(u[1:4]) / ||Re(u[1:4])||.  |adj_00| >= SALSA_COL0_MIN keeps everything O(1e-6..1): no rescale.
+template <typename T> SALSA_HD void normalise_foa_col0(const cplx<T> *u, T *e)
+{
+    const T ss = u[1].re * u[1].re + u[2].re * u[2].re + u[3].re * u[3].re;
+    T inv = (T)refined_rsqrt((double)ss);
+    if (u[0].re < (T)0) inv = -inv;
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = u[i + 1].re * inv;
+}
+
+// MIC from a column-0 eigenvector: angle(u_i conj(u_0)) = angle(sign(adj_00) u_i).
+template <typename T> SALSA_HD void normalise_mic_col0(const cplx<T> *u, T dk, T *e)
+{
+    const T sg = u[0].re < (T)0 ? (T)-1 : (T)1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = atan2(sg * u[i + 1].im, sg * u[i + 1].re) / dk;
 }
 
 // MIC: angle(u[1:]*conj(u[0])) / (delta*k) (salsa_feature_extraction.py:121-123); dk = delta*(ibin+lower_bin).

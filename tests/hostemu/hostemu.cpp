@@ -96,11 +96,14 @@ int hostemu_eigvec(const float *X, int nb, long nt, double cond, int n_hop, int 
                 for (int c = 0; c < 4; c++) x[c] = {(double)Xb[tt * 8 + 2 * c], (double)Xb[tt * 8 + 2 * c + 1]};
                 herm4_rank1_add(R, x);
             }
-            eig_result<double> er = herm4_gate_eigvec(R, cond, 1.0 / cond, !tracking);
+            eig_result<double> er = herm4_gate_eigvec(R, cond, 1.0 / cond, !tracking, format != 0);
             rank[(size_t)b * nt + t] = er.rank1 ? 2 : 1;
             if (tracking && !er.rank1) continue;
             double e[3];
-            if (format == 0) normalise_foa(er.u, e, !tracking);
+            if (er.col0) { // the kernel's gated fast path
+                if (format == 0) normalise_foa_col0(er.u, e);
+                else normalise_mic_col0(er.u, delta * (double)(b + lower_bin), e);
+            } else if (format == 0) normalise_foa(er.u, e, !tracking);
             else normalise_mic(er.u, delta * (double)(b + lower_bin), e);
             for (int i = 0; i < 3; i++) out[((size_t)i * nb + b) * nt + t] = e[i];
         }
@@ -122,6 +125,44 @@ int hostemu_solve(const double *d, const double *o, double cond, int need_vec, i
     eig_result<double> er = herm4_gate_eigvec(R, cond, cond > 0 ? 1.0 / cond : 0.0, need_vec != 0);
     *rank1 = er.rank1 ? 1 : 0;
     for (int i = 0; i < 4; i++) { u[2 * i] = er.u[i].re; u[2 * i + 1] = er.u[i].im; }
+    return 0;
+}
+}
+
+extern "C" {
+// The per-bin solve + normalisation as the kernel's emit path runs it, in float64 or (study only: DESIGN "precision policy")
+// with the whole solve instantiated in float32 on the float64-accumulated covariance.  gated != 0: the tracking-on mode (gate
+// decides, column-0 fast path allowed); returns rank1, whether the fast path was taken, and the 3 feature values.
+int hostemu_feature(const double *d, const double *o, double cond, int gated, int format, double dk, int use_f32, int *rank1,
+                    int *col0, double *e3)
+{
+    herm4<double> R;
+    for (int i = 0; i < 4; i++) R.d[i] = d[i];
+    for (int k = 0; k < 6; k++) R.o[k] = {o[2 * k], o[2 * k + 1]};
+    e3[0] = e3[1] = e3[2] = 0.0;
+    if (use_f32) {
+        herm4<float> Rf;
+        const double sc = pow2_unscale(R.d[0] + R.d[1] + R.d[2] + R.d[3]); // exact power of two: keep float32 in range
+        for (int i = 0; i < 4; i++) Rf.d[i] = (float)(R.d[i] * sc);
+        for (int k = 0; k < 6; k++) Rf.o[k] = {(float)(R.o[k].re * sc), (float)(R.o[k].im * sc)};
+        eig_result<float> er = herm4_gate_eigvec(Rf, (float)cond, (float)(1.0 / cond), !gated, format != 0);
+        *rank1 = er.rank1;
+        *col0 = er.col0;
+        if (gated && !er.rank1) return 0;
+        float e[3];
+        if (er.col0) { if (format == 0) normalise_foa_col0(er.u, e); else normalise_mic_col0(er.u, (float)dk, e); }
+        else if (format == 0) normalise_foa(er.u, e, !gated);
+        else normalise_mic(er.u, (float)dk, e);
+        for (int i = 0; i < 3; i++) e3[i] = e[i];
+        return 0;
+    }
+    eig_result<double> er = herm4_gate_eigvec(R, cond, 1.0 / cond, !gated, format != 0);
+    *rank1 = er.rank1;
+    *col0 = er.col0;
+    if (gated && !er.rank1) return 0;
+    if (er.col0) { if (format == 0) normalise_foa_col0(er.u, e3); else normalise_mic_col0(er.u, dk, e3); }
+    else if (format == 0) normalise_foa(er.u, e3, !gated);
+    else normalise_mic(er.u, dk, e3);
     return 0;
 }
 }

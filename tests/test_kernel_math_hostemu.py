@@ -190,3 +190,82 @@ def test_solver_stress_controlled_spectra(emu):
                     c = abs(np.vdot(q, uu)) / (np.linalg.norm(uu) + 1e-300)
                     assert c > 1 - 1e-9, (lam, scale, c)
 
+
+
+def _feature(emu, R, cond=5.0, gated=True, fmt='foa', dk=0.86, f32=False):
+    emu.hostemu_feature.argtypes = ([C.POINTER(C.c_double)] * 2 + [C.c_double, C.c_int, C.c_int, C.c_double, C.c_int] +
+                                    [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_double)])
+    d, o = _pack(R)
+    rank1, col0, e = C.c_int(), C.c_int(), np.zeros(3)
+    emu.hostemu_feature(_dp(d), _dp(o), cond, int(gated), 0 if fmt == 'foa' else 1, dk, int(f32), C.byref(rank1), C.byref(col0), _dp(e))
+    return bool(rank1.value), bool(col0.value), e
+
+
+def _ref_feature(R, fmt, dk):
+    w, v = np.linalg.eigh(R)
+    u = v[:, -1]
+    if fmt == 'foa':
+        e = np.real(u[1:] / u[0])
+        return e / np.sqrt((e ** 2).sum())
+    return np.angle(u[1:] * np.conj(u[0])) / dk
+
+
+def test_gated_column0_fast_path_equals_general_path_and_eigh(emu):
+    """Round 3's gated fast path (column 0 of adj(A - mu1 I), real pivot): on covariances that pass the gate it must give the
+    feature the general arg-max path gives and numpy's eigh gives, for FOA and MIC, any scale, any cond > 1; a tiny pivot
+    (u_0 ~ 0) must fall back to the general path; the ungated mode must never take it."""
+    rng = np.random.RandomState(21)
+    took, fell = 0, 0
+    for trial in range(400):
+        lam1 = 1.0
+        cond = [5.0, 2.0, 1.5, 20.0][trial % 4]
+        lam = np.array([lam1] + list(np.sort(rng.uniform(0, lam1 / cond * 0.98, 3))[::-1]))
+        Q, _ = np.linalg.qr(rng.randn(4, 4) + 1j * rng.randn(4, 4))
+        if trial % 5 == 0:                       # principal eigenvector with a (nearly) vanishing first component
+            q = Q[:, 0].copy()
+            q[0] *= [0.0, 1e-9, 1e-5, 1e-3][(trial // 5) % 4]
+            Q[:, 0] = q / np.linalg.norm(q)
+            Q, _ = np.linalg.qr(Q)               # re-orthonormalise keeping span{q0}
+        scale = [1.0, 1e-20, 4e+17, 3.3e-3][trial % 4]
+        R = (Q * (lam * scale)) @ Q.conj().T
+        R = (R + R.conj().T) / 2
+        u0 = abs(np.linalg.eigh(R)[1][0, -1])
+        for fmt in ('foa', 'mic'):
+            r1, c0, e = _feature(emu, R, cond, True, fmt)
+            r1g, c0g, eg = _feature(emu, R, cond, False, fmt)       # ungated = general path
+            assert r1 and r1g and not c0g
+            took += c0
+            fell += not c0
+            if u0 < 1e-4:
+                assert not c0 or u0 ** 2 * 0.1 > 1e-7               # small pivots fall back
+            ref = _ref_feature(R, fmt, 0.86)
+            if u0 > 1e-3:
+                tol = 1e-10 / u0 ** 2
+                assert np.abs(e - eg).max() < tol and np.abs(e - ref).max() < tol, (trial, fmt, u0, e, eg, ref)
+            elif not c0:
+                assert np.array_equal(e, eg) or (np.isnan(e) == np.isnan(eg)).all()   # same code path -> same bits
+    assert took > 500 and fell > 20, (took, fell)
+
+
+def test_float32_solve_misses_the_parity_bar(emu):
+    """The study behind DESIGN's precision policy ('try a certified mixed-precision solve'): the same solve
+    instantiated in float32 on the float64-accumulated covariance.  Its features miss the test bar (1e-6 + 1e-5 |ref|) on a
+    large share of the GATED bins -- the share that would have to be re-solved in float64 -- so a float32 first pass cannot pay
+    for itself; and non-packed float32 VALU issues at the float64 rate on gfx950 anyway."""
+    rng = np.random.RandomState(3)
+    n, miss, flips = 0, 0, 0
+    for trial in range(600):
+        X = (rng.randn(7, 4) + 1j * rng.randn(7, 4)) * 0.3
+        steer = rng.uniform(-1, 1, 4) * np.exp(1j * rng.uniform(-np.pi, np.pi, 4))
+        steer[0] = 1.0
+        X = X + (rng.randn(7, 1) + 1j * rng.randn(7, 1)) * rng.uniform(1, 6) * steer[None, :]
+        X = X.astype(np.complex64).astype(complex)
+        R = X.T @ X.conj()
+        r64, _, e64 = _feature(emu, R, 5.0, True, 'foa')
+        r32, _, e32 = _feature(emu, R, 5.0, True, 'foa', f32=True)
+        flips += r64 != r32
+        if r64 and r32:
+            n += 1
+            miss += bool((np.abs(e32 - e64) > 1e-6 + 1e-5 * np.abs(e64)).any())
+    assert n > 200
+    assert miss / n > 0.02, (miss, n, flips)        # float32 is NOT good enough: a measurable share misses the bar
