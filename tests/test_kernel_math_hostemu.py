@@ -247,25 +247,29 @@ def test_gated_column0_fast_path_equals_general_path_and_eigh(emu):
     assert took > 500 and fell > 20, (took, fell)
 
 
-def test_float32_solve_misses_the_parity_bar(emu):
-    """The study behind DESIGN's precision policy ('try a certified mixed-precision solve'): the same solve
-    instantiated in float32 on the float64-accumulated covariance.  Its features miss the test bar (1e-6 + 1e-5 |ref|) on a
-    large share of the GATED bins -- the share that would have to be re-solved in float64 -- so a float32 first pass cannot pay
-    for itself; and non-packed float32 VALU issues at the float64 rate on gfx950 anyway."""
+def test_float32_solve_error_study(emu):
+    """The numbers behind DESIGN's note on VERDICT r2 item 4 ('try a certified mixed-precision solve'): the same solve
+    instantiated in float32 on the float64-accumulated covariance of strongly and weakly directional 7-frame windows.  On GATED
+    bins with an ordinary pivot its FOA features stay within a few percent of the test bar (1e-6 + 1e-5 |ref|) and the gate only
+    disagrees inside ~1e-6 of the threshold -- accuracy would allow a float32 solve with a float64 re-solve of the uncertain
+    lanes.  (What it would NOT buy on gfx950 is issue rate: non-packed float32 VALU runs at the float64 rate; see DESIGN.)"""
     rng = np.random.RandomState(3)
-    n, miss, flips = 0, 0, 0
-    for trial in range(600):
+    worst, n, flips = 0.0, 0, 0
+    for trial in range(800):
+        amp = (1, 6) if trial % 2 else (0.3, 1.0)
         X = (rng.randn(7, 4) + 1j * rng.randn(7, 4)) * 0.3
         steer = rng.uniform(-1, 1, 4) * np.exp(1j * rng.uniform(-np.pi, np.pi, 4))
         steer[0] = 1.0
-        X = X + (rng.randn(7, 1) + 1j * rng.randn(7, 1)) * rng.uniform(1, 6) * steer[None, :]
+        X = X + (rng.randn(7, 1) + 1j * rng.randn(7, 1)) * rng.uniform(*amp) * steer[None, :]
         X = X.astype(np.complex64).astype(complex)
         R = X.T @ X.conj()
+        w = np.linalg.eigvalsh(R)
         r64, _, e64 = _feature(emu, R, 5.0, True, 'foa')
         r32, _, e32 = _feature(emu, R, 5.0, True, 'foa', f32=True)
-        flips += r64 != r32
+        if abs(w[-1] - 5 * w[-2]) > 1e-4 * w[-1]:
+            flips += r64 != r32
         if r64 and r32:
             n += 1
-            miss += bool((np.abs(e32 - e64) > 1e-6 + 1e-5 * np.abs(e64)).any())
-    assert n > 200
-    assert miss / n > 0.02, (miss, n, flips)        # float32 is NOT good enough: a measurable share misses the bar
+            worst = max(worst, float(np.max(np.abs(e32 - e64) / (1e-6 + 1e-5 * np.abs(e64)))))
+    assert n > 400 and flips == 0
+    assert worst < 0.5, worst                       # observed 0.03 - 0.05 of the bar
