@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsalsa_hip.so')
+LIB_PATH = os.environ.get('SALSA_HIP_LIB') or os.path.join(_HERE, 'lib', 'libsalsa_hip.so')   # (env override: A/B probes of kernel variants)
 SRC_PATH = os.path.join(_HERE, 'csrc', 'salsa_kernels.hip')
 GRU_SRC_PATH = os.path.join(_HERE, 'csrc', 'gru_scan.hip')
 NN_SRC_PATH = os.path.join(_HERE, 'csrc', 'nn_ops.hip')

@@ -21,6 +21,7 @@
 // Arithmetic types follow the reference (see DESIGN.md "Precision"): STFT evaluated in float64 and rounded to
 // float32, log-spectrogram in float32, tracker / covariance / eigen-solve in float64.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdio.h>
 #include <string.h>
 
@@ -555,7 +556,10 @@ constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins
 #define K3_XCD_CHUNK 16
 #endif
 
-template <bool FEAT, int NHOP>
+// FAST (round 3; tracking on, compile-time window): the work-list loop compiles ONLY the gate and the column-0 eigenvector
+// (salsa_math.h, PATH 1); a gated bin whose column-0 pivot is too small (u_0 ~ 0: rare) is pushed onto a second LDS list and
+// solved after the loop by the general arg-max path (PATH 2), one frame at a time.
+template <bool FEAT, int NHOP, bool FAST = false>
 __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned *__restrict__ valid32,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
@@ -565,7 +569,8 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     constexpr bool PAIRED = G > 1;
     static_assert(K3_FT % G == 0 && G <= 4 && K3_FT / G <= 16, "work-list entry layout");
     __shared__ unsigned short list[K3_FT * 256];
-    __shared__ int count;
+    __shared__ unsigned short slow[FAST ? K3_FT * 256 : 1]; // (frame in tile) << 8 | bin in block
+    __shared__ int count, nslow;
     // FEAT: the tile's channels 4-6 are assembled in LDS (zeros + the gated bins' results) and written out as whole rows with
     // 16-byte stores at the end, instead of one 4-byte store per lane per (channel, frame) for the zeros plus three scattered
     // 4-byte stores per result
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
     const int bin0 = blockIdx.z * 256;
     const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
-    if (tid == 0) count = 0;
+    if (tid == 0) count = 0, nslow = 0;
     if (FEAT) {
         for (int i = tid; i < 3 * K3_FT * K3_OW / 4; i += 256) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -680,26 +685,35 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
     const float4 *xclip = Xs + (long)b * Tn * stride;
     // :111-112 the coherence test only gates when tracking -- except in contrib, whose test always gates (:352-354)
     const bool ungated = !kp.tracking && !kp.flex;
-    auto solve_emit = [&](const salsa::herm4<double> &R, int t, int bin) {
+    auto solve_emit = [&](const salsa::herm4<double> &R, int t, int bin, auto path) {
+        constexpr int PATH = decltype(path)::value;
         const bool foa = kp.format == SALSA_FORMAT_FOA;
-        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec(R, kp.cond, kp.inv_cond, ungated, !foa);
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec<PATH>(R, kp.cond, kp.inv_cond, ungated, !foa);
+        if (PATH == 1 && er.fallback) { // passed the gate, pivot too small: the cold loop below takes it
+            slow[atomicAdd(&nslow, 1)] = (unsigned short)(((t - t0) << 8) | (bin - bin0));
+            return;
+        }
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || ungated) {
             const int k = bin + kp.lower;
             // delta*k (:121-123); contrib divides by a float32 frequency vector with [0] = 1 (:188-190)
             const double den = kp.flex ? (double)((float)(k == 0 ? 1 : k) * (float)kp.delta) : kp.delta * (double)k;
-            if (er.col0) { // gated fast path: column 0 of the adjugate, real pivot (salsa_math.h)
+            if (PATH != 2 && er.col0) { // gated fast path: column 0 of the adjugate, real pivot (salsa_math.h)
                 if (foa) salsa::normalise_foa_col0(er.u, e);
                 else salsa::normalise_mic_col0(er.u, den, e);
-            } else if (foa) salsa::normalise_foa(er.u, e, ungated);
-            else salsa::normalise_mic(er.u, den, e);
+            } else if (PATH != 1) {
+                if (foa) salsa::normalise_foa(er.u, e, ungated);
+                else salsa::normalise_mic(er.u, den, e);
+            }
             g = 2;
         } else if (FEAT && kp.flex && !kp.tracking) {
             e[0] = __builtin_nan(""); // marks "failed the test" for flex_allpass_kernel (a passing bin can be exactly 0)
         }
         emit(t, bin, e, g);
     };
+    using hot_path = std::integral_constant<int, FAST ? 1 : 2>;
+    using cold_path = std::integral_constant<int, 2>;
     for (int s = tid; s < n; s += 256) {
         const int i = list[s];
         const int t = t0 + G * ((i >> 8) & 15); // entry = validity of the group's frames << 12 | group << 8 | bin
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                     for (int k = j; k < G - 1; k++) frame(k, R);
 #pragma unroll
                     for (int k = 2 * NHOP + 1; k <= 2 * NHOP + j; k++) frame(k, R);
-                    solve_emit(R, t + j, bin);
+                    solve_emit(R, t + j, bin, hot_path{});
                 }
             }
         } else {
@@ -751,7 +765,27 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                                            {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
                 salsa::herm4_rank1_add(R, x);
             }
-            solve_emit(R, t, bin);
+            solve_emit(R, t, bin, hot_path{});
+        }
+    }
+    if (FAST) { // cold loop: the few gated bins the hot loop could not finish, general path, one frame per item
+        __syncthreads();
+        const int ns = nslow;
+        for (int s = tid; s < ns; s += 256) {
+            const int i = slow[s];
+            const int t = t0 + (i >> 8), bin = bin0 + (i & 255);
+            const float4 *xb = xclip + bin;
+            salsa::herm4<double> R = {};
+            for (int k = -nhop; k <= nhop; k++) {
+                int tt = t + k;
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
+                const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
+                                           {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
+                salsa::herm4_rank1_add(R, x);
+            }
+            solve_emit(R, t, bin, cold_path{});
         }
     }
     if (FEAT) { // write the tile out: 3 channels x nft frames, `seg` consecutive floats each
@@ -776,7 +810,10 @@ template <bool FEAT>
 static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned *valid,
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
-    if (kp.n_hop == 3)
+    const bool gated = kp.tracking || kp.flex; // (!ungated: the coherence test decides, so passing bins have a spectral gap)
+    if (kp.n_hop == 3 && gated && SALSA_COL0)
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+    else if (kp.n_hop == 3)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);

@@ -277,6 +277,7 @@ template <typename T> struct eig_result {
     T margin;        // diagnostic: q(mu1/cond) (negative = exactly one root above the threshold)
     cplx<T> u[4];    // principal eigenvector (arbitrary scale and phase); valid when computed
     bool col0;       // u is column 0 of adj(A - mu1 I): u[0] is REAL (its imaginary part is exactly 0)
+    bool fallback;   // PATH 1 only: the bin passed the gate but its column-0 pivot is too small -- solve it again with PATH 2
 };
 
 // Gate + principal eigenvector of a Hermitian PSD 4x4 R (any positive scale).
@@ -305,12 +306,17 @@ template <typename T> struct eig_result {
 #ifndef SALSA_COL0
 #define SALSA_COL0 1
 #endif
-template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, bool need_vector_always,
-                                                               bool want_imag = true)
+// PATH selects what is COMPILED: 0 = fast path with the general path behind it (one call does everything; host harness),
+// 1 = fast path only (the kernel's hot loop: a gated bin whose pivot is too small comes back with `fallback` set and no
+// vector, to be re-solved by a PATH-2 call in the kernel's cold loop -- the hot loop then carries neither the general path's
+// instructions nor its registers), 2 = general path only (the cold loop, and the ungated mode).
+template <int PATH = 0, typename T>
+SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, bool need_vector_always, bool want_imag = true)
 {
     eig_result<T> res;
     res.rank1 = false;
     res.col0 = false;
+    res.fallback = false;
     res.margin = 0;
     res.u[0] = {(T)1, (T)0};
     res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
@@ -379,7 +385,7 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
     herm4<T> B = A;
 #pragma unroll
     for (int i = 0; i < 4; i++) B.d[i] -= mu1;
-    if (SALSA_COL0 && !need_vector_always) {
+    if (SALSA_COL0 && PATH != 2 && !need_vector_always) {
         const cplx<T> a01 = A.o[0], a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4], a23 = A.o[5];
         const T c5 = B.d[2] * B.d[3] - (a23.re * a23.re + a23.im * a23.im);
         const cplx<T> c4 = {m.c4.re - mu1 * a12.re, m.c4.im + mu1 * a12.im}; // conj(a12) (a33-mu) - a31 a23
@@ -405,6 +411,10 @@ template <typename T> SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R
             res.col0 = true;
             return res;
         }
+    }
+    if (PATH == 1) { // hot loop: leave the rare small-pivot bin (and nothing else) to the cold loop
+        res.fallback = true;
+        return res;
     }
     minors4<T> n = m;
     {
