@@ -374,6 +374,26 @@ __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__
     }
 }
 
+// x / 3 correctly rounded (= the reference's float64 division, :53-55) in three instructions instead of the ~14 of the compiler's
+// IEEE division sequence (two v_div_scale, a quarter-rate v_rcp_f64, five FMAs, v_div_fmas, v_div_fixup): with y = RN(1/3) and
+// q = RN(x y) faithful, the residual r = x - 3 q is exact in one FMA and RN(q + r y) is the correctly rounded quotient (Markstein's
+// theorem; checked against exact rational arithmetic on 7e5 values incl. subnormals, tools/probes/div3_check.py).  The tracker's
+// producer waves do one division and one square root per (frame, bin): 29 M of each per 32-clip batch.
+#ifndef TR_DIV3_EXACT
+#define TR_DIV3_EXACT 1
+#endif
+__device__ __forceinline__ double div3_exact(const double x)
+{
+#if TR_DIV3_EXACT
+    const double y = 1.0 / 3.0; // RN(1/3), a compile-time constant
+    const double q = x * y;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, y, q);
+#else
+    return x / 3;
+#endif
+}
+
 template <int COUNT, int BINS>
 __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *dst /*[TR_CH][BINS]*/, int col, bool raw)
 {
@@ -386,7 +406,7 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 #pragma unroll
     for (int i = 0; i < COUNT; i++) {
         if (first + i < TR_CH) // :53-55 in the reference's order ; contrib :326-328 tracks the raw |X0| instead
-            dst[(first + i) * BINS + col] = raw ? sqrt(p[i + 2]) : sqrt((((0.0 + p[i + 2]) + p[i + 1]) + p[i]) / 3);
+            dst[(first + i) * BINS + col] = raw ? sqrt(p[i + 2]) : sqrt(div3_exact(((0.0 + p[i + 2]) + p[i + 1]) + p[i]));
     }
 }
 
@@ -408,6 +428,12 @@ __device__ __forceinline__ void tracker_mag(const float2 *x, int first, double *
 //    one iteration are first used in the next, a whole chunk later.  (Round 1 copied "next" into "current" at the end of every
 //    iteration, which made each iteration wait for the loads it had just issued.)
 constexpr int TR_BINS = 32;
+#ifndef TR_IDLE4
+#define TR_IDLE4 1
+#endif
+#ifndef TR_MASK_HISTORY
+#define TR_MASK_HISTORY 1 // the countdown as three scalar `above` masks (round 3); 0: the per-lane countdown of round 2
+#endif
 #ifndef TR_LAZY_CLAMP
 #define TR_LAZY_CLAMP 0 // measured: 0.35 ms with the lazy clamp against 0.22 ms without -- the chain is not what bounds the step
 #endif
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                                                                 unsigned *__restrict__ valid32)
 {
     constexpr int BINS = TR_BINS, FS = 64 / BINS;                                         // FS frames per producer instruction
-    constexpr bool IDLE4 = TR_WAVES > 4;                                                 // wave 4 shares the consumer's SIMD: keep it idle
+    constexpr bool IDLE4 = TR_WAVES > 4 && TR_IDLE4;                                     // wave 4 shares the consumer's SIMD: keep it idle
     constexpr int NPROD = IDLE4 ? TR_WAVES - 2 : TR_WAVES - 1;
     constexpr int PER_ALL = (TR_CH + TR_WAVES * FS - 1) / (TR_WAVES * FS);               // prologue: all waves produce chunk 0
     constexpr int PER_PROD = (TR_CH + NPROD * FS - 1) / (NPROD * FS);                    // frames per producer lane per chunk
@@ -455,6 +481,33 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     int cd = 3;
     const double snr = kp.snr_ratio;
     unsigned *vout = valid32 + ((long)b * ng32 + g) * Tn; // [b][32-bin group][t]
+#if TR_MASK_HISTORY
+    // Round 3: the countdown never becomes a per-lane value either.  "countdown < 1 before this step's decrement" (:68-69: the
+    // slow rise) holds exactly when the three steps before this one were all `above` (the countdown starts at 3, every `above`
+    // takes one off, anything else puts it back to 3), and `above` is already a scalar lane mask -- the float64 compare writes
+    // one.  So the state is three 64-bit masks in SGPRs, the test is two s_and_b64 on the scalar unit, and
+    // __builtin_amdgcn_inverse_ballot hands the result to v_cndmask as its mask operand: the three VALU instructions of the
+    // per-lane countdown (compare, reset-select, decrement) are gone, and with them the reason to form BOTH candidate products --
+    // the factor (1.02 | 1.002 | 0.98) is selected and multiplied once, the same single multiplication the reference does.
+    // 14 -> 10 vector instructions per step.  Measured (tools/probes/f64_latency_probe.hip, the probe builds TR_PROBE_NO_*): the
+    // consumer wave alone is 0.158 of the kernel's 0.177 ms, and its step time follows its INSTRUCTION COUNT (~7.6 cycles per
+    // vector instruction of this mix: VOP3 compares writing SGPR pairs, selects reading them), not the dependent chain -- a
+    // hand-pipelined order that puts the indicator of step t-1 into the stall slots of step t's chain ran no faster (0.179).
+    unsigned long long h1 = 0ull, h2 = 0ull, h3 = 0ull; // `above` masks of the previous three steps (wave-uniform)
+    auto step = [&](const double m) -> unsigned long long {
+        const bool slow = __builtin_amdgcn_inverse_ballot_w64(h1 & h2 & h3);
+        const double up = slow ? 1.0 + 0.1 * 0.02 : 1.0 + 0.02;
+        const bool above = m > fl;
+        const double f = above ? up : 1.0 - 0.02;
+        fl = fmax(f * fl, 1e-6); // (a product of finite numbers is canonical: one v_max_f64)
+        h3 = h2;
+        h2 = h1;
+        h1 = __ballot(above);
+        return __ballot(m > snr * fl); // :87
+    };
+#else
+    auto step = [&](const double m) -> unsigned long long { return __ballot(salsa::tracker_step(fl, cd, m, snr)); }; // :65-87
+#endif
     auto consume = [&](const int c) {
         const double *cur = ring[c & 1] + col;
         if (c == 0) { // noise_floor = 0.5 * mean(mag[0:5])  (:58)
@@ -472,7 +525,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 double m[16]; // one LDS round trip per 16 frames, not per frame
 #pragma unroll
                 for (int i = 0; i < 16; i++) m[i] = cur[(i0 + i) * BINS];
-#if TR_LAZY_CLAMP
+#if TR_LAZY_CLAMP && !TR_MASK_HISTORY
                 // The 1e-6 clamp (:85) is a float64 max on the step's dependent chain (multiply -> select -> max), yet it only
                 // ever acts on near-silent bins.  So a block of 16 steps runs WITHOUT it, a running minimum of the floor rides
                 // along off the chain, and only if some lane's floor dipped below 1e-6 (wave-uniform test) the block is redone
@@ -500,14 +553,14 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 #else
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, m[i], snr)); // :65-87
+                    const unsigned long long bal = step(m[i]);
                     word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
                 }
 #endif
             }
         } else {
             for (int i = 0; i < nfr; i++) {
-                const unsigned long long bal = __ballot(salsa::tracker_step(fl, cd, cur[i * BINS], snr));
+                const unsigned long long bal = step(cur[i * BINS]);
                 word = lane == i ? (unsigned)bal : word; // (ragged last chunk only)
             }
         }
@@ -520,13 +573,22 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
         if (c + 2 < nchunks) tracker_load<PER_PROD>(kp, x0, stride, (c + 2) * TR_CH, pfirst, active, nxt);
         tracker_mag<PER_PROD, BINS>(now, pfirst, ring[(c + 1) & 1], col, raw);
     };
+    // (probe builds: TR_PROBE_NO_CONSUME / TR_PROBE_NO_PRODUCE drop one role -- wrong results, the other role's time)
     for (int c = 0; c < nchunks; c += 2) {
+#ifndef TR_PROBE_NO_CONSUME
         if (w == 0) consume(c);
-        else if (producer) produce(c, xa, xb);
+#endif
+#ifndef TR_PROBE_NO_PRODUCE
+        if (w != 0 && producer) produce(c, xa, xb);
+#endif
         __syncthreads();
         if (c + 1 < nchunks) {
+#ifndef TR_PROBE_NO_CONSUME
             if (w == 0) consume(c + 1);
-            else if (producer) produce(c + 1, xb, xa);
+#endif
+#ifndef TR_PROBE_NO_PRODUCE
+            if (w != 0 && producer) produce(c + 1, xb, xa);
+#endif
         }
         __syncthreads();
     }

@@ -6,7 +6,7 @@ for i in $(seq $R); do
   for L in $A $B; do
     SALSA_HIP_LIB=$(realpath $L) python bench.py --no-crnn --no-cpu-baseline --blocks 3 2>/dev/null | python -c "
 import json,sys
-l=json.loads(sys.stdin.readline()); k={x['name']:x['ms_per_launch'] for x in l['roofline']['kernels']}
-print('$L', 'step %.4f ms' % l['ms_per_step'], ' '.join('%s %.4f' % kv for kv in k.items()))"
+l=json.loads(sys.stdin.readline()); k={x['name']:(x['ms_per_launch'], x.get('ms_event_pair')) for x in l['roofline']['kernels']}
+print('$L', 'step %.4f ms |' % l['ms_per_step'], ' | '.join('%s prefix %.4f pair %.4f' % (n, a, b) for n, (a, b) in k.items()))"
   done
 done
