@@ -57,16 +57,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const unsigned short *__re
 #pragma unroll
         for (int t = 0; t < NT; t++) a_cur[t] = a_nxt[t];
     }
-    if (p < M) {
-        unsigned short *o = y + p * N + n0 + 4 * kg;
+    {   // 16-byte stores: the partner lane (same pixel, lane +- 32) holds the other half of every 8-channel run; v_permlane32_swap
+        // trades runs so that each lane owns whole ones (round 3, as in conv_mfma.hip conv64_epilogue)
+        const bool inside = p < M;                         // (the same for both lanes of a pair)
+        unsigned short *o = y + (inside ? p : 0) * N + n0 + 8 * kg;
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                uint2 v;
-                v.x = pack_bf16(acc[t][4 * g], acc[t][4 * g + 1]);
-                v.y = pack_bf16(acc[t][4 * g + 2], acc[t][4 * g + 3]);
-                *(uint2 *)(o + 32 * t + 8 * g) = v;
+            for (int g = 0; g < 4; g += 2) {
+                const unsigned ax = pack_bf16(acc[t][4 * g], acc[t][4 * g + 1]), ay = pack_bf16(acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                const unsigned bx = pack_bf16(acc[t][4 * g + 4], acc[t][4 * g + 5]), by = pack_bf16(acc[t][4 * g + 6], acc[t][4 * g + 7]);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); // lanes 32-63 of a <-> lanes 0-31 of b
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (inside) *(uint4 *)(o + 32 * t + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             }
     }
 }

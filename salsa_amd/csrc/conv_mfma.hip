@@ -18,6 +18,9 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CONV_WIDE_STORE
+#define CONV_WIDE_STORE 1 // 16-byte epilogue stores through v_permlane32_swap (0: the 8-byte stores of rounds 1-2)
+#endif
 constexpr int CH = 64;            // channels in = out
 constexpr int ROW = 72;           // padded channel stride in LDS (bf16 elements): 144 bytes
 #ifndef CONV_RPW
@@ -79,37 +82,62 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         }
         return;
     }
+    // A lane holds, of its pixel, four runs of 4 consecutive channels (8 g + 4 khalf + 0..3) and its partner lane (the same
+    // pixel, lane +- 32) the other half of each 8-channel run.  Written as they lie that is four 8-byte stores per row: the
+    // epilogue was store-ISSUE-bound (probe builds, 8 x 2400 x 100: 0.229 ms, 0.148 without the epilogue and its stores).
+    // v_permlane32_swap (gfx950) trades runs between the two lanes -- the low lane gives away its runs 1 and 3 for the partner's
+    // halves of runs 0 and 2 -- so that every lane owns two whole 8-channel runs: two 16-byte stores per row (round 3).
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++) {
         const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
-        if (h < H && wcol < W) {
-            const long off = ((n * H + h) * W + wcol) * CH + 32 * mb + 4 * (lane >> 5);
+        const bool inside = h < H && wcol < W;      // (the same for both lanes of a pair: they share the pixel)
+        const long off = ((n * H + (inside ? h : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
+            if (shift) { // inference epilogue: folded BatchNorm shift (+ residual) (+ ReLU) before the single rounding
+                const float4 sh = shv[g];
+                v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                if (residual) {
+                    const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
+                    v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                }
+            }
+            pk[g].x = pack_bf16(v4[0], v4[1]);
+            pk[g].y = pack_bf16(v4[2], v4[3]);
+        }
+#if CONV_WIDE_STORE
+        // swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B.  With A = run g (even), B = run g + 1: the low lane ends with
+        // (own half of run g, partner's half of run g) = channels 8 g .. 8 g + 7, the high lane with the two halves of run g + 1
+        unsigned short *o = y + ((n * H + (inside ? h : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 8 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+            const uint4 v = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+#ifdef CONV_NO_STORE // probe: everything computed, nothing written
+            if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
+#endif
+            if (inside) *(uint4 *)(o + 8 * g) = v;
+        }
+#else
+        if (inside) {
             unsigned short *o = y + off;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
-                if (shift) { // inference epilogue: folded BatchNorm shift (+ residual) (+ ReLU) before the single rounding
-                    const float4 sh = shv[g];
-                    v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-                    if (residual) {
-                        const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
-                        v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
-                        v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
-                    }
-                    if (relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
-                    }
-                }
-                uint2 v;
-                v.x = pack_bf16(v4[0], v4[1]);
-                v.y = pack_bf16(v4[2], v4[3]);
-#ifdef CONV_NO_STORE // probe: everything computed, nothing written
-                if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
+#ifdef CONV_NO_STORE
+                if (pk[g].x == 0x12345678u && pk[g].y == 0x9abcdef0u)
 #endif
-                *(uint2 *)(o + 8 * g) = v;
+                *(uint2 *)(o + 8 * g) = pk[g];
             }
         }
+#endif
     }
 }
 
@@ -327,9 +355,13 @@ template <int U>
 __device__ __forceinline__ void conv64_lds_read(bf16x8 &dst, const unsigned (&rb)[8])
 {
     constexpr int ir = U / 12, sx = (U / 4) % 3, kc = U & 3;
+#ifdef CONV_NO_LDSREAD // probe: the fragment is whatever the register holds
+    asm volatile("" : "=v"(dst) : "v"(rb[(2 * kc + sx + 2 * ir) & 7]));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2"
                  : "=v"(dst)
                  : "v"(rb[(2 * kc + sx + 2 * ir) & 7]), "n"(2 * ((ir * (TW + 2) + sx) * 64)));
+#endif
 }
 
 template <int S, int AD>
@@ -353,8 +385,11 @@ __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[S % RING]));
         __builtin_amdgcn_sched_barrier(0);
         constexpr int u = conv64_frag(S), ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
-        if constexpr (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[S % RING], acc[0], 0, 0, 0);
-        if constexpr (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[S % RING], acc[1], 0, 0, 0);
+        // (the first product into each accumulator takes a ZERO C operand -- an inline constant of the instruction -- instead of
+        // 32 v_mov clearing the accumulators every tile; with CONV_ORDER these are steps 0 (row 0 -> acc 0) and 1 (row 3 -> acc 1))
+        constexpr bool first0 = CONV_ORDER && S == 0, first1 = CONV_ORDER && S == 1;
+        if constexpr (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[S % RING], first0 ? f32x16{} : acc[0], 0, 0, 0);
+        if constexpr (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[S % RING], first1 ? f32x16{} : acc[1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         conv64_steps<S + 1, AD>(af, bb, acc, rb);
     }
@@ -459,7 +494,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     }
     advance(ahead); // two tiles ahead of `cur` from here on
     for (int it = 0; tile < n_tiles; tile += stride, it++, advance(cur), advance(ahead)) {
+#ifndef CONV_NO_BARRIER // (probe)
         __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
+#endif
         if (tile + 2 * stride < n_tiles) fetch(ahead, (it + 2) % NBUF); // into the buffer of the tile before
         const int tw = cur.tw, th = cur.th;
         const long n = cur.n;
@@ -495,8 +532,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CONV_NO_EPI // probe: the accumulators are kept alive, nothing is converted or stored
+        asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
+#else
         conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
         if (STATS) conv64_stats(acc, rs, rq, th, tw, H, W, px, rg);
+#endif
     }
 #undef WAIT_ALL_BUT_LAST_FETCH
     if (STATS) { // this workgroup's partial sums: [2][64] float64, row blockIdx.x of the BatchNorm kernels' partial table

@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;                // input channels per chunk (2 MFMA k-steps)
 constexpr int MAX_XL_BYTES = 53248;   // input chunk: up to 832 slots of 64 bytes (a multiple of 1 KiB: whole wave-loads)
 
+#ifndef WIDE_STORE16
+#define WIDE_STORE16 1 // 16-byte epilogue stores through v_permlane32_swap (0: 8-byte stores)
+#endif
 __device__ uint4 wide_zero16; // zero-initialised: the source of every padding piece
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -214,36 +217,50 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
             compute(r, (unsigned)(xb * xl_bytes), (unsigned)(2 * xl_bytes + wb * WL_BYTES));
         }
     }
-    // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 8-byte bf16 stores.
+    // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds runs of 4
+    // consecutive channels and its partner lane (the same pixel, lane +- 32) the other half of each 8-channel run.
+    // v_permlane32_swap trades runs between the two so that each lane owns whole 8-channel runs: 16-byte stores, half as many
+    // (round 3; the 8-byte version was store-issue-bound in the 64 -> 64 kernel: conv_mfma.hip conv64_epilogue).
     // Inference epilogue (shift != NULL): folded BatchNorm shift (+ residual) (+ ReLU) on the float32 sums, one rounding.
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
-        if (pix[pt] < P) {
-            const long off = pix[pt] * COUT + co0 + 4 * khalf;
-            unsigned short *o = y + off;
+        const bool inside = pix[pt] < P;                   // (the same for both lanes of a pair)
+        const long off = (inside ? pix[pt] : 0) * COUT + co0 + 4 * khalf;
+        unsigned short *o = y + (inside ? pix[pt] : 0) * COUT + co0 + 8 * khalf;
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++)
+        for (int ct = 0; ct < CT; ct++) {
+            uint2 pk[4];
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    float v4[4] = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
-                    if (shift) {
-                        const float4 sh = *(const float4 *)(shift + co0 + 4 * khalf + ct * 32 + 8 * g);
-                        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-                        if (residual) {
-                            const uint2 rv = *(const uint2 *)(residual + off + ct * 32 + 8 * g);
-                            v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
-                            v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
-                        }
+            for (int g = 0; g < 4; g++) {
+                float v4[4] = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+                if (shift) {
+                    const float4 sh = *(const float4 *)(shift + co0 + 4 * khalf + ct * 32 + 8 * g);
+                    v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+                    if (residual) {
+                        const uint2 rv = *(const uint2 *)(residual + off + ct * 32 + 8 * g);
+                        v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
                     }
-                    uint2 v;
-                    v.x = pack_bf16(v4[0], v4[1]);
-                    v.y = pack_bf16(v4[2], v4[3]);
-                    *(uint2 *)(o + ct * 32 + 8 * g) = v;
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v4[j] = fmaxf(v4[j], 0.f);
+                    }
                 }
+                pk[g].x = pack_bf16(v4[0], v4[1]);
+                pk[g].y = pack_bf16(v4[2], v4[3]);
+            }
+#if WIDE_STORE16
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) { // swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B
+                const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+                if (inside) *(uint4 *)(o + ct * 32 + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+#else
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                if (inside) *(uint2 *)(y + off + ct * 32 + 8 * g) = pk[g];
+#endif
         }
     }
 }
