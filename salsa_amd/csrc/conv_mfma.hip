@@ -55,6 +55,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         // the full-resolution activation is never written (H and W even: a tile holds whole 2x2 cells)
         const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
         const bool inside = h0 < H && wcol < W;
+        uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -73,12 +74,16 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) s4[j] = 0.25f * (s4[j] + __shfl_xor(s4[j], 1));
-            if (inside && !(px & 1)) {
-                uint2 v;
-                v.x = pack_bf16(s4[0], s4[1]);
-                v.y = pack_bf16(s4[2], s4[3]);
-                *(uint2 *)(y + ((n * (H / 2) + h0 / 2) * (W / 2) + wcol / 2) * CH + 32 * mb + 4 * (lane >> 5) + 8 * g) = v;
-            }
+            pk[g].x = pack_bf16(s4[0], s4[1]);
+            pk[g].y = pack_bf16(s4[2], s4[3]);
+        }
+        // 16-byte stores: runs traded with the partner lane (same pixel, lane +- 32), as in the plain epilogue below
+        unsigned short *o = y + ((n * (H / 2) + (inside ? h0 / 2 : 0)) * (W / 2) + (inside ? wcol / 2 : 0)) * CH + 32 * mb + 8 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
+            if (inside && !(px & 1)) *(uint4 *)(o + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
         return;
     }
@@ -917,36 +922,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x16{};
     const int tiles_w = (W + WT_W - 1) / WT_W, tiles_h = (H + WT_H - 1) / WT_H;
-    const long n_tiles = (long)N * tiles_h * tiles_w;
+    const int n_tiles = N * tiles_h * tiles_w; // (fits: the host checks N*H*W)
     constexpr int XP = (WHALO_H * WHALO_W * 8 + 255) / 256, GP = WT_H * WT_W * 8 / 256; // 16-byte pieces per thread
     uint4 px_[XP], pg_[GP];
-    auto fetch = [&](long tile) { // one tile's x (with halo, zeros outside the image) and dy into registers
-        const int tw = (int)(tile % tiles_w);
-        const int th = (int)((tile / tiles_w) % tiles_h);
-        const long n = tile / ((long)tiles_w * tiles_h);
-        const int h0 = th * WT_H, w0 = tw * WT_W;
+    // Round 3: the fetch used to decode the tile with 64-bit divisions and rebuild a 64-bit address with a division by 34 for
+    // every one of its 11 loads -- ~45 instructions per load, as many issue cycles per tile as the 72 MFMAs (probe builds at
+    // 32 x 640 x 200: 0.445 ms, 0.252 without the fetch, 0.242 without the multiply, 0.114 with neither: purely additive).
+    // Now a cursor steps (tw, th, n) by the grid size with carries, the tile's origin is ONE wave-uniform 64-bit pointer, and a
+    // load is that pointer + a 32-bit offset from the thread's halo position (q / 34 by multiply-shift, exact for q < 236).
+    struct Cursor { int tw, th, n; };
+    const int stride_ = (int)gridDim.x;
+    const int d_tw = stride_ % tiles_w, d_th = (stride_ / tiles_w) % tiles_h, d_n = stride_ / (tiles_w * tiles_h);
+    auto advance = [&](Cursor &c) {
+        c.tw += d_tw;
+        int carry = c.tw >= tiles_w ? 1 : 0;
+        c.tw -= carry ? tiles_w : 0;
+        c.th += d_th + carry;
+        carry = c.th >= tiles_h ? 1 : 0;
+        c.th -= carry ? tiles_h : 0;
+        c.n += d_n + carry;
+    };
+    static_assert(WHALO_W == 34 && WHALO_H * WHALO_W + 31 < 236, "q / 34 == (q * 241) >> 13 holds for q < 236");
+    auto fetch = [&](const Cursor &c) { // one tile's x (with halo, zeros outside the image) and dy into registers
+        const int h0 = c.th * WT_H, w0 = c.tw * WT_W;
+        const unsigned short *xo = x + (((long)c.n * H + h0 - 1) * W + (w0 - 1)) * CH;   // halo pixel (0, 0); wave-uniform
+        const unsigned short *go = dy + (((long)c.n * H + h0) * W + w0) * CH;
+        const int p0 = tid >> 3, piece8 = (tid & 7) * 8;
 #pragma unroll
         for (int j = 0; j < XP; j++) {
-            const int i = tid + j * 256, piece = i & 7, p = i >> 3;
-            const int hh = p / WHALO_W, ww = p - hh * WHALO_W;
-            const int h = h0 + hh - 1, wc = w0 + ww - 1;
+            const int q = p0 + 32 * j;                   // halo pixel of this piece, row-major in the 6 x 34 halo
+            const int hh = (q * 241) >> 13, ww = q - hh * WHALO_W;
+            const bool ok = q < WHALO_H * WHALO_W && (unsigned)(h0 - 1 + hh) < (unsigned)H && (unsigned)(w0 - 1 + ww) < (unsigned)W;
             px_[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < WHALO_H * WHALO_W * 8 && h >= 0 && h < H && wc >= 0 && wc < W)
-                px_[j] = *(const uint4 *)(x + (((n * H + h) * W + wc) * CH + piece * 8));
+#ifndef WRW64_NO_FETCH // (probe builds: WRW64_NO_FETCH / WRW64_NO_LDSWRITE / WRW64_NO_MULT drop one phase each)
+            if (ok) px_[j] = *(const uint4 *)(xo + ((hh * W + ww) * CH + piece8));
+#endif
         }
 #pragma unroll
         for (int j = 0; j < GP; j++) {
-            const int i = tid + j * 256, piece = i & 7, p = i >> 3;
-            const int hh = p / WT_W, ww = p - hh * WT_W;
-            const int h = h0 + hh, wc = w0 + ww;
+            const int q = p0 + 32 * j, hh = q >> 5, ww = q & 31;
             pg_[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (h < H && wc < W) pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
+#ifndef WRW64_NO_FETCH
+            if (h0 + hh < H && w0 + ww < W) pg_[j] = *(const uint4 *)(go + ((hh * W + ww) * CH + piece8));
+#endif
         }
     };
-    long tile = blockIdx.x;
-    if (tile < n_tiles) fetch(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
+    int tile = (int)blockIdx.x;
+    Cursor cur = {tile % tiles_w, (tile / tiles_w) % tiles_h, tile / (tiles_w * tiles_h)};
+    if (tile < n_tiles) fetch(cur);
+    for (; tile < n_tiles; tile += stride_) {
         __syncthreads(); // the previous tile's LDS reads are done
+#ifndef WRW64_NO_LDSWRITE
 #pragma unroll
         for (int j = 0; j < XP; j++) {
             const int i = tid + j * 256;
@@ -957,8 +983,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
             const int i = tid + j * 256;
             *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = pg_[j];
         }
+#endif
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
+        advance(cur);
+        if (tile + stride_ < n_tiles) fetch(cur); // in flight during the multiply below
         // 8 K-steps (4 rows x 2 halves of 16 consecutive pixels) x 9 taps, software-pipelined by hand like the forward kernel:
         // the fragment of step q+1 is requested before step q's MFMA issues.  Step q = ks * 10 + j: j = 0 is the dy
         // fragment of K-step ks, j = 1..9 the x fragment of tap j-1.
@@ -973,7 +1001,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
         else if constexpr (WRW_DEPTH == 2) LDS_TR_WAIT_N(fr[0], 2);
         else if constexpr (WRW_DEPTH == 3) LDS_TR_WAIT_N(fr[0], 4);
         else LDS_TR_WAIT_N(fr[0], 6);
+#ifndef WRW64_NO_MULT
         wrw_steps<0>(fr, a, acc, ga, xa);
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     }
     // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the block
 #pragma unroll
@@ -981,6 +1013,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), ci = 32 * nb + (lane & 31);
+#ifdef WRW64_NO_ATOMIC // (probe)
+            if (acc[tap][reg] == 123.456f)
+#endif
             atomicAdd(dw + ((long)(co * 9 + tap) * CH + ci), acc[tap][reg]);
         }
 }
