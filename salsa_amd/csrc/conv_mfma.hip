@@ -330,6 +330,52 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
     }
 }
 
+
+// ---- XCD-aware walk of a persistent workgroup over the (image, tile row, tile column) space (round 3).
+// Workgroup b runs on XCD b % 8, each XCD with its own L2.  Dealing the tiles round-robin (tile = b + i * grid) puts vertically
+// neighbouring tiles -- which share two of a tile's six halo rows -- on different XCDs, so every halo row came from HBM twice:
+// rocprofv3 FETCH_SIZE of the forward kernel at 8 x 2400 x 100 was 392 MB for a 246-MB input (1.59x = the 6/4 x 34/32 halo), of
+// the weight-gradient kernel 1.34 GB for 1.05 GB.  Here the flattened (image, tile row) axis is cut into bands of TW_BAND rows,
+// band k belongs to XCD k % 8, and the G = grid / 8 workgroups of an XCD walk ITS bands' tiles in order: at any moment an XCD works
+// on ~G consecutive tiles of a few neighbouring rows, and the shared halo rows are L2 hits.  nx = 1 (grids that are not a
+// multiple of 8) degenerates to the plain round-robin order.
+constexpr int TW_BAND = 4;
+struct TileWalk {
+    int tiles_w, tiles_h, nx, xcd, G, n_local, d_tw, d_lr;
+};
+struct TilePos {
+    int tw, lr; // tile column, row index among this XCD's rows
+};
+__device__ __forceinline__ TileWalk tile_walk(int N, int tiles_h, int tiles_w, int grid, int b)
+{
+    TileWalk w;
+    w.tiles_w = tiles_w;
+    w.tiles_h = tiles_h;
+    w.nx = (grid % 8 == 0 && grid >= 64) ? 8 : 1;
+    w.xcd = b % w.nx;
+    w.G = grid / w.nx;
+    const int rows = N * tiles_h, full = rows / TW_BAND, rem = rows % TW_BAND;
+    const int mine = full / w.nx + (w.xcd < full % w.nx ? 1 : 0);
+    w.n_local = (mine * TW_BAND + (full % w.nx == w.xcd ? rem : 0)) * tiles_w;
+    w.d_tw = w.G % tiles_w;
+    w.d_lr = w.G / tiles_w;
+    return w;
+}
+__device__ __forceinline__ TilePos tile_pos(const TileWalk &w, int s) { return {s % w.tiles_w, s / w.tiles_w}; }
+__device__ __forceinline__ void tile_advance(const TileWalk &w, TilePos &p) // s += G
+{
+    p.tw += w.d_tw;
+    const int carry = p.tw >= w.tiles_w ? 1 : 0;
+    p.tw -= carry ? w.tiles_w : 0;
+    p.lr += w.d_lr + carry;
+}
+__device__ __forceinline__ void tile_coords(const TileWalk &w, const TilePos &p, int &n, int &th)
+{
+    const int r = ((p.lr / TW_BAND) * w.nx + w.xcd) * TW_BAND + p.lr % TW_BAND; // global (image, tile row) index
+    n = r / w.tiles_h;
+    th = r - n * w.tiles_h;
+}
+
 // ---- variant with the input tiles loaded STRAIGHT INTO LDS (global_load_lds_dwordx4), two tiles ahead.
 // Probe builds of the kernel above: 0.242 ms for 8 x 2400 x 100, 0.143 ms without its input loads -- the next tile's halo,
 // prefetched into registers ONE tile ahead, arrives later than one tile's multiply takes, and 256 VGPRs leave no room for a
@@ -369,6 +415,11 @@ __device__ __forceinline__ void conv64_lds_read(bf16x8 &dst, const unsigned (&rb
 #endif
 }
 
+#ifdef CONV_NO_SCHED // (probe: let the compiler order the step stream)
+#define CONV_SCHED_BARRIER() do {} while (0)
+#else
+#define CONV_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int S, int AD>
 __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&bb)[AD + 1], f32x16 (&acc)[RPW], const unsigned (&rb)[8])
 {
@@ -388,14 +439,14 @@ __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&
         else if constexpr (47 - S == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bb[S % RING]));
         else if constexpr (47 - S == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bb[S % RING]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[S % RING]));
-        __builtin_amdgcn_sched_barrier(0);
+        CONV_SCHED_BARRIER();
         constexpr int u = conv64_frag(S), ir = u / 12, sx = (u / 4) % 3, kc = u & 3;
         // (the first product into each accumulator takes a ZERO C operand -- an inline constant of the instruction -- instead of
         // 32 v_mov clearing the accumulators every tile; with CONV_ORDER these are steps 0 (row 0 -> acc 0) and 1 (row 3 -> acc 1))
         constexpr bool first0 = CONV_ORDER && S == 0, first1 = CONV_ORDER && S == 1;
         if constexpr (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[S % RING], first0 ? f32x16{} : acc[0], 0, 0, 0);
         if constexpr (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[S % RING], first1 ? f32x16{} : acc[1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        CONV_SCHED_BARRIER();
         conv64_steps<S + 1, AD>(af, bb, acc, rb);
     }
 }
@@ -436,22 +487,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #pragma unroll
     for (int g = 0; g < 4; g++) asm volatile("" ::"v"(shv[g].x), "v"(shv[g].y), "v"(shv[g].z), "v"(shv[g].w));
     const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + TH - 1) / TH;
-    const int n_tiles = N * tiles_h * tiles_w; // (fits: the host checks N*H*W; 32-bit tile arithmetic, no 64-bit divisions)
     // Tile cursors.  Probe builds with neither loads nor stores still ran at 2x the MFMA time: the per-tile integer work
     // (two divisions per decode, a division by 34 and 64-bit address arithmetic per load) was the bound.  So a cursor keeps
     // (tw, th, n) and steps by the grid size with carries, and a thread's halo pixel walks rows incrementally (its channel
     // block never changes: the slot index advances by 256 = 0 mod 8 and the pixel by 32 = 0 mod 8 per load).
     struct Cursor { int tw, th, n; };
-    const int stride = (int)gridDim.x;
-    const int d_tw = stride % tiles_w, d_th = (stride / tiles_w) % tiles_h, d_n = stride / (tiles_w * tiles_h);
-    auto advance = [&](Cursor &c) {
-        c.tw += d_tw;
-        int carry = c.tw >= tiles_w ? 1 : 0;
-        c.tw -= carry ? tiles_w : 0;
-        c.th += d_th + carry;
-        carry = c.th >= tiles_h ? 1 : 0;
-        c.th -= carry ? tiles_h : 0;
-        c.n += d_n + carry;
+    const TileWalk walk = tile_walk(N, tiles_h, tiles_w, (int)gridDim.x, (int)blockIdx.x);
+    const int stride = walk.G;                       // step of this workgroup's position in its XCD's tile sequence
+    auto cursor_of = [&](const TilePos &p) {
+        Cursor c;
+        c.tw = p.tw;
+        tile_coords(walk, p, c.n, c.th);
+        return c;
     };
     const int p0 = tid >> 3, hh0 = p0 / HALO_W, ww0 = p0 - hh0 * HALO_W;
     const int blk8 = (((tid & 7) - p0) & 7) * 8; // channel offset of this thread's 16 bytes: slot (block + pixel) & 7
@@ -487,22 +534,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFETCH - 1) : "memory");             \
     } while (0)
     static_assert(HALO_PIECES % 256 != 0, "the last fetch instruction is issued by the first (HALO_PIECES % 256 + 63) / 64 waves only");
-    int tile = (int)blockIdx.x;
-    Cursor cur = {tile % tiles_w, (tile / tiles_w) % tiles_h, tile / (tiles_w * tiles_h)}, ahead = cur;
-    if (tile < n_tiles) fetch(ahead, 0);
-    advance(ahead);
+    const int n_tiles = walk.n_local;                // tiles of this workgroup's XCD; `tile` = position in that sequence
+    int tile = (int)blockIdx.x / walk.nx;
+    TilePos pcur = tile_pos(walk, tile), pahead = pcur;
+    if (tile < n_tiles) fetch(cursor_of(pahead), 0);
+    tile_advance(walk, pahead);
     if (tile + stride < n_tiles) {
-        fetch(ahead, 1);
+        fetch(cursor_of(pahead), 1);
         WAIT_ALL_BUT_LAST_FETCH();
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    advance(ahead); // two tiles ahead of `cur` from here on
-    for (int it = 0; tile < n_tiles; tile += stride, it++, advance(cur), advance(ahead)) {
+    tile_advance(walk, pahead); // two tiles ahead of `pcur` from here on
+    for (int it = 0; tile < n_tiles; tile += stride, it++, tile_advance(walk, pcur), tile_advance(walk, pahead)) {
+        const Cursor cur = cursor_of(pcur);
 #ifndef CONV_NO_BARRIER // (probe)
         __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
 #endif
-        if (tile + 2 * stride < n_tiles) fetch(ahead, (it + 2) % NBUF); // into the buffer of the tile before
+        if (tile + 2 * stride < n_tiles) fetch(cursor_of(pahead), (it + 2) % NBUF); // into the buffer of the tile before
         const int tw = cur.tw, th = cur.th;
         const long n = cur.n;
         f32x16 acc[RPW];
@@ -922,7 +971,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x16{};
     const int tiles_w = (W + WT_W - 1) / WT_W, tiles_h = (H + WT_H - 1) / WT_H;
-    const int n_tiles = N * tiles_h * tiles_w; // (fits: the host checks N*H*W)
     constexpr int XP = (WHALO_H * WHALO_W * 8 + 255) / 256, GP = WT_H * WT_W * 8 / 256; // 16-byte pieces per thread
     uint4 px_[XP], pg_[GP];
     // Round 3: the fetch used to decode the tile with 64-bit divisions and rebuild a 64-bit address with a division by 34 for
@@ -931,16 +979,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
     // Now a cursor steps (tw, th, n) by the grid size with carries, the tile's origin is ONE wave-uniform 64-bit pointer, and a
     // load is that pointer + a 32-bit offset from the thread's halo position (q / 34 by multiply-shift, exact for q < 236).
     struct Cursor { int tw, th, n; };
-    const int stride_ = (int)gridDim.x;
-    const int d_tw = stride_ % tiles_w, d_th = (stride_ / tiles_w) % tiles_h, d_n = stride_ / (tiles_w * tiles_h);
-    auto advance = [&](Cursor &c) {
-        c.tw += d_tw;
-        int carry = c.tw >= tiles_w ? 1 : 0;
-        c.tw -= carry ? tiles_w : 0;
-        c.th += d_th + carry;
-        carry = c.th >= tiles_h ? 1 : 0;
-        c.th -= carry ? tiles_h : 0;
-        c.n += d_n + carry;
+    const TileWalk walk = tile_walk(N, tiles_h, tiles_w, (int)gridDim.x, (int)blockIdx.x); // XCD-aware order (see tile_walk)
+    const int stride_ = walk.G;
+    auto cursor_of = [&](const TilePos &p) {
+        Cursor c;
+        c.tw = p.tw;
+        tile_coords(walk, p, c.n, c.th);
+        return c;
     };
     static_assert(WHALO_W == 34 && WHALO_H * WHALO_W + 31 < 236, "q / 34 == (q * 241) >> 13 holds for q < 236");
     auto fetch = [&](const Cursor &c) { // one tile's x (with halo, zeros outside the image) and dy into registers
@@ -967,10 +1012,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #endif
         }
     };
-    int tile = (int)blockIdx.x;
-    Cursor cur = {tile % tiles_w, (tile / tiles_w) % tiles_h, tile / (tiles_w * tiles_h)};
-    if (tile < n_tiles) fetch(cur);
-    for (; tile < n_tiles; tile += stride_) {
+    const int n_local = walk.n_local;                // tiles of this workgroup's XCD; `tile` = position in that sequence
+    int tile = (int)blockIdx.x / walk.nx;
+    TilePos pcur = tile_pos(walk, tile);
+    if (tile < n_local) fetch(cursor_of(pcur));
+    for (; tile < n_local; tile += stride_) {
         __syncthreads(); // the previous tile's LDS reads are done
 #ifndef WRW64_NO_LDSWRITE
 #pragma unroll
@@ -985,8 +1031,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
         }
 #endif
         __syncthreads();
-        advance(cur);
-        if (tile + stride_ < n_tiles) fetch(cur); // in flight during the multiply below
+        tile_advance(walk, pcur);
+        if (tile + stride_ < n_local) fetch(cursor_of(pcur)); // in flight during the multiply below
         // 8 K-steps (4 rows x 2 halves of 16 consecutive pixels) x 9 taps, software-pipelined by hand like the forward kernel:
         // the fragment of step q+1 is requested before step q's MFMA issues.  Step q = ks * 10 + j: j = 0 is the dy
         // fragment of K-step ks, j = 1..9 the x fragment of tap j-1.
