@@ -570,3 +570,37 @@ def test_contrib_multichannel_batch_against_oracle(dev, oracle, n_ch):
                              spat_tol=ATOL_SP, spat_rtol=RTOL)
         if kind == 'salsa' and call.get('is_tracking', True):
             assert (out[:, n_ch:] != 0).any(), 'degenerate case: nothing passed the gates'
+
+
+def test_timing_modes_leave_results_untouched(dev):
+    """The measurement knobs of salsa_plan_set_timing (include/salsa_hip.h): an event pair per launch (1), K launches of every
+    kernel between one event pair (K > 1), and the plain issue of a PREFIX of the path (-1: STFT alone, -2: STFT + tracker) that
+    bench.py uses to attribute the step to its kernels.  Every kernel is idempotent on (audio, spill, masks), so the output of
+    any of them -- on buffers a full call left behind -- must be the plain call's bit for bit, and the timing modes must report
+    one positive duration per kernel."""
+    ys = np.stack([synth_clip(300 + i, 4 * 24000) for i in range(3)])
+    a = torch.from_numpy(ys).to(dev)
+    ex = _extractor()
+    ref = ex.extract(a).clone()
+    out = torch.empty_like(ref)
+    for mode in (1, 4):
+        ex.set_timing(mode)
+        ex.extract(a, out=out)
+        t = ex.read_timing()
+        assert [n for n, _ in t] == ['stft_logspec', 'noise_floor_tracker', 'cov_eig'] and all(ms > 0 for _, ms in t), t
+        assert torch.equal(out, ref)
+    ex.set_timing(0)
+    assert ex.read_timing() == []
+    ex.extract(a, out=out)                       # full call: spill and masks in place
+    spatial = out[:, 4:].clone()
+    out[:, 4:] = 7.0                             # poison the channels the skipped kernel would have written
+    out[:, :4] = 0.0
+    for mode in (-1, -2):
+        ex.set_timing(mode)
+        ex.extract(a, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:, :4], ref[:, :4])                         # the STFT launch ran and rewrote the spectrograms
+        assert bool((out[:, 4:] == 7.0).all())                             # ... and the covariance kernel did not
+    ex.set_timing(0)
+    ex.extract(a, out=out)
+    assert torch.equal(out, ref) and torch.equal(out[:, 4:], spatial)
