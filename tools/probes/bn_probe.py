@@ -7,7 +7,7 @@ from torch.profiler import ProfilerActivity, profile
 from salsa_amd.crnn.nn_ops import BatchNormAct2d
 
 dev = 'cuda:0'
-for shape, res in (((32, 64, 640, 200), False), ((32, 64, 320, 100), True), ((32, 128, 160, 50), False)):
+for shape, res in (((32, 64, 640, 200), False), ((32, 64, 320, 100), True), ((32, 128, 160, 50), False), ((32, 256, 80, 25), True), ((32, 512, 40, 12), True)):
     bn = BatchNormAct2d(shape[1]).to(dev).train()
     x = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     r = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
