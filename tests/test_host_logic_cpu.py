@@ -115,3 +115,41 @@ def test_feature_files_dispatch_on_extension_and_one_name_per_clip(tmp_path):
     got = sio.load_arrays(str(tmp_path / 'clip_b.npz'))                  # an .npz name is read as .npz whatever is installed
     assert np.array_equal(got['feature'], a)
     assert np.array_equal(sio.load_arrays(str(tmp_path / 'clip_b.h5'))['feature'], a)  # .h5 name, only the twin exists
+
+
+def test_tracker_countdown_equals_three_step_above_history():
+    """The tracker kernel keeps no per-bin countdown (round 3): 'countdown < 1 before this step's decrement' -- the slow-rise
+    test of dataset/salsa_feature_extraction.py:68-69, with the countdown starting at 3, reset to 3 by every frame that is not
+    `above` and decremented by every frame that is (:30, :67-79) -- holds exactly when the three previous frames were all
+    `above`.  Simulated both ways on random and adversarial `above` sequences."""
+    rng = np.random.RandomState(0)
+    seqs = [rng.rand(4000) < p for p in (0.05, 0.3, 0.5, 0.8, 0.97)]
+    seqs += [np.ones(50, bool), np.zeros(50, bool), np.array(([True] * 3 + [False]) * 20), np.array(([True] * 4 + [False]) * 20)]
+    for above in seqs:
+        countdown, h = 3, [False, False, False]
+        for a in above:
+            slow_ref = countdown < 1                       # evaluated BEFORE the update, like tracker_step
+            slow_new = h[0] and h[1] and h[2]
+            assert slow_ref == slow_new
+            countdown = countdown - 1 if a else 3
+            h = [bool(a), h[0], h[1]]
+
+
+def test_three_instruction_division_by_three_is_ieee():
+    """salsa_kernels.hip div3_exact (the tracker producers' x / 3): q = RN(x y), r = fma(-3, q, x), RN(q + r y) with y = RN(1/3)
+    against IEEE division in exact rational arithmetic (Markstein's theorem; the long run is tools/probes/div3_check.py)."""
+    from fractions import Fraction as Fr
+    y = 1.0 / 3.0
+
+    def div3(a):
+        q = a * y
+        r = float(Fr(a) - 3 * Fr(q))                      # one FMA = one correctly rounded operation
+        return float(Fr(q) + Fr(r) * Fr(y))
+
+    rng = np.random.RandomState(1)
+    vals = [0.0, 5e-324, 1e-310, 2.2250738585072014e-308, 1.0, 3.0, 1e300]
+    vals += list(np.ldexp(rng.rand(3000) + 1.0, rng.randint(-200, 200, 3000)))
+    vals += list((rng.randint(1, 2 ** 52, 2000).astype(np.float64)) * 3.0)
+    for a in vals:
+        a = float(a)
+        assert div3(a) == a / 3.0, a.hex()
