@@ -366,21 +366,26 @@ __device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
 // ~1 us of multiply, so the loop is pipelined two deep: while tile i is multiplied, tile i+1's LDS-direct loads are in flight
 // into the other half of LDS and tile i+2's table look-ups into registers.  (First version, everything serial with two
 // workgroups per CU to cover for each other: 324 - 488 TFLOP/s, on a par with MIOpen.)
-constexpr int WG_XP = WG_XL / 16 / 256;             // input wave-loads per thread per tile (upper bound): 7
-constexpr int WG_KS = WG_TM / 16;                   // k-steps per tile: 8
+#ifndef WG_KQ
+#define WG_KQ 2                                      // wave groups that split a tile's k-steps (pixels): 2 = eight waves, two per SIMD, so that
+#endif                                               // one wave's LDS round trips sit under the other's MFMAs; 1 = the four-wave kernel of round 2
+constexpr int WG_NT = 256 * WG_KQ;                  // threads per workgroup
+constexpr int WG_XP = (WG_XL / 16 + WG_NT - 1) / WG_NT; // input wave-loads per thread per tile (upper bound): 7 | 4
+constexpr int WG_KS = WG_TM / 16 / WG_KQ;           // k-steps per tile and wave: 8 | 4
+constexpr int WG_LDS = WG_KQ == 2 && 2 * (WG_XL + WG_DL) < 9 * 16 * 256 * 4 ? 9 * 16 * 256 * 4 : 2 * (WG_XL + WG_DL); // tiles, or the pair reduction (144 KiB)
 #ifndef WG_DEPTH
 #define WG_DEPTH 2                                   // fragments in flight ahead of the MFMA (<= 4: the counted waits below); measured
                                                      // 1: 433, 2: 583, 3: 558, 4: 543 TFLOP/s on 256 -> 256
 #endif
 
-__global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
+__global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                   const int *__restrict__ vpos, const int *__restrict__ inv,
                                                                   const int2 *__restrict__ tbounds, long P, int W, int CIN, int COUT,
                                                                   int n_shares)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wave & 3, kq = wave >> 2;
     const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
     const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 32;
     const int W2 = W + 2;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         (void)p_last;
 #pragma unroll
         for (int j = 0; j < WG_XP; j++) {
-            const int sl = (j * 256 + tid) >> 2;
+            const int sl = (j * WG_NT + tid) >> 2;
             L.pix[j] = inv[L.vb + (sl < L.ns ? sl : 0)]; // (clamped address; the value is ignored beyond ns)
             if (sl >= L.ns) L.pix[j] = -1;
         }
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         for (int ks = 0; ks < WG_KS; ks++)
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-                long p = p0 + 16 * ks + 8 * kh + (i16 >> 2) + 4 * hf;
+                long p = p0 + 16 * (kq * WG_KS + ks) + 8 * kh + (i16 >> 2) + 4 * hf;
                 if (p >= P) p = P - 1; // (dy is zero there: no contribution)
                 L.vp[ks][hf] = vpos[p];
             }
@@ -431,25 +436,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         unsigned char *xl = wlds + buf * WG_XL, *dl = wlds + 2 * WG_XL + buf * WG_DL;
 #pragma unroll
         for (int j = 0; j < WG_XP; j++) {
-            if (j * 256 < L.ns * 4) { // block-uniform: this 4-KiB piece range holds slots of the tile
+            if (j * WG_NT + wave * 64 < L.ns * 4) { // wave-uniform: this wave's 64 pieces (16 slots) hold slots of the tile
                 const int piece = tid & 3;
                 const unsigned short *src = L.pix[j] >= 0 ? x + ((long)L.pix[j] * CIN + ci0 + piece * 8) : (const unsigned short *)&wide_zero16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(xl + (j * 256 + wv * 64) * 16), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(xl + (j * WG_NT + wave * 64) * 16), 16, 0, 0);
             }
         }
 #pragma unroll
-        for (int k = 0; k < WG_DL / 16 / 256; k++) {
-            const int idx = k * 256 + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
+        for (int k = 0; k < WG_DL / 16 / WG_NT; k++) {
+            const int idx = k * WG_NT + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
             const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : (const unsigned short *)&wide_zero16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dl + (k * 256 + wv * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dl + (k * WG_NT + wave * 64) * 16), 16, 0, 0);
         }
     };
     auto multiply = [&](const Look &L, int buf) {
         const unsigned xbase = lbase + (unsigned)(buf * WG_XL), dbase = lbase + (unsigned)(2 * WG_XL + buf * WG_DL);
         // dy fragment of k-step ks: pixel rows 16 ks + 8 kh + (i16 >> 2) (+4), this wave's channel group
-        const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
+        const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 16 * WG_KS * kq + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
         unsigned xa[WG_KS][2];
 #pragma unroll
         for (int ks = 0; ks < WG_KS; ks++)
@@ -511,6 +516,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wide_wrw_kernel(const unsigned
         Lcur = Lnext;
         Lnext = Lnn;
     }
+#if WG_KQ == 2
+    // the two k-halves of a channel group meet in LDS (9 x 16 floats per lane, lane-major: 36 KiB per wave pair, the tile
+    // buffers are free now) and the first half's waves issue the atomics
+    __syncthreads();
+    {
+        float *red = (float *)wlds + (wv * 64 + lane) * 4;
+        if (kq == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *(float4 *)(red + (t * 4 + g) * 1024) = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
+        __syncthreads();
+        if (kq == 1) return;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 v = *(const float4 *)(red + (t * 4 + g) * 1024);
+                acc[t][4 * g] += v.x; acc[t][4 * g + 1] += v.y; acc[t][4 * g + 2] += v.z; acc[t][4 * g + 3] += v.w;
+            }
+    }
+#endif
     // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the wave's 32
 #pragma unroll
     for (int t = 0; t < 9; t++)
@@ -573,8 +602,8 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
     if (shares < 1) shares = 1;
     if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return -6; // 120 KiB of dynamic LDS (per device: set on every launch)
-    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(256),
-                       2 * (WG_XL + WG_DL), (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
+    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(WG_NT),
+                       WG_LDS, (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
                        (int)shares);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
