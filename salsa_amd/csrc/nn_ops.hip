@@ -155,8 +155,19 @@ __device__ __forceinline__ void bn_sum_partials4(const P *__restrict__ part, int
     const int o = threadIdx.x & 7, seg = threadIdx.x >> 3;
     const int c = c0 + (o & 3), which = o >> 2;
     double acc = 0.0;
-    if (c < C)
-        for (int b = seg; b < nblk; b += 32) acc += (double)part[((long)b * 2 + which) * C + c];
+    if (c < C) // eight independent loads in flight per thread (one at a time, the loop was a chain of ~32 memory round trips:
+               // 7.9 us per launch, 42 launches per training step); the additions keep their order
+        for (int b = seg; b < nblk; b += 32 * 8) {
+            P v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int bb = b + 32 * u;
+                v[u] = part[((long)(bb < nblk ? bb : b) * 2 + which) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (b + 32 * u < nblk) acc += (double)v[u];
+        }
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s >= 8; s >>= 1) {
