@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, invalidate_conv_caches
+from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, invalidate_conv_caches,
+                     new_backward_generation)
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -95,6 +96,7 @@ class Encoder(nn.Module):
     def forward(self, x):
         if self.training and torch.is_grad_enabled():
             self._filter_bank.mark_stale()                     # training: the bank is rebuilt every forward, unconditionally
+            new_backward_generation()                          # weight-gradient buffers: one allocation + one fill per pass
         x = self.stem(x)
         x = F.dropout(x, p=self.p_dropout, training=self.training)
         return self.stages(x)

@@ -290,3 +290,28 @@ def test_train_bench_ddp_branch_under_gloo(tmp_path):
     assert l0['config']['parallelism'] == 'dp2' and l0['config']['grad_allreduce'] == 'fp32'
     assert l0['value'] > 0 and np.isfinite(l0['final_loss'])
     assert abs(l0['value'] - 2 * 2 * 2 / (l0['ms_per_step'] * 2 / 1e3)) / l0['value'] < 1e-2   # whole-job chunks / max-rank time
+
+
+def test_weight_gradient_buffer_pool_hands_out_fresh_zeros():
+    """nn_ops._GradZeros (one allocation + one fill per backward pass for the atomically accumulating weight-gradient kernels):
+    the first generation learns the plan through plain torch.zeros; later generations carve the requests out of ONE flat zero
+    tensor; a slice is never handed out twice nor re-zeroed (gradient accumulation keeps earlier gradients intact); requests
+    beyond the plan fall back to torch.zeros and extend it."""
+    from salsa_amd.crnn import nn_ops
+    g, dev = nn_ops._GradZeros(), torch.device('cpu')
+    g.new_generation()
+    first = [g.take((4, 3), dev), g.take((4, 3), dev), g.take((2, 2), dev)]
+    assert len({t.untyped_storage().data_ptr() for t in first}) == 3                 # learning pass: separate tensors
+    g.new_generation()
+    a, b, c = g.take((4, 3), dev), g.take((4, 3), dev), g.take((2, 2), dev)
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() == c.untyped_storage().data_ptr()
+    base = a.untyped_storage().data_ptr()
+    assert a.data_ptr() != b.data_ptr() and all((t.data_ptr() - base) % 256 == 0 for t in (a, b, c))
+    assert all((t == 0).all() for t in (a, b, c))
+    a += 5.0
+    extra = g.take((4, 3), dev)                                                      # a second backward through the same forward
+    assert (extra == 0).all() and extra.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    g.new_generation()
+    a3 = g.take((4, 3), dev)
+    assert (a3 == 0).all() and (a == 5).all() and a3.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    assert all((g.take((4, 3), dev) == 0).all() for _ in range(2))                   # the plan now holds three (4, 3) buffers
