@@ -18,6 +18,7 @@ from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
 FUSED_GRU = os.environ.get('SALSA_FUSED_GRU', '1') == '1'
+BATCHED_HEADS = os.environ.get('SALSA_BATCHED_HEADS', '1') == '1'   # the four FC heads as one batch of four (Decoder._heads_batched)
 
 
 def _xavier(layer):
@@ -165,8 +166,29 @@ class Decoder(nn.Module):
         return self._heads(seq)
 
     def _heads(self, seq):
+        if BATCHED_HEADS and seq.dim() == 3:
+            return self._heads_batched(seq)
         doa = torch.cat([torch.tanh(self.x(seq)), torch.tanh(self.y(seq)), torch.tanh(self.z(seq))], dim=-1)
         return {'event_frame_logit': self.event(seq), 'doa_frame_output': doa}
+
+    def _heads_batched(self, seq):
+        """The four heads (same shapes, same input, independent dropout masks) as ONE batch of four: two batched GEMMs, two
+        dropout launches and one tanh instead of eight small GEMMs, eight dropouts, three tanh and a concatenation -- with their
+        backward kernels the heads were ~0.45 ms of the 12-ms training step for 0.02 % of its FLOPs.  The parameters stay where
+        the reference's state dict has them (event / x / y / z . fc1 / fc2); they are stacked per call (four small copies)."""
+        heads = (self.event, self.x, self.y, self.z)
+        B, T, D = seq.shape
+        w1 = torch.stack([h.fc1.weight for h in heads])                    # (4, D/2, D)
+        b1 = torch.stack([h.fc1.bias for h in heads]).unsqueeze(1)         # (4, 1, D/2)
+        w2 = torch.stack([h.fc2.weight for h in heads])                    # (4, n_classes, D/2)
+        b2 = torch.stack([h.fc2.bias for h in heads]).unsqueeze(1)
+        x = seq.reshape(1, B * T, D).expand(4, B * T, D)
+        x = F.dropout(x, 0.2, self.training)                                # four independent masks (drop1 of each head)
+        h = F.relu(torch.baddbmm(b1, x, w1.transpose(1, 2)), inplace=True)
+        h = F.dropout(h, 0.2, self.training)
+        o = torch.baddbmm(b2, h, w2.transpose(1, 2))                        # (4, B*T, n_classes)
+        doa = torch.tanh(o[1:]).permute(1, 0, 2).reshape(B, T, 3 * o.shape[2])   # [x | y | z] along the last axis
+        return {'event_frame_logit': o[0].view(B, T, -1), 'doa_frame_output': doa}
 
 
 def interpolate_tensor(t, ratio: float):

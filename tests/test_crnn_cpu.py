@@ -315,3 +315,38 @@ def test_weight_gradient_buffer_pool_hands_out_fresh_zeros():
     a3 = g.take((4, 3), dev)
     assert (a3 == 0).all() and (a == 5).all() and a3.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
     assert all((g.take((4, 3), dev) == 0).all() for _ in range(2))                   # the plan now holds three (4, 3) buffers
+
+
+def test_batched_heads_equal_the_four_separate_heads():
+    """Decoder._heads_batched (the event / x / y / z heads as one batch of four GEMMs) against the module-by-module heads in eval
+    mode: outputs and every parameter / input gradient agree to float32 rounding, and dropout in training mode draws an
+    independent mask per head (the four first-layer inputs differ)."""
+    from salsa_amd.crnn import model as M
+    torch.manual_seed(0)
+    d = M.Decoder().eval()
+    seq = torch.randn(3, 10, 512, requires_grad=True)
+    res = {}
+    old = M.BATCHED_HEADS
+    try:
+        for flag in (False, True):
+            M.BATCHED_HEADS = flag
+            d.zero_grad()
+            seq.grad = None
+            o = d._heads(seq)
+            (o['event_frame_logit'].square().sum() + (o['doa_frame_output'] * torch.arange(36.0)).sum()).backward()
+            res[flag] = ({k: v.detach().clone() for k, v in o.items()}, [p.grad.clone() for n, p in d.named_parameters() if 'gru' not in n],
+                         seq.grad.clone())
+        M.BATCHED_HEADS = True
+        d.train()
+        torch.manual_seed(1)
+        o = d._heads(torch.ones(2, 50, 512))['doa_frame_output']
+        assert not torch.equal(o[..., :12], o[..., 12:24])                          # (x and y share nothing but the input)
+    finally:
+        M.BATCHED_HEADS = old
+    for k in res[False][0]:
+        assert res[True][0][k].shape == res[False][0][k].shape
+        assert torch.allclose(res[True][0][k], res[False][0][k], rtol=1e-5, atol=1e-6)
+    assert len(res[True][1]) == 16
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(res[True][2], res[False][2], rtol=1e-4, atol=1e-5)
