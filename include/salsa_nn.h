@@ -148,6 +148,16 @@ int salsa_nn_conv1x1_wrw(const void *x, const void *dy, float *dw, int64_t M, in
  * n_blocks = the total.  Cout, Cin % 32 == 0. */
 int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void *hip_stream);
 
+/* The SELD training loss and its gradients in one launch (reference models/interfaces.py:304-355, compute_loss: 0.3 x
+ * BCE-with-logits of the event logits + 0.7 x the sum over x / y / z of the activity-masked mean absolute error): logit, sed_gt
+ * [rows][nc], doa, doa_gt [rows][3 nc] (blocks x | y | z), float32 contiguous.  out3 = {loss, sed loss, doa loss};
+ * g_logit = d sed / d logit, g_doa = d doa / d prediction, unweighted.  salsa_nn_seld_loss_bwd scales them by the incoming
+ * gradients (device scalars, NULL = 0): out_a = a (g_loss w_sed + g_sed), out_b = b (g_loss w_doa + g_doa). */
+int salsa_nn_seld_loss(const float *logit, const float *doa, const float *sed_gt, const float *doa_gt, int64_t rows, int nc,
+                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, void *hip_stream);
+int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t nb, const float *g_loss, const float *g_sed,
+                           const float *g_doa, float w_sed, float w_doa, float *out_a, float *out_b, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,10 +191,23 @@ class Decoder(nn.Module):
         return {'event_frame_logit': o[0].view(B, T, -1), 'doa_frame_output': doa}
 
 
+_INTERP_IDX = {}
+
+
 def interpolate_tensor(t, ratio: float):
     """nearest-index resampling along time (model_utils.py:57-75): out[j] = in[floor(j / ratio)]."""
     n_out = int(round(t.shape[1] * float(ratio)))
-    idx = torch.floor(torch.arange(n_out, device=t.device) / float(ratio)).long()
+    r = int(round(float(ratio)))
+    if r >= 1 and float(ratio) == r and n_out == r * t.shape[1]:
+        # integer ratio (the SELD configuration: 2): floor(j / r) = j // r, i.e. every frame r times -- a broadcast view and one
+        # copy, whose backward is one sum, instead of arange / div / floor / index and an index_add into a zero tensor
+        return t.unsqueeze(2).expand(t.shape[0], t.shape[1], r, *t.shape[2:]).reshape(t.shape[0], n_out, *t.shape[2:])
+    key = (n_out, float(ratio), t.device)
+    idx = _INTERP_IDX.get(key)
+    if idx is None:
+        if len(_INTERP_IDX) > 16:
+            _INTERP_IDX.clear()
+        idx = _INTERP_IDX[key] = torch.floor(torch.arange(n_out, device=t.device) / float(ratio)).long()
     return t[:, idx]
 
 

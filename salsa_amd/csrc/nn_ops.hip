@@ -550,6 +550,79 @@ __global__ __launch_bounds__(256) void conv_filter_bank_kernel(const long long *
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------ SELD loss
+// models/interfaces.py:304-355 in one launch: sed = mean BCE-with-logits(logit, sed_gt); doa = sum over the x / y / z blocks of
+// sum(|p - t| m) / sum(m) with m = sed_gt (the three blocks share sum(m)); loss = w_sed sed + w_doa doa -- and the gradients of
+// sed w.r.t. logit and of doa w.r.t. the predictions (unweighted: the backward launch scales them by what flows in).
+// One workgroup: 4 x rows x nc elements (123 k in the training step), float64 sums, fixed order = deterministic.
+__global__ __launch_bounds__(1024) void seld_loss_kernel(const float *__restrict__ logit, const float *__restrict__ doa,
+                                                         const float *__restrict__ sed_gt, const float *__restrict__ doa_gt,
+                                                         long rows, int nc, float w_sed, float w_doa, float *__restrict__ out3,
+                                                         float *__restrict__ g_logit, float *__restrict__ g_doa)
+{
+    __shared__ double red[3][1024];
+    const long n = rows * nc;
+    double s_bce = 0.0, s_mask = 0.0, s_abs = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const long r = i / nc;
+        const int c = (int)(i - r * nc);
+        const float x = logit[i], z = sed_gt[i];
+        // max(x, 0) - x z + log1p(exp(-|x|))  (torch's binary_cross_entropy_with_logits)
+        s_bce += (double)(fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))));
+        s_mask += (double)z;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) a += fabsf(doa[r * 3 * nc + k * nc + c] - doa_gt[r * 3 * nc + k * nc + c]) * z;
+        s_abs += (double)a;
+    }
+    red[0][threadIdx.x] = s_bce;
+    red[1][threadIdx.x] = s_mask;
+    red[2][threadIdx.x] = s_abs;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int k = 0; k < 3; k++) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    const float sed = (float)(red[0][0] / (double)n);
+    const float msum = (float)red[1][0];
+    const float d = (float)red[2][0] / msum; // 0 / 0 = nan when no class is active anywhere, as in the reference
+    if (threadIdx.x == 0) {
+        out3[0] = w_sed * sed + w_doa * d;
+        out3[1] = sed;
+        out3[2] = d;
+    }
+    const float inv_n = 1.f / (float)n, inv_m = 1.f / msum;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const long r = i / nc;
+        const int c = (int)(i - r * nc);
+        const float x = logit[i], z = sed_gt[i];
+        g_logit[i] = (1.f / (1.f + expf(-x)) - z) * inv_n;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const long j = r * 3 * nc + k * nc + c;
+            const float e = doa[j] - doa_gt[j];
+            g_doa[j] = (e > 0.f ? 1.f : e < 0.f ? -1.f : 0.f) * z * inv_m;
+        }
+    }
+}
+
+// backward: g_logit *= g_loss w_sed + g_sed ; g_doa *= g_loss w_doa + g_doa_loss   (the incoming gradients are device scalars
+// or NULL = 0), out of place
+__global__ __launch_bounds__(256) void seld_loss_scale_kernel(const float *__restrict__ a, long na, const float *__restrict__ b,
+                                                              long nb, const float *__restrict__ g_loss,
+                                                              const float *__restrict__ g_sed, const float *__restrict__ g_d,
+                                                              float w_sed, float w_doa, float *__restrict__ oa,
+                                                              float *__restrict__ ob)
+{
+    const float gl = g_loss ? *g_loss : 0.f;
+    const float fa = gl * w_sed + (g_sed ? *g_sed : 0.f), fb = gl * w_doa + (g_d ? *g_d : 0.f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (long)gridDim.x * 256) {
+        if (i < na) oa[i] = a[i] * fa;
+        else ob[i - na] = b[i - na] * fb;
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -784,6 +857,29 @@ int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void
     if (!desc || n_layers <= 0 || n_blocks <= 0) return -1;
     hipLaunchKernelGGL(conv_filter_bank_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, (const long long *)desc,
                        n_layers);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* SELD training loss and its gradients (salsa_amd/crnn/loss.py; reference models/interfaces.py:304-355): logit, sed_gt
+ * [rows][nc]; doa, doa_gt [rows][3 nc] float32 contiguous.  out3 = {loss, sed, doa}; g_logit / g_doa = d sed / d logit and
+ * d doa / d prediction (unweighted). */
+int salsa_nn_seld_loss(const float *logit, const float *doa, const float *sed_gt, const float *doa_gt, int64_t rows, int nc,
+                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, void *hip_stream)
+{
+    if (!logit || !doa || !sed_gt || !doa_gt || !out3 || !g_logit || !g_doa || rows <= 0 || nc <= 0) return -1;
+    hipLaunchKernelGGL(seld_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, logit, doa, sed_gt, doa_gt, (long)rows, nc,
+                       w_sed, w_doa, out3, g_logit, g_doa);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* out_a = a (g_loss w_sed + g_sed), out_b = b (g_loss w_doa + g_doa): the loss's backward; g_* are device scalars or NULL (= 0) */
+int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t nb, const float *g_loss, const float *g_sed,
+                           const float *g_doa, float w_sed, float w_doa, float *out_a, float *out_b, void *hip_stream)
+{
+    if (!a || !b || !out_a || !out_b || na <= 0 || nb <= 0) return -1;
+    const long blocks = (na + nb + 255) / 256;
+    hipLaunchKernelGGL(seld_loss_scale_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)hip_stream, a,
+                       (long)na, b, (long)nb, g_loss, g_sed, g_doa, w_sed, w_doa, out_a, out_b);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

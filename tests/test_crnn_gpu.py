@@ -829,3 +829,41 @@ def test_first_layer_statistics_epilogue_matches_the_stored_tensor():
         tot, yf = part.view(nb, 2, 64).sum(0), y.double()
         torch.testing.assert_close(tot[0], yf.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
         torch.testing.assert_close(tot[1], (yf * yf).sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+def test_fused_seld_loss_matches_the_eager_loss():
+    """salsa_nn_seld_loss / _bwd (loss + gradients in one launch each) against the eager torch expression of crnn/loss.py
+    (reference models/interfaces.py:304-355): the three values to 1e-6 relative, the gradients w.r.t. both predictions to 1e-6
+    of their scale, also when the detached parts receive gradients of their own; a batch with no active class gives nan in
+    both (0 / 0), as the reference does."""
+    from salsa_amd.crnn import loss as L
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(5)
+    B, T, nc = 8, 80, 12
+    sed = (torch.rand(B, T, nc, generator=g) < 0.2).float().to(dev)
+    doa_gt = (torch.rand(B, T, 3 * nc, generator=g) * 2 - 1).to(dev) * sed.repeat(1, 1, 3)
+    logit0 = (torch.randn(B, T, nc, generator=g) * 3).to(dev)
+    doa0 = torch.tanh(torch.randn(B, T, 3 * nc, generator=g)).to(dev)
+    doa0[0, 0, :4] = doa_gt[0, 0, :4]                                   # exact hits: sign(0) = 0 in both
+    res = {}
+    old = L.FUSED_LOSS
+    try:
+        for fused in (False, True):
+            L.FUSED_LOSS = fused
+            logit, doa = logit0.clone().requires_grad_(True), doa0.clone().requires_grad_(True)
+            out = L.seld_loss({'event_frame_logit': logit, 'doa_frame_output': doa}, sed, doa_gt)
+            (out[0] * 1.7 + out[1] * 0.25 - out[2] * 0.5).backward()
+            res[fused] = ([float(o.detach()) for o in out], logit.grad.clone(), doa.grad.clone())
+            logit.grad = doa.grad = None
+            out = L.seld_loss({'event_frame_logit': logit, 'doa_frame_output': doa}, sed, doa_gt)
+            out[0].backward()                                          # the trainer's case: only the total is differentiated
+            res[fused] += (logit.grad.clone(), doa.grad.clone())
+        L.FUSED_LOSS = True
+        nan = L.seld_loss({'event_frame_logit': logit0, 'doa_frame_output': doa0}, torch.zeros_like(sed), doa_gt)
+        assert torch.isnan(nan[2]) and torch.isnan(nan[0]) and torch.isfinite(nan[1])
+    finally:
+        L.FUSED_LOSS = old
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 1e-6 * abs(b) + 1e-7, (res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert a.shape == b.shape and (a - b).abs().max() <= 1e-6 * b.abs().max(), (a - b).abs().max()
