@@ -6,6 +6,7 @@
 // in LDS, and W_hh (768 KB fp32 per direction) is streamed from L2 every step with coalesced rows -- every workgroup of a
 // direction reads the same weights, so they stay L2-resident.  float32 throughout (same arithmetic as nn.GRU fp32).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "../../include/salsa_gru.h"
 
 namespace {
@@ -124,6 +125,8 @@ __global__ __launch_bounds__(H) void gru_bwd_kernel(const float *__restrict__ dh
 // training keeps the float32 kernels above.  One barrier per step (h is double-buffered); nothing but the weights lives
 // in registers across steps (biases are re-read with the step's input projections: kept, they were spilled).
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int H>
 __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restrict__ gi, const float *__restrict__ whh,
@@ -149,7 +152,12 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
         const int t = d == 0 ? s : T - 1 - s;
         const long base = ((long)t * B + b) * D + d;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, br = 0.f, bz = 0.f, bn = 0.f;
+#ifdef GRU_PROBE_NO_GI
+        g0 = 0.1f; g1 = -0.2f; g2 = 0.3f; br = bz = bn = 0.01f;
+        if (false) {
+#else
         if (part == 0) { // this step's input projections, in flight during the dot products
+#endif
             const float *g = gi + base * 3 * H;
             g0 = g[q];
             g1 = g[H + q];
@@ -162,38 +170,61 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
             bz = bp[H];
             bn = bp[2 * H];
         }
-        typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2))); // the operand type of the dot-product builtin
         const uint4 *hp = (const uint4 *)&h[s & 1][part * KS];
         float ar = 0.f, az = 0.f, an = 0.f;
+        // LDS reads one ahead of the dot products that consume them, issued and waited for by hand (the compiler cannot count
+        // LDS returns across the asm statements below and would wait for the read it has just issued)
+        const unsigned haddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)hp;
+        u32x4 hb[2];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(hb[0]) : "v"(haddr));
+#ifdef GRU_PROBE_NO_DOT
+#pragma unroll
+        for (int i = 0; i < 0; i++) {
+#else
 #pragma unroll
         for (int i = 0; i < KS / 8; i++) {
-            const uint4 raw = hp[i]; // 8 consecutive elements of h
-            const unsigned hv[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int g = 0; g < 3; g++) {
-                float acc = g == 0 ? ar : g == 1 ? az : an;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    half2_t w = wp[g][4 * i + j];
-                    asm volatile("" : "+v"(w)); // keeps each weight pair packed in its one register
-                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(fp16x2_t, w), __builtin_bit_cast(fp16x2_t, hv[j]), acc, false); // v_dot2_f32_f16
-                }
-                if (g == 0) ar = acc;
-                else if (g == 1) az = acc;
-                else an = acc;
+#endif
+            if (i + 1 < KS / 8) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hb[(i + 1) & 1]) : "v"(haddr), "n"(16 * (i + 1)));
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(hb[i & 1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hb[i & 1]));
             }
-            __builtin_amdgcn_sched_barrier(0); // 96 of the 128 registers hold weights: one h vector in flight at a time
+            const unsigned hv[4] = {hb[i & 1].x, hb[i & 1].y, hb[i & 1].z, hb[i & 1].w}; // 8 consecutive elements of h
+            // v_dot2c_f32_f16 acc, w, h written out: the weights are plain INPUT operands.  (Round 2 had the builtin behind an
+            // empty asm with the weight as an in/out operand to keep each pair packed in its register -- which made the compiler
+            // copy every weight to a scratch register first: v_mov + s_nop + v_dot2 per pair, 2.0 of the step's 2.3 us.)  The three
+            // gates' accumulators alternate, so no dot product waits for the one before it.
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(ar) : "v"(wp[0][4 * i + j]), "v"(hv[j]));
+                asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(az) : "v"(wp[1][4 * i + j]), "v"(hv[j]));
+                asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(an) : "v"(wp[2][4 * i + j]), "v"(hv[j]));
+            }
         }
+#ifdef GRU_PROBE_NO_DOT
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hb[0]));
+#endif
         ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
         ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
         if (part == 0) {
+#ifdef GRU_PROBE_NO_GATE
+            const float r = g0 + ar + br, z = 0.5f + 1e-3f * (g1 + az + bz), n = g2 + r * (an + bn) * 1e-3f;
+#else
             const float r = sigmoid_fast(g0 + ar + br);
             const float z = sigmoid_fast(g1 + az + bz);
             const float n = tanh_fast(g2 + r * (an + bn));
+#endif
             hq = (1.f - z) * n + z * hq;
+#ifndef GRU_PROBE_NO_STORE
             hs[base * H + q] = hq;
+#endif
             h[(s + 1) & 1][q] = (_Float16)hq;
-            if (saved) { // for the backward scan: r, z, n and W_hn h + b_hn
+#ifdef GRU_PROBE_NO_STORE
+            if (saved && hq == 123.f) {
+#else
+            if (saved) {
+#endif // for the backward scan: r, z, n and W_hn h + b_hn
                 float *sv = saved + base * 4 * H;
                 sv[q] = r;
                 sv[H + q] = z;
@@ -205,25 +236,35 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
     }
 }
 
-// Backward scan with W_hh resident in registers (float16), the counterpart of gru_fwd_regw_kernel: thread (q, part) keeps
-// COLUMN q of W_hh for the rows part*192 .. +191 (192 weights), i.e. its share of dh_prev[q] = sum_rows W_hh[row][q] * dgh[row].
-// Per step: the part-0 lane of unit q forms the gate derivatives of its unit and publishes (dr_pre, dz_pre, dhn) in LDS; after
-// a barrier every thread multiplies its 192 weights with its slice of that vector and a 4-lane butterfly completes dh_prev.
+// Backward scan with W_hh resident in registers (float16), the counterpart of gru_fwd_regw_kernel.  dh_prev[q] = sum over the 3H
+// rows of W_hh[row][q] * dgh[row].  Thread (cg, rs) keeps the 4 columns 4 cg .. 4 cg + 3 of the 48 rows rs * 48 .. + 47 (192 weights,
+// two rows of one column per register).  Per step: lane rs = c < 4 of group cg forms the gate derivatives of unit 4 cg + c and
+// publishes (dr_pre, dz_pre, dhn) in LDS; after a barrier every thread multiplies its weights with ITS 48-row slice of that
+// vector (12 reads of 16 B) and a 16-lane DPP reduction completes the four columns.
+// (Round 2's layout -- one column x 192 rows per thread -- had every thread read 768 B of LDS per step: 16 waves x 48
+// ds_read_b128 = 6 144 LDS cycles, 5 of the step's 6.2 us; the LDS moves a full 1 KiB per wave-read whether or not lanes share
+// addresses.  Four columns per thread need a quarter of the reads for the same 192 multiply-adds.)
 template <int H>
 __global__ __launch_bounds__(1024) void gru_bwd_regw_kernel(const float *__restrict__ dhs, const float *__restrict__ whh,
                                                             const float *__restrict__ hs, const float *__restrict__ saved,
                                                             float *__restrict__ dgi, float *__restrict__ dgh, int T, int B, int D)
 {
-    static_assert(H == 256, "1024 threads = 256 units x 4 row slices");
-    constexpr int RS = 3 * H / 4; // rows per thread
+    static_assert(H == 256, "1024 threads = 64 groups of 4 columns x 16 row slices");
+    constexpr int RS = 3 * H / 16; // rows per thread: 48
     __shared__ __attribute__((aligned(16))) float g[2][3 * H];
-    const int q = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int cg = threadIdx.x >> 4, rs = threadIdx.x & 15;
+    const int q = 4 * cg + (rs & 3); // the unit whose gate derivatives this lane forms (lanes rs < 4 only)
+    const bool gate_lane = rs < 4;
     const int b = blockIdx.x, d = blockIdx.y;
-    half2_t wp[RS / 2];
+    half2_t wp[4][RS / 2];
 #pragma unroll
     for (int i = 0; i < RS / 2; i++) {
-        const float *w0 = whh + ((long)d * 3 * H + part * RS + 2 * i) * H + q;
-        wp[i] = half2_t{(_Float16)w0[0], (_Float16)w0[H]};
+        const float *w0 = whh + ((long)d * 3 * H + rs * RS + 2 * i) * H + 4 * cg;
+        const float4 r0 = *(const float4 *)w0, r1 = *(const float4 *)(w0 + H);
+        wp[0][i] = half2_t{(_Float16)r0.x, (_Float16)r1.x};
+        wp[1][i] = half2_t{(_Float16)r0.y, (_Float16)r1.y};
+        wp[2][i] = half2_t{(_Float16)r0.z, (_Float16)r1.z};
+        wp[3][i] = half2_t{(_Float16)r0.w, (_Float16)r1.w};
     }
     float carry = 0.f;
     for (int s = T - 1; s >= 0; s--) { // reverse of the forward scan order
@@ -231,21 +272,32 @@ __global__ __launch_bounds__(1024) void gru_bwd_regw_kernel(const float *__restr
         const long base = ((long)t * B + b) * D + d;
         float dhz = 0.f;
         float *gs = g[s & 1];
-        if (part == 0) {
+        if (gate_lane) {
             float hprev = 0.f;
+#ifdef GRU_PROBE_BWD_NO_LOAD
+            if (false) {
+#else
             if (s > 0) {
+#endif
                 const int tp = d == 0 ? t - 1 : t + 1;
                 hprev = hs[(((long)tp * B + b) * D + d) * H + q];
             }
             const float *sv = saved + base * 4 * H;
+#ifdef GRU_PROBE_BWD_NO_LOAD
+            const float r = 0.3f, z = 0.4f, n = 0.1f, hn = 0.2f;
+            const float dh = 0.01f + carry;
+            (void)sv;
+#else
             const float r = sv[q], z = sv[H + q], n = sv[2 * H + q], hn = sv[3 * H + q];
             const float dh = dhs[base * H + q] + carry;
+#endif
             const float dn = dh * (1.f - z);
             const float dz = dh * (hprev - n);
             const float dn_pre = dn * (1.f - n * n);
             const float dr_pre = dn_pre * hn * r * (1.f - r);
             const float dz_pre = dz * z * (1.f - z);
             const float dhn = dn_pre * r;
+#ifndef GRU_PROBE_BWD_NO_STORE
             float *o = dgi + base * 3 * H;
             o[q] = dr_pre;
             o[H + q] = dz_pre;
@@ -254,28 +306,58 @@ __global__ __launch_bounds__(1024) void gru_bwd_regw_kernel(const float *__restr
             qq[q] = dr_pre;
             qq[H + q] = dz_pre;
             qq[2 * H + q] = dhn;
+#endif
             gs[q] = dr_pre;
             gs[H + q] = dz_pre;
             gs[2 * H + q] = dhn;
             dhz = dh * z;
         }
         __syncthreads(); // g of this step is complete (the other buffer may still be read by slower waves: double-buffered)
-        const float4 *gp = (const float4 *)&gs[part * RS];
-        float acc = 0.f;
+        // v_fma_mix_f32 acc, w.lo|hi (float16), g (float32), acc written out with the weights as plain INPUT operands (round 2: the
+        // compiler's own fma_mix behind an empty asm with in/out weights = a v_mov per pair) and one accumulator per column; the
+        // LDS reads run one ahead of the multiply-adds that consume them, issued and counted by hand (see the forward kernel)
+        const unsigned gaddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)&gs[rs * RS];
+        f32x4 gb[2];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(gb[0]) : "v"(gaddr));
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#ifdef GRU_PROBE_BWD_NO_MATVEC
+#pragma unroll
+        for (int i = RS / 4 - 1; i < RS / 4; i++) {
+#else
 #pragma unroll
         for (int i = 0; i < RS / 4; i++) {
-            const float4 gv = gp[i];
-            half2_t w01 = wp[2 * i], w23 = wp[2 * i + 1];
-            asm volatile("" : "+v"(w01), "+v"(w23)); // keep the loop-invariant half -> float conversions out of registers
-            acc = fmaf((float)w01.x, gv.x, acc);
-            acc = fmaf((float)w01.y, gv.y, acc);
-            acc = fmaf((float)w23.x, gv.z, acc);
-            acc = fmaf((float)w23.y, gv.w, acc);
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (i + 1 < RS / 4) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(gb[(i + 1) & 1]) : "v"(gaddr), "n"(16 * (i + 1)));
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(gb[i & 1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gb[i & 1]));
+            }
+            const f32x4 gv = gb[i & 1];
+#define GRU_MIX_LO(acc, w, x) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(w), "v"(x))
+#define GRU_MIX_HI(acc, w, x) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(w), "v"(x))
+            GRU_MIX_LO(a0, wp[0][2 * i], gv.x); GRU_MIX_LO(a1, wp[1][2 * i], gv.x); GRU_MIX_LO(a2, wp[2][2 * i], gv.x); GRU_MIX_LO(a3, wp[3][2 * i], gv.x);
+            GRU_MIX_HI(a0, wp[0][2 * i], gv.y); GRU_MIX_HI(a1, wp[1][2 * i], gv.y); GRU_MIX_HI(a2, wp[2][2 * i], gv.y); GRU_MIX_HI(a3, wp[3][2 * i], gv.y);
+            GRU_MIX_LO(a0, wp[0][2 * i + 1], gv.z); GRU_MIX_LO(a1, wp[1][2 * i + 1], gv.z); GRU_MIX_LO(a2, wp[2][2 * i + 1], gv.z); GRU_MIX_LO(a3, wp[3][2 * i + 1], gv.z);
+            GRU_MIX_HI(a0, wp[0][2 * i + 1], gv.w); GRU_MIX_HI(a1, wp[1][2 * i + 1], gv.w); GRU_MIX_HI(a2, wp[2][2 * i + 1], gv.w); GRU_MIX_HI(a3, wp[3][2 * i + 1], gv.w);
+#undef GRU_MIX_LO
+#undef GRU_MIX_HI
         }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        carry = acc + dhz; // only read by the part-0 lane
+        // sum over the 16 row slices (= the 16 lanes of a DPP row): quad butterflies, then the two mirrors; every lane ends with
+        // the four totals and lane rs = c keeps column c's
+        auto row_sum = [](float x) {
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true)); // row_half_mirror
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true)); // row_mirror
+            return x;
+        };
+        a0 = row_sum(a0);
+        a1 = row_sum(a1);
+        a2 = row_sum(a2);
+        a3 = row_sum(a3);
+        const int c = rs & 3;
+        carry = (c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3) + dhz; // only read by the gate lanes
     }
 }
 
