@@ -151,24 +151,15 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
     for (int s = 0; s < T; s++) {
         const int t = d == 0 ? s : T - 1 - s;
         const long base = ((long)t * B + b) * D + d;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, br = 0.f, bz = 0.f, bn = 0.f;
-#ifdef GRU_PROBE_NO_GI
-        g0 = 0.1f; g1 = -0.2f; g2 = 0.3f; br = bz = bn = 0.01f;
-        if (false) {
-#else
-        if (part == 0) { // this step's input projections, in flight during the dot products
-#endif
-            const float *g = gi + base * 3 * H;
-            g0 = g[q];
-            g1 = g[H + q];
-            g2 = g[2 * H + q];
-            // the biases too: 96 of the 128 registers hold weights, so values kept across steps were being spilled and
-            // reloaded from scratch one by one in the middle of the gate math; re-read (L1 hits) they ride with the loads above
-            const float *bp = bhh + d * 3 * H + q;
+        // lane `part` of a unit's quad owns one gate: 0 = r, 1 = z, 2 = n and the unit's state; each loads ITS input projection
+        // and bias (in flight during the dot products).  The biases are re-read every step: 96 of the 128 registers hold weights,
+        // values kept across steps were being spilled; re-read (L1 hits) they ride with the projections.
+        float gx = 0.f, bx = 0.f;
+        if (part < 3) {
+            gx = gi[base * 3 * H + part * H + q];
+            const float *bp = bhh + d * 3 * H + part * H + q;
             asm volatile("" : "+v"(bp)); // (not loop-invariant as far as the compiler can tell)
-            br = bp[0];
-            bz = bp[H];
-            bn = bp[2 * H];
+            bx = bp[0];
         }
         const uint4 *hp = (const uint4 *)&h[s & 1][part * KS];
         float ar = 0.f, az = 0.f, an = 0.f;
@@ -177,13 +168,8 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
         const unsigned haddr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)hp;
         u32x4 hb[2];
         asm volatile("ds_read_b128 %0, %1" : "=v"(hb[0]) : "v"(haddr));
-#ifdef GRU_PROBE_NO_DOT
-#pragma unroll
-        for (int i = 0; i < 0; i++) {
-#else
 #pragma unroll
         for (int i = 0; i < KS / 8; i++) {
-#endif
             if (i + 1 < KS / 8) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hb[(i + 1) & 1]) : "v"(haddr), "n"(16 * (i + 1)));
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(hb[i & 1]));
@@ -202,34 +188,32 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
                 asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(an) : "v"(wp[2][4 * i + j]), "v"(hv[j]));
             }
         }
-#ifdef GRU_PROBE_NO_DOT
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hb[0]));
-#endif
-        ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
-        ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
-        if (part == 0) {
-#ifdef GRU_PROBE_NO_GATE
-            const float r = g0 + ar + br, z = 0.5f + 1e-3f * (g1 + az + bz), n = g2 + r * (an + bn) * 1e-3f;
-#else
-            const float r = sigmoid_fast(g0 + ar + br);
-            const float z = sigmoid_fast(g1 + az + bz);
-            const float n = tanh_fast(g2 + r * (an + bn));
-#endif
+        // the four column slices of a unit are the four lanes of a DPP quad: two quad permutes instead of two LDS shuffles
+        auto quad_sum = [](float x) {
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+            return x;
+        };
+        ar = quad_sum(ar);
+        az = quad_sum(az);
+        an = quad_sum(an);
+        // gates, one per lane of the quad: r and z through ONE sigmoid (lanes 0 and 1), broadcast to the quad; lane 2 finishes n
+        // and the state.  (Round 2: lane 0 did all three -- every wave issued two sigmoids and a tanh for 16 active lanes.)
+        const float a = part == 0 ? ar : part == 1 ? az : an;
+        const float hn = a + bx;                                  // lane 2: W_hn h + b_hn
+        const float sg = sigmoid_fast(gx + a + bx);               // lane 0: r, lane 1: z
+        const float r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0x00, 0xF, 0xF, true)); // quad_perm [0,0,0,0]
+        const float z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sg), 0x55, 0xF, 0xF, true)); // quad_perm [1,1,1,1]
+        if (saved && part < 2) saved[base * 4 * H + part * H + q] = sg; // for the backward scan: r, z, n and W_hn h + b_hn
+        if (part == 2) {
+            const float n = tanh_fast(gx + r * hn);
             hq = (1.f - z) * n + z * hq;
-#ifndef GRU_PROBE_NO_STORE
             hs[base * H + q] = hq;
-#endif
             h[(s + 1) & 1][q] = (_Float16)hq;
-#ifdef GRU_PROBE_NO_STORE
-            if (saved && hq == 123.f) {
-#else
             if (saved) {
-#endif // for the backward scan: r, z, n and W_hn h + b_hn
                 float *sv = saved + base * 4 * H;
-                sv[q] = r;
-                sv[H + q] = z;
                 sv[2 * H + q] = n;
-                sv[3 * H + q] = an + bn;
+                sv[3 * H + q] = hn;
             }
         }
         __syncthreads();
