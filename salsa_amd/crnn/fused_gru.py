@@ -48,30 +48,32 @@ def _ones(n, device):
 
 
 class _InputProjection(torch.autograd.Function):
-    """gi[t, b, d] = W_ih[d] x[b, t] + b_ih[d] for both directions (D, 3H, In): the einsum + bias of the scan's input, with
-    the bias gradient as a ones-row GEMV instead of autograd's reduction over (t, b)."""
+    """gi[t, b, d] = W_ih[d] x[t, b] + b_ih[d] for both directions (D, 3H, In): the einsum + bias of the scan's input, with
+    the bias gradient as a ones-row GEMV instead of autograd's reduction over (t, b).  TIME-MAJOR in and out (x (T, B, In) ->
+    gi (T, B, D, 3H)): the GEMM's rows are already in the scan's order, so neither gi nor its gradient is transposed (two 7.8-MB
+    copies per layer per step when x was batch-major)."""
 
     @staticmethod
     def forward(ctx, x, wih, bih):
         ctx.save_for_backward(x, wih)
-        B, T, In = x.shape
+        T, B, In = x.shape
         D, G, _ = wih.shape
-        gi = torch.addmm(bih.reshape(1, D * G), x.reshape(B * T, In), wih.reshape(D * G, In).t())      # (B*T, D*3H)
-        return gi.view(B, T, D, G).transpose(0, 1).contiguous()                                        # (T, B, D, 3H)
+        gi = torch.addmm(bih.reshape(1, D * G), x.reshape(T * B, In), wih.reshape(D * G, In).t())      # (T*B, D*3H)
+        return gi.view(T, B, D, G)
 
     @staticmethod
     def backward(ctx, dgi):
         x, wih = ctx.saved_tensors
-        B, T, In = x.shape
+        T, B, In = x.shape
         D, G, _ = wih.shape
-        g2 = dgi.transpose(0, 1).reshape(B * T, D * G)                                                 # (B*T, D*3H), rows as in x
+        g2 = dgi.reshape(T * B, D * G)                                                                 # rows as in x
         dx = dwih = dbih = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(g2, wih.reshape(D * G, In)).view(B, T, In)
+            dx = torch.mm(g2, wih.reshape(D * G, In)).view(T, B, In)
         if ctx.needs_input_grad[1]:
-            dwih = torch.mm(g2.t(), x.reshape(B * T, In)).view(D, G, In)
+            dwih = torch.mm(g2.t(), x.reshape(T * B, In)).view(D, G, In)
         if ctx.needs_input_grad[2]:
-            dbih = torch.mv(g2.t(), _ones(B * T, x.device)).view(D, G)
+            dbih = torch.mv(g2.t(), _ones(T * B, x.device)).view(D, G)
         return dx, dwih, dbih
 
 
@@ -145,7 +147,7 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weigh
     alike.  A float32 caller (half_weights=False) gets the float32 streaming kernels in both modes, so pure-float32
     evaluation matches float32 training and the reference's nn.GRU."""
     assert gru.batch_first and gru.bidirectional and gru.bias
-    out = x
+    out = x.transpose(0, 1).contiguous()        # time-major between the layers: the scans' order (one copy in, one view out)
     for layer in range(gru.num_layers):
         names = ['_l%d' % layer, '_l%d_reverse' % layer]
         wih = torch.stack([getattr(gru, 'weight_ih' + n) for n in names])          # (D,3H,In)
@@ -154,12 +156,12 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weigh
         bhh = torch.stack([getattr(gru, 'bias_hh' + n) for n in names])
         if layer > 0 and training and gru.dropout > 0:
             out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
-        gi = _InputProjection.apply(out.contiguous(), wih, bih) if (out.is_cuda and LEAN) else \
-            (torch.einsum('bti,dgi->tbdg', out, wih) + bih).contiguous()           # (T,B,D,3H)
+        gi = _InputProjection.apply(out, wih, bih) if (out.is_cuda and LEAN) else \
+            (torch.einsum('tbi,dgi->tbdg', out, wih) + bih).contiguous()           # (T,B,D,3H)
         no_grad = not (torch.is_grad_enabled() and (gi.requires_grad or whh.requires_grad))
         if REGISTER_WEIGHTS and half_weights and whh.shape[2] == 256 and no_grad:
             hs = _scan_inference(gi, whh, bhh)                                      # W_hh (float16) resident in registers
         else:
             hs = _GruScan.apply(gi, whh, bhh, bool(half_weights and REGISTER_WEIGHTS and whh.shape[2] == 256))   # (T,B,D,H)
-        out = hs.permute(1, 0, 2, 3).reshape(x.shape[0], x.shape[1], -1)
-    return out
+        out = hs.view(hs.shape[0], hs.shape[1], -1)                                 # (T, B, D*H)
+    return out.transpose(0, 1)                                                      # (B, T, 2H), a view
