@@ -158,6 +158,12 @@ int salsa_nn_seld_loss(const float *logit, const float *doa, const float *sed_gt
 int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t nb, const float *g_loss, const float *g_sed,
                            const float *g_doa, float w_sed, float w_doa, float *out_a, float *out_b, void *hip_stream);
 
+/* The decoder's frequency mean (reference models/decoders.py: x.mean(dim=3) then (B, C, T) -> (B, T, C)) in one pass:
+ * x bf16 channels-last [N][H][W][C] -> float32 y [H][N][C] (time_major != 0: the GRU scans' order) or [N][H][C]; C % 8 == 0.
+ * _bwd: dx[n][h][w][c] = g[row(n, h)][c] / W, bf16 channels-last. */
+int salsa_nn_freq_mean_fwd(const void *x, float *y, int64_t N, int H, int W, int C, int time_major, void *hip_stream);
+int salsa_nn_freq_mean_bwd(const float *g, void *dx, int64_t N, int H, int W, int C, int time_major, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, invalidate_conv_caches,
-                     new_backward_generation)
+from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, freq_mean_sequence,
+                     invalidate_conv_caches, new_backward_generation)
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -146,7 +146,7 @@ class Decoder(nn.Module):
         self.x, self.y, self.z = Head(2 * size, n_classes), Head(2 * size, n_classes), Head(2 * size, n_classes)
 
     def forward(self, feat):
-        seq = feat.mean(dim=3).transpose(1, 2)                  # (B, T', 512)
+        seq = freq_mean_sequence(feat)                          # (B, T', 512): mean over frequency
         if seq.is_cuda and GRU_FP32:
             # 0.4 % of the FLOPs but, under bf16 autocast, ~6000 per-timestep cell kernels per forward (torch's native
             # fallback); in float32 the whole sequence goes through MIOpen's fused RNN

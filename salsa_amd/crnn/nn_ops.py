@@ -210,6 +210,45 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         return y
 
 
+USE_HIP_FREQ_MEAN = os.environ.get('SALSA_HIP_FREQ_MEAN', '1') != '0'
+
+
+class _FreqMean(torch.autograd.Function):
+    """salsa_nn_freq_mean_fwd / _bwd: (N, C, T, F) bf16 channels-last -> float32 (T, N, C) time-major mean over F."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Cn, H, W = x.shape
+        y = torch.empty((H, N, Cn), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().salsa_nn_freq_mean_fwd(_ptr(x), _ptr(y), N, H, W, Cn, 1, _stream(x))
+        if rc:
+            raise RuntimeError('salsa_nn_freq_mean_fwd failed (%d)' % rc)
+        ctx.shape = (N, Cn, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, Cn, H, W = ctx.shape
+        g = g.contiguous().float()
+        dx = torch.empty((N, Cn, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().salsa_nn_freq_mean_bwd(_ptr(g), _ptr(dx), N, H, W, Cn, 1, _stream(g))
+        if rc:
+            raise RuntimeError('salsa_nn_freq_mean_bwd failed (%d)' % rc)
+        return dx
+
+
+def freq_mean_sequence(feat):
+    """(B, C, T, F) encoder output -> (B, T, C) float32: the mean over frequency and the transpose of models/decoders.py in one
+    pass for bf16 channels-last CUDA maps (the result is a view of a TIME-major buffer, the order the GRU scans want);
+    ``feat.mean(dim=3).transpose(1, 2)`` otherwise."""
+    if (USE_HIP_FREQ_MEAN and feat.is_cuda and feat.dtype == torch.bfloat16 and feat.dim() == 4 and feat.shape[1] % 8 == 0
+            and feat.is_contiguous(memory_format=torch.channels_last)):
+        return _FreqMean.apply(feat).transpose(0, 1)
+    return feat.mean(dim=3).transpose(1, 2)
+
+
 class _GradZeros:
     """Zero-initialised float32 weight-gradient buffers for the atomically accumulating weight-gradient kernels, ONE allocation
     and ONE fill per backward pass instead of one ``torch.zeros`` per layer (25 fills of ~4 us in the training step).

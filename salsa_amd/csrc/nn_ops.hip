@@ -550,6 +550,57 @@ __global__ __launch_bounds__(256) void conv_filter_bank_kernel(const long long *
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------ frequency mean
+// The decoder's first step (models/decoders.py: x.mean(dim=3), then (B, C, T) -> (B, T, C)): x bf16 channels-last [N][H][W][C]
+// -> float32 [H][N][C] (time-major, the GRU's order) or [N][H][C]; torch's reduction over the strided axis ran at 0.4 TB/s.
+__global__ __launch_bounds__(256) void freq_mean_fwd_kernel(const unsigned short *__restrict__ x, float *__restrict__ y, long rows,
+                                                            int N, int H, int W, int C, int time_major)
+{
+    const int cv = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cv) return;
+    const long r = i / cv;
+    const int c8 = (int)(i - r * cv);
+    const uint4 *p = (const uint4 *)(x + (r * W) * C + c8 * 8);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < W; w++) {
+        const uint4 v = p[(long)w * cv];
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[2 * k] += __uint_as_float(u[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(u[k] & 0xFFFF0000u);
+        }
+    }
+    const float inv = 1.f / (float)W;
+    const long n = r / H, h = r - n * H;
+    float *o = y + ((time_major ? h * N + n : r) * C + c8 * 8);
+    *(float4 *)o = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    *(float4 *)(o + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+}
+
+// dx[n][h][w][c] = g[row(n, h)][c] / W, bf16 channels-last
+__global__ __launch_bounds__(256) void freq_mean_bwd_kernel(const float *__restrict__ g, unsigned short *__restrict__ dx, long rows,
+                                                            int N, int H, int W, int C, int time_major)
+{
+    const int cv = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * W * cv) return;
+    const long rw = i / cv;
+    const int c8 = (int)(i - rw * cv);
+    const long r = rw / W;
+    const long n = r / H, h = r - n * H;
+    const float *src = g + ((time_major ? h * N + n : r) * C + c8 * 8);
+    const float4 a = *(const float4 *)src, b = *(const float4 *)(src + 4);
+    const float inv = 1.f / (float)W;
+    uint4 o;
+    o.x = pack_bf16(a.x * inv, a.y * inv);
+    o.y = pack_bf16(a.z * inv, a.w * inv);
+    o.z = pack_bf16(b.x * inv, b.y * inv);
+    o.w = pack_bf16(b.z * inv, b.w * inv);
+    *(uint4 *)(dx + rw * C + c8 * 8) = o;
+}
+
 // ------------------------------------------------------------------------------------------------------------ SELD loss
 // models/interfaces.py:304-355 in one launch: sed = mean BCE-with-logits(logit, sed_gt); doa = sum over the x / y / z blocks of
 // sum(|p - t| m) / sum(m) with m = sed_gt (the three blocks share sum(m)); loss = w_sed sed + w_doa doa -- and the gradients of
@@ -880,6 +931,26 @@ int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t n
     const long blocks = (na + nb + 255) / 256;
     hipLaunchKernelGGL(seld_loss_scale_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, (hipStream_t)hip_stream, a,
                        (long)na, b, (long)nb, g_loss, g_sed, g_doa, w_sed, w_doa, out_a, out_b);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* mean over the frequency axis of a bf16 channels-last map x [N][H][W][C] -> float32 y, [H][N][C] when time_major else [N][H][C];
+ * C % 8 == 0.  _bwd: dx = g / W broadcast over W, bf16 channels-last. */
+int salsa_nn_freq_mean_fwd(const void *x, float *y, int64_t N, int H, int W, int C, int time_major, void *hip_stream)
+{
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return -1;
+    const long rows = (long)N * H, n = rows * (C / 8);
+    hipLaunchKernelGGL(freq_mean_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const unsigned short *)x, y, rows, (int)N, H, W, C, time_major);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_freq_mean_bwd(const float *g, void *dx, int64_t N, int H, int W, int C, int time_major, void *hip_stream)
+{
+    if (!g || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return -1;
+    const long rows = (long)N * H, n = rows * W * (C / 8);
+    hipLaunchKernelGGL(freq_mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, g,
+                       (unsigned short *)dx, rows, (int)N, H, W, C, time_major);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

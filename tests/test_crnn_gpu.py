@@ -867,3 +867,25 @@ def test_fused_seld_loss_matches_the_eager_loss():
         assert abs(a - b) <= 1e-6 * abs(b) + 1e-7, (res[True][0], res[False][0])
     for a, b in zip(res[True][1:], res[False][1:]):
         assert a.shape == b.shape and (a - b).abs().max() <= 1e-6 * b.abs().max(), (a - b).abs().max()
+
+
+def test_hip_frequency_mean_matches_torch_forward_and_backward():
+    """salsa_nn_freq_mean_fwd / _bwd (the decoder's mean over frequency + transpose, one pass, time-major float32 output) against
+    ``feat.float().mean(3).transpose(1, 2)``: forward to float32 rounding of a 12-term sum, backward exactly g / F rounded to bf16."""
+    from salsa_amd.crnn import nn_ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(11)
+    for shape in ((3, 512, 40, 12), (2, 64, 7, 5)):
+        x = torch.randn(shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = nn_ops.freq_mean_sequence(x)
+        assert y.shape == (shape[0], shape[2], shape[1]) and y.dtype == torch.float32
+        assert y.transpose(0, 1).is_contiguous()                                   # a view of the time-major buffer
+        ref = x.detach().float().mean(dim=3).transpose(1, 2)
+        assert torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
+        gy = torch.randn(y.shape, generator=g).to(dev)
+        y.backward(gy)
+        want = (gy.transpose(1, 2).unsqueeze(3) / shape[3]).expand(shape).to(torch.bfloat16)
+        assert x.grad.shape == x.shape and x.grad.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(x.grad, want)
+    xf = torch.randn(2, 64, 7, 5, device=dev)                                      # float32 input: the torch expression
+    assert torch.equal(nn_ops.freq_mean_sequence(xf), xf.mean(dim=3).transpose(1, 2))
