@@ -176,11 +176,13 @@ int salsa_plan_set_pipeline(salsa_plan *plan, int n_groups, int flags);
 int salsa_plan_set_groups(salsa_plan *plan, int n_groups);
 
 /* contrib/salsa_flexible.py accepts any number of microphones (stacked_covmat_eigh :52-77).  Up to 4 go through
- * salsa_extract_batch (fewer than 4: pad with silent channels).  5 - 8 go through this entry point: plan created with
- * SALSA_FLAG_FLEX (SALSA or SALSA-Lite, MIC), d_audio float32 planar [B][n_channels][N] with n_channels = 6 or 8 (an odd
- * count: append one silent channel -- the covariance only gains a zero eigenvalue -- and drop its output planes),
+ * salsa_extract_batch (fewer than 4: pad with silent channels).  5 - SALSA_MAX_MICS go through this entry point: plan created
+ * with SALSA_FLAG_FLEX (SALSA or SALSA-Lite, MIC), d_audio float32 planar [B][n_channels][N] with n_channels EVEN, 6 .. 16 (an
+ * odd count: append one silent channel -- the covariance only gains a zero eigenvalue -- and drop its output planes),
  * d_out float32 [B][2*n_channels - 1][T][F]: n_channels log-spectrograms, then n_channels - 1 spatial planes.  The
- * N x N eigenproblem is solved by cyclic complex Jacobi in float64, one lane per gated TF bin. */
+ * N x N eigenproblem is solved by cyclic complex Jacobi in float64, one lane per gated TF bin (6 and 8 channels: fully
+ * unrolled instantiations; 10 - 16: one instantiation with the channel count read at run time). */
+#define SALSA_MAX_MICS 16
 size_t salsa_multichannel_workspace_bytes(const salsa_plan *plan, int n_channels, int batch, int64_t n_samples);
 int salsa_extract_multichannel(salsa_plan *plan, const float *d_audio, int n_channels, int batch, int64_t n_samples,
                                float *d_out, void *d_workspace, size_t workspace_bytes, void *hip_stream);

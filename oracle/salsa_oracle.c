@@ -479,7 +479,7 @@ int salsa_oracle_extract_lite(const float *audio, long N, int fs, int n_fft, int
  * n x n Hermitian eigen-decomposition standing in for np.linalg.eigh(covmats, UPLO='U') (:75): cyclic complex Jacobi in
  * float64, eigenvalues returned ASCENDING and signed like LAPACK's, v = eigenvector of the largest one (any unit phase:
  * :362 only uses conj(v0)*v_i). */
-#define SALSA_FLEX_MAXCH 8
+#define SALSA_FLEX_MAXCH 16
 static void hermn_eigh(int n, double ar[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH], double ai[SALSA_FLEX_MAXCH][SALSA_FLEX_MAXCH],
                        double *lam, double *vr, double *vi)
 {

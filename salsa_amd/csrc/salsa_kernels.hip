@@ -160,13 +160,16 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
         }
     }
     if (t_begin >= Tn) return; // wave-uniform; nothing below uses a workgroup barrier
-    constexpr int NCH = 2 * NPAIRS;              // channels per clip: 4 (the dataset scripts), 6 / 8 on the contrib surface
-    const float *clip = audio + (long)b * NCH * Ns;
+    // channel pairs per clip: 2 (the dataset scripts), 3 / 4 on the contrib surface; NPAIRS == 0: any count, read from kp.nch
+    // (9 - 16 microphones: one instantiation, the index arithmetic below is all that depends on it)
+    const int npairs = NPAIRS > 0 ? NPAIRS : kp.nch / 2;
+    const int nch = 2 * npairs;
+    const float *clip = audio + (long)b * nch * Ns;
     // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
     // path -- no per-load branching; frames that overlap a clip end take the reflect path (np.pad(mode='reflect'); one
     // fold suffices because Ns > N/2, checked on the host).
     const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
-    const int sstride = planar ? 1 : NCH;
+    const int sstride = planar ? 1 : nch;
     // Item order.  Full SALSA: PAIR-major (all the wave's frames of channels 0/1, then of channels 2/3), so consecutive
     // items re-read the 41 % of samples that overlapping frames share while they are still in L2 (frame-major order
     // puts another 4 KiB item and a whole CU's worth of traffic in between: measured 1.7x audio over-fetch).  SALSA-Lite
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     const int nfr_ = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
     const int psel = LITE ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
     auto item_frame = [&](int item) {
-        if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / NPAIRS;
+        if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / npairs;
         return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1;
     };
     auto item_pair = [&](int item) {
-        if (NPAIRS != 2) return PAIR_MAJOR ? item / nfr_ : item % NPAIRS;
+        if (NPAIRS != 2) return PAIR_MAJOR ? item / nfr_ : item % npairs;
         return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1;
     };
     auto load_item = [&](int item, float *y0, float *y1) {
@@ -211,10 +214,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
         }
     };
 
-    const int nitems = psel >= 0 ? nfr_ : nfr_ * NPAIRS;
+    const int nitems = psel >= 0 ? nfr_ : nfr_ * npairs;
     float y0[R], y1[R];
     float *o = out + (long)b * kp.OC * Tn * kp.F; // [OC][T][F] of this clip (int offsets below)
-    float4 *xs = Xs + (long)b * Tn * NPAIRS * kp.nd;
+    float4 *xs = Xs + (long)b * Tn * npairs * kp.nd;
     const int mlane = (64 - lane) & 63;           // lane holding the mirror bins N-k of this lane's bins
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    st_off(xs, 16u * (unsigned)((t * NPAIRS + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
+                    st_off(xs, 16u * (unsigned)((t * npairs + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
                 if (k >= kp.spec_lo && k < kp.spec_hi) {
                     const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + (k - kp.spec_lo));
                     st_off(o, off, spec(pa, c0, k - kp.spec_lo));
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
                         }
                         return atan2f(wi, wr) * inv_scale;
                     };
-                    if (pr >= 1) st_off(o, off + (unsigned)(NCH - 1) * plane, phase(xa));
-                    st_off(o, off + (unsigned)NCH * plane, phase(xb));
+                    if (pr >= 1) st_off(o, off + (unsigned)(nch - 1) * plane, phase(xa));
+                    st_off(o, off + (unsigned)nch * plane, phase(xb));
                 }
             }
         };
@@ -888,12 +891,16 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
 // the 2*n_hop+1 frames in float64, cyclic complex Jacobi with the rotations accumulated (eigenvalues = the diagonal, eigen-
 // vectors = the accumulated columns), gate "largest > second largest * ew_thresh" (:353), feature angle(conj(u_0) u_c) / f
 // (:360-362).  A completeness path, not a tuned one: the 2 x NCH^2 float64 matrices spill to scratch.
+// NCH > 0: compile-time size, fully unrolled (6 | 8).  NCH == 0: any even count up to MAXN = 16 read from kp.nch -- the same code
+// with run-time loop bounds and dynamically indexed scratch arrays (9 - 16 microphones: slower still, and as rare).
+constexpr int HERMN_MAX = SALSA_MAX_MICS;
 template <int NCH> struct hermn {
-    double ar[NCH][NCH], ai[NCH][NCH];
+    static constexpr int S = NCH > 0 ? NCH : HERMN_MAX;
+    double ar[S][S], ai[S][S];
 };
 
 template <int NCH>
-__device__ __forceinline__ void hermn_rotate(hermn<NCH> &A, hermn<NCH> &V, const int p, const int q)
+__device__ __forceinline__ void hermn_rotate(hermn<NCH> &A, hermn<NCH> &V, const int p, const int q, const int n)
 {
     const double xr = A.ar[p][q], xi = A.ai[p][q];
     const double r2 = xr * xr + xi * xi;
@@ -908,7 +915,7 @@ __device__ __forceinline__ void hermn_rotate(hermn<NCH> &A, hermn<NCH> &V, const
     const double uqp_r = -sn * er, uqp_i = sn * ei, uqq_r = c * er, uqq_i = -c * ei;
     auto cols = [&](hermn<NCH> &M) { // M <- M U (columns p and q)
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
+        for (int i = 0; i < n; i++) {
             const double pr = M.ar[i][p], pi = M.ai[i][p], qr = M.ar[i][q], qi = M.ai[i][q];
             M.ar[i][p] = pr * c + (qr * uqp_r - qi * uqp_i);
             M.ai[i][p] = pi * c + (qr * uqp_i + qi * uqp_r);
@@ -918,7 +925,7 @@ __device__ __forceinline__ void hermn_rotate(hermn<NCH> &A, hermn<NCH> &V, const
     };
     cols(A);
 #pragma unroll
-    for (int j = 0; j < NCH; j++) { // A <- U^H A (rows p and q): conj(U_pp) = c, conj(U_qp), conj(U_pq) = sn, conj(U_qq)
+    for (int j = 0; j < n; j++) { // A <- U^H A (rows p and q): conj(U_pp) = c, conj(U_qp), conj(U_pq) = sn, conj(U_qq)
         const double pr = A.ar[p][j], pi = A.ai[p][j], qr = A.ar[q][j], qi = A.ai[q][j];
         A.ar[p][j] = c * pr + (uqp_r * qr + uqp_i * qi);
         A.ai[p][j] = c * pi + (uqp_r * qi - uqp_i * qr);
@@ -934,24 +941,25 @@ template <int NCH>
 __global__ __launch_bounds__(64) void cov_eig_n_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                        const unsigned *__restrict__ valid32, float *__restrict__ out)
 {
-    constexpr int NP = NCH / 2;
+    constexpr int S = hermn<NCH>::S;
+    const int n = NCH > 0 ? NCH : kp.nch, NP = n / 2;
     const int t = blockIdx.x, b = blockIdx.y, Tn = kp.T;
     const int ng32 = (kp.nd + TR_BINS - 1) / TR_BINS;
-    float *of = out + ((long)b * kp.OC + NCH) * Tn * kp.F + (long)t * kp.F; // first spatial plane, this frame's row
+    float *of = out + ((long)b * kp.OC + n) * Tn * kp.F + (long)t * kp.F; // first spatial plane, this frame's row
     const long plane = (long)Tn * kp.F;
     const float4 *xclip = Xs + (long)b * Tn * NP * kp.nd;
     for (int bin = threadIdx.x; bin < kp.F; bin += 64) {
-        float e[NCH - 1];
+        float e[S - 1];
 #pragma unroll
-        for (int c = 0; c < NCH - 1; c++) e[c] = 0.f;
+        for (int c = 0; c < S - 1; c++) e[c] = 0.f;
         bool gated = bin < kp.nd;
         if (gated && kp.tracking) gated = (valid32[((long)b * ng32 + (bin >> 5)) * Tn + t] >> (bin & 31)) & 1u;
         if (gated) {
             hermn<NCH> A, V;
 #pragma unroll
-            for (int i = 0; i < NCH; i++)
+            for (int i = 0; i < n; i++)
 #pragma unroll
-                for (int j = 0; j < NCH; j++) {
+                for (int j = 0; j < n; j++) {
                     A.ar[i][j] = A.ai[i][j] = 0.0;
                     V.ar[i][j] = i == j ? 1.0 : 0.0;
                     V.ai[i][j] = 0.0;
@@ -960,60 +968,60 @@ __global__ __launch_bounds__(64) void cov_eig_n_kernel(const KParams kp, const f
                 int tt = t + k;
                 while (tt < 0) tt += Tn;
                 while (tt >= Tn) tt -= Tn;
-                double xr[NCH], xi[NCH];
+                double xr[S], xi[S];
 #pragma unroll
                 for (int pr = 0; pr < NP; pr++) {
                     const float4 v = xclip[((long)tt * NP + pr) * kp.nd + bin];
                     xr[2 * pr] = v.x; xi[2 * pr] = v.y; xr[2 * pr + 1] = v.z; xi[2 * pr + 1] = v.w;
                 }
 #pragma unroll
-                for (int i = 0; i < NCH; i++)
+                for (int i = 0; i < n; i++)
 #pragma unroll
-                    for (int j = 0; j < NCH; j++) { // x_i conj(x_j)
+                    for (int j = 0; j < n; j++) { // x_i conj(x_j)
                         A.ar[i][j] += xr[i] * xr[j] + xi[i] * xi[j];
                         A.ai[i][j] += xi[i] * xr[j] - xr[i] * xi[j];
                     }
             }
             double tr = 0.0;
 #pragma unroll
-            for (int i = 0; i < NCH; i++) tr += A.ar[i][i];
+            for (int i = 0; i < n; i++) tr += A.ar[i][i];
             bool good = false;
             if (tr > 0.0) {
                 for (int sweep = 0; sweep < 16; sweep++) {
                     double off = 0.0;
 #pragma unroll
-                    for (int p = 0; p < NCH; p++)
+                    for (int p = 0; p < n; p++)
 #pragma unroll
-                        for (int q = p + 1; q < NCH; q++) off += A.ar[p][q] * A.ar[p][q] + A.ai[p][q] * A.ai[p][q];
+                        for (int q = p + 1; q < n; q++) off += A.ar[p][q] * A.ar[p][q] + A.ai[p][q] * A.ai[p][q];
                     if (off <= 1e-34 * tr * tr) break;
 #pragma unroll
-                    for (int p = 0; p < NCH; p++)
+                    for (int p = 0; p < n; p++)
 #pragma unroll
-                        for (int q = p + 1; q < NCH; q++) hermn_rotate<NCH>(A, V, p, q);
+                        for (int q = p + 1; q < n; q++) hermn_rotate<NCH>(A, V, p, q, n);
                 }
                 int i1 = 0;
                 double l1 = A.ar[0][0];
 #pragma unroll
-                for (int i = 1; i < NCH; i++)
+                for (int i = 1; i < n; i++)
                     if (A.ar[i][i] > l1) { l1 = A.ar[i][i]; i1 = i; }
                 double l2 = -1e300;
 #pragma unroll
-                for (int i = 0; i < NCH; i++)
+                for (int i = 0; i < n; i++)
                     if (i != i1 && A.ar[i][i] > l2) l2 = A.ar[i][i];
                 good = l1 > l2 * kp.cond; // ews[:, -1] > ews[:, -2] * ew_thresh (:353)
                 if (good) {
-                    double ur[NCH], ui[NCH];
+                    double ur[S], ui[S];
 #pragma unroll
-                    for (int i = 0; i < NCH; i++) {
+                    for (int i = 0; i < n; i++) {
                         ur[i] = ui[i] = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NCH; j++)
+                        for (int j = 0; j < n; j++)
                             if (j == i1) { ur[i] = V.ar[i][j]; ui[i] = V.ai[i][j]; }
                     }
                     const int kb = bin + kp.lower;
                     const double den = (double)((float)(kb == 0 ? 1 : kb) * (float)kp.delta); // float32 norm_freq (:188-190)
 #pragma unroll
-                    for (int c = 1; c < NCH; c++) { // angle(conj(u_0) u_c) / f   (:360-362)
+                    for (int c = 1; c < n; c++) { // angle(conj(u_0) u_c) / f   (:360-362)
                         const double wr = ur[0] * ur[c] + ui[0] * ui[c], wi = ur[0] * ui[c] - ui[0] * ur[c];
                         e[c - 1] = (float)(atan2(wi, wr) / den);
                     }
@@ -1022,7 +1030,7 @@ __global__ __launch_bounds__(64) void cov_eig_n_kernel(const KParams kp, const f
             if (!good && !kp.tracking) e[0] = __builtin_nanf(""); // marks "failed the test" for flex_allpass_kernel
         }
 #pragma unroll
-        for (int c = 0; c < NCH - 1; c++) of[c * plane + bin] = e[c];
+        for (int c = 0; c < n - 1; c++) of[c * plane + bin] = e[c];
     }
 }
 
@@ -1665,7 +1673,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
 
 size_t salsa_multichannel_workspace_bytes(const salsa_plan *pl, int n_channels, int batch, int64_t n_samples)
 {
-    if (!pl || batch <= 0 || n_samples <= 0 || n_channels < 4 || n_channels > 8 || (n_channels & 1)) return 0;
+    if (!pl || batch <= 0 || n_samples <= 0 || n_channels < 4 || n_channels > SALSA_MAX_MICS || (n_channels & 1)) return 0;
     if (pl->p.feature_type != SALSA_FEATURE_SALSA) return 256;
     const size_t T = 1 + n_samples / pl->p.hop_len;
     return align256((size_t)batch * T * n_channels * pl->nd * sizeof(float2)) +
@@ -1678,8 +1686,8 @@ int salsa_extract_multichannel(salsa_plan *pl, const float *d_audio, int n_chann
     if (!pl || !d_audio || !d_out || batch <= 0 || n_samples <= 0) return fail(SALSA_EINVAL, "salsa_extract_multichannel: bad argument%s");
     if (!pl->flex || pl->p.audio_layout != SALSA_LAYOUT_PLANAR)
         return fail(SALSA_EINVAL, "salsa_extract_multichannel is the contrib (SALSA_FLAG_FLEX) surface, planar audio%s");
-    if (n_channels != 6 && n_channels != 8)
-        return fail(SALSA_EINVAL, "salsa_extract_multichannel takes 6 or 8 channels (pad an odd count with a silent channel; <= 4: salsa_extract_batch)%s");
+    if (n_channels < 6 || n_channels > SALSA_MAX_MICS || (n_channels & 1))
+        return fail(SALSA_EINVAL, "salsa_extract_multichannel takes an even number of channels from 6 to 16 (pad an odd count with a silent channel; <= 4: salsa_extract_batch)%s");
     if (n_samples <= pl->p.n_fft / 2) return fail(SALSA_EINVAL, "clip shorter than n_fft/2 samples cannot be reflect-padded%s");
     const int64_t T64 = 1 + n_samples / pl->p.hop_len;
     const int OC = 2 * n_channels - 1;
@@ -1705,7 +1713,9 @@ int salsa_extract_multichannel(salsa_plan *pl, const float *d_audio, int n_chann
         Xs = (float4 *)d_workspace;
         valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * n_channels * kp.nd * sizeof(float2)));
     }
-    int rc = n_channels == 6 ? launch_stft_multi<3>(pl, kp, d_audio, d_out, Xs, s) : launch_stft_multi<4>(pl, kp, d_audio, d_out, Xs, s);
+    int rc = n_channels == 6 ? launch_stft_multi<3>(pl, kp, d_audio, d_out, Xs, s)
+           : n_channels == 8 ? launch_stft_multi<4>(pl, kp, d_audio, d_out, Xs, s)
+                             : launch_stft_multi<0>(pl, kp, d_audio, d_out, Xs, s); // 10 - 16: channel count at run time
     if (rc || !full) return rc;
     if (kp.tracking && kp.nd > 0) {
         hipLaunchKernelGGL(tracker_kernel, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
@@ -1713,7 +1723,8 @@ int salsa_extract_multichannel(salsa_plan *pl, const float *d_audio, int n_chann
     }
     dim3 grid((unsigned)kp.T, (unsigned)kp.B);
     if (n_channels == 6) hipLaunchKernelGGL(cov_eig_n_kernel<6>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
-    else hipLaunchKernelGGL(cov_eig_n_kernel<8>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
+    else if (n_channels == 8) hipLaunchKernelGGL(cov_eig_n_kernel<8>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
+    else hipLaunchKernelGGL(cov_eig_n_kernel<0>, grid, dim3(64), 0, s, kp, Xs, valid, d_out);
     HIP_TRY(hipGetLastError());
     if (!kp.tracking && kp.nd > 0) {
         hipLaunchKernelGGL(flex_allpass_kernel, dim3((unsigned)((kp.nd + 255) / 256), (unsigned)kp.B), dim3(256), 0, s, kp, d_out);

@@ -129,12 +129,12 @@ class SalsaExtractor:
     __call__ = extract
 
     def extract_multichannel(self, audio: torch.Tensor) -> torch.Tensor:
-        """contrib surface, 6 or 8 microphones (salsa_extract_multichannel): audio float32 CUDA [B, C, N] planar ->
+        """contrib surface, 6 - 16 microphones, even (salsa_extract_multichannel): audio float32 CUDA [B, C, N] planar ->
         [B, 2C-1, T, F] float32 (C log-spectrograms, then C-1 spatial planes).  The plan must carry FLAG_FLEX."""
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3 and audio.is_contiguous()
         B, ch, N = audio.shape
-        if ch not in (6, 8):
-            raise ValueError('extract_multichannel takes 6 or 8 channels, got %d' % ch)
+        if ch not in (6, 8, 10, 12, 14, 16):
+            raise ValueError('extract_multichannel takes an even number of channels from 6 to 16, got %d' % ch)
         if audio.device != self.device:
             raise ValueError('plan is bound to %s, audio is on %s' % (self.device, audio.device))
         _, T, F = self.output_shape(N)

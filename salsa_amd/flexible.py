@@ -8,9 +8,9 @@ Same constructor arguments, call arguments, defaults, assertions and output layo
 and ``SalsaLiteFeatures`` (:373-400); the arithmetic runs in libsalsa_hip.so (salsa_extract_batch with
 SALSA_FLAG_FLEX + salsa_to_freq_major -- include/salsa_hip.h lists what that flag changes relative to the dataset
 scripts).  ``extract_batch`` is the same computation for a device-resident batch of clips (the Dataset-fused form SURVEY
-config 4 wants).  Any microphone count from 2 to 8, like the reference's "arbitrary channels": 2 or 3 microphones are padded
-with silent channels to the 4-channel kernels (closed-form 4 x 4 eigen-solver), 5 - 8 to an even count for
-salsa_extract_multichannel (N x N Hermitian eigenproblem by cyclic Jacobi, one lane per gated TF bin).  A silent channel
+config 4 wants).  Any microphone count from 2 to 16 (include/salsa_hip.h SALSA_MAX_MICS), like the reference's "arbitrary
+channels": 2 or 3 microphones are padded with silent channels to the 4-channel kernels (closed-form 4 x 4 eigen-solver), 5 - 16
+to an even count for salsa_extract_multichannel (N x N Hermitian eigenproblem by cyclic Jacobi, one lane per gated TF bin).  A silent channel
 leaves the coherence gate and the principal eigenvector unchanged (the covariance only gains a zero eigenvalue); its
 output planes are dropped.
 """
@@ -21,6 +21,8 @@ import torch
 
 from . import _lib
 from .extractor import SalsaExtractor, _raise
+
+MAX_MICS = 16   # include/salsa_hip.h SALSA_MAX_MICS
 
 
 class SpatialFeaturesAbstract:
@@ -63,14 +65,14 @@ class SpatialFeaturesAbstract:
         return self._plans[key]
 
     def extract_batch(self, audio: torch.Tensor, clip_freqs=True, clip_spatial_alias=False, **feat_kwargs) -> torch.Tensor:
-        """audio float32 CUDA [B, C, N], 2 <= C <= 8 -> float64 CUDA [B, 2C-1, F, T] (freq-major like the reference)."""
+        """audio float32 CUDA [B, C, N], 2 <= C <= 16 -> float64 CUDA [B, 2C-1, F, T] (freq-major like the reference)."""
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 3
         B, n_ch, N = audio.shape
-        if not 2 <= n_ch <= 8:
-            raise ValueError('the MI355X kernels take 2 to 8 microphones, got %d' % n_ch)
+        if not 2 <= n_ch <= MAX_MICS:
+            raise ValueError('the MI355X kernels take 2 to %d microphones, got %d' % (MAX_MICS, n_ch))
         ex = self._plan(clip_freqs, clip_spatial_alias, **feat_kwargs)
         if n_ch > 4:
-            n_pad = n_ch + (n_ch & 1)                                              # 6 or 8
+            n_pad = n_ch + (n_ch & 1)                                              # even: 6 .. 16
             if n_pad != n_ch:
                 audio = torch.cat([audio, audio.new_zeros((B, 1, N))], dim=1)
             out = to_freq_major(ex.extract_multichannel(audio.contiguous()))        # [B, 2*n_pad-1, F, T] float64

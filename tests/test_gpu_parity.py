@@ -420,10 +420,11 @@ def test_fused_scaler_equals_separate_normalisation(dev):
 
 
 # ----------------------------------------------------------------------------------------------- contrib on-the-fly surface
-@pytest.mark.parametrize('fixture', ['g10_flexible', 'g13_flexible_multi'])
+@pytest.mark.parametrize('fixture', ['g10_flexible', 'g13_flexible_multi', 'g15_flexible_many'])
 def test_contrib_flexible_surface_matches_reference_golden(dev, fixture):
     """SalsaFeatures / SalsaLiteFeatures of contrib/salsa_flexible.py, called like the reference's docstrings:
-    2 - 4 microphones (g10, the 4-channel kernels) and 5 - 8 (g13, salsa_extract_multichannel: N x N Jacobi eigen-solver)."""
+    2 - 4 microphones (g10, the 4-channel kernels) and 5 - 8 (g13, salsa_extract_multichannel: N x N Jacobi eigen-solver; 9 - 16
+    microphones: g15, the run-time-sized instantiations)."""
     from flex_compare import compare_flexible
     from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures
     meta, g = load_golden(fixture)
@@ -490,7 +491,7 @@ def test_to_freq_major(dev):
     assert torch.equal(to_freq_major(x), x.permute(0, 1, 3, 2).double())
     with pytest.raises(ValueError):
         from salsa_amd.flexible import SalsaFeatures
-        SalsaFeatures().extract_batch(torch.zeros(1, 9, 4000, device=dev))          # 2 - 8 microphones
+        SalsaFeatures().extract_batch(torch.zeros(1, 17, 4000, device=dev))         # 2 - 16 microphones
     with pytest.raises(AssertionError):
         from salsa_amd.flexible import SalsaFeatures
         SalsaFeatures(fmax_doa=9500)                                            # contrib :183
@@ -545,9 +546,10 @@ def test_host_pipeline_matches_direct_extraction(dev):
     assert all(np.array_equal(a, b) for a, b in zip(got3, want[:5]))
 
 
-@pytest.mark.parametrize('n_ch', [5, 6, 8])
+@pytest.mark.parametrize('n_ch', [5, 6, 8, 9, 12, 16])
 def test_contrib_multichannel_batch_against_oracle(dev, oracle, n_ch):
-    """salsa_extract_multichannel (5 - 8 microphones: N x N Hermitian eigenproblem by Jacobi) on a batch of longer clips,
+    """salsa_extract_multichannel (5 - 16 microphones: N x N Hermitian eigenproblem by Jacobi; 6 / 8 unrolled instantiations,
+    10 - 16 the run-time-sized one) on a batch of longer clips,
     tracking on and off, against the oracle (which golden g13 ties to the reference)."""
     from flex_compare import compare_flexible
     from salsa_amd.flexible import SalsaFeatures, SalsaLiteFeatures

@@ -307,6 +307,20 @@ def g13_flexible_multi():
     g10_flexible('g13_flexible_multi', 13500, G13_CASES)              # 0.5625 s -> 46 frames
 
 
+G15_CASES = [
+    # 9 - 16 microphones: the run-time-sized instantiations of the MI355X kernels (include/salsa_hip.h SALSA_MAX_MICS)
+        ('salsa_9mics', 'salsa', 191, 9, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+        ('salsa_12mics_alias_notrack', 'salsa', 192, 12, {}, dict(clip_freqs=True, clip_spatial_alias=True, is_tracking=False)),
+        ('salsa_16mics_kwargs', 'salsa', 193, 16, dict(fmin_doa=100, fmax_doa=4000, fmax_spec=8000),
+         dict(clip_freqs=True, clip_spatial_alias=True, ew_thresh=3.0, covmat_avg_neighbours=2, floor_mask_ratio=2.0)),
+        ('lite_11mics', 'lite', 194, 11, {}, dict(clip_freqs=True, clip_spatial_alias=False)),
+]
+
+
+def g15_flexible_many():
+    g10_flexible('g15_flexible_many', 9000, G15_CASES)                # 0.375 s -> 31 frames
+
+
 # ----------------------------------------------------------------------------------------------- G11: train augmentation
 def g11_augment():
     """The reference's training augmentation for SALSA features (dataset/datamodule.py:45-52 FOA, :73-82 MIC) applied the
@@ -399,5 +413,6 @@ if __name__ == '__main__':
     g8_stft()
     g10_flexible()
     g13_flexible_multi()
+    g15_flexible_many()
     g11_augment()
     g12_metrics()
