@@ -164,6 +164,10 @@ int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t n
 int salsa_nn_freq_mean_fwd(const void *x, float *y, int64_t N, int H, int W, int C, int time_major, void *hip_stream);
 int salsa_nn_freq_mean_bwd(const float *g, void *dx, int64_t N, int H, int W, int C, int time_major, void *hip_stream);
 
+/* Column sums of one or two float32 row-major [M][C] matrices, ADDED to out_a / out_b (zero them first; b may be NULL): the GRU's
+ * bias gradients db_ih = sum_(t,b) dgi, db_hh = sum_(t,b) dgh in one launch (torch's reduction / a ones-vector GEMV: ~17 us each). */
+int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b, int64_t M, int C, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

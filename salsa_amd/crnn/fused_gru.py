@@ -36,6 +36,22 @@ def _scan_inference(gi, whh, bhh):
 
 _ONES = {}
 LEAN = os.environ.get('SALSA_GRU_LEAN', '1') != '0'   # GEMM / GEMV forms of the projection and bias gradients (0: einsum + reductions)
+HIP_COLSUM = os.environ.get('SALSA_HIP_COLSUM', '1') != '0'   # bias gradients by salsa_nn_colsum2 (0: the ones-vector GEMV)
+
+
+def _bias_grad(g2, shape):
+    """sum over the rows of g2 (T*B, D*3H) float32 contiguous -> `shape`: salsa_nn_colsum2 into a zero slice of the backward
+    pass's gradient pool (the ones-vector GEMV took 17 us per call, four calls per step)."""
+    if not (HIP_COLSUM and g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous()):
+        return torch.mv(g2.t(), _ones(g2.shape[0], g2.device)).view(shape)
+    from .nn_ops import _grad_zeros
+    out = _grad_zeros(tuple(shape), g2.device)
+    with torch.cuda.device(g2.device):
+        rc = _lib.load().salsa_nn_colsum2(C.c_void_p(g2.data_ptr()), None, C.c_void_p(out.data_ptr()), None, g2.shape[0], g2.shape[1],
+                                          _stream(g2))
+    if rc:
+        raise RuntimeError('salsa_nn_colsum2 failed (%d)' % rc)
+    return out
 
 
 def _ones(n, device):
@@ -73,7 +89,7 @@ class _InputProjection(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dwih = torch.mm(g2.t(), x.reshape(T * B, In)).view(D, G, In)
         if ctx.needs_input_grad[2]:
-            dbih = torch.mv(g2.t(), _ones(T * B, x.device)).view(D, G)
+            dbih = _bias_grad(g2, (D, G))
         return dx, dwih, dbih
 
 
@@ -136,7 +152,7 @@ class _GruScan(torch.autograd.Function):
                 torch.mm(dgh[:-1, :, 1].reshape(-1, 3 * H).t(), hs[1:, :, 1].reshape(-1, H), out=dwhh[1])
         else:
             dwhh.zero_()
-        dbhh = torch.mv(dgh.view(T * B, D * 3 * H).t(), _ones(T * B, hs.device)).view(D, 3 * H)
+        dbhh = _bias_grad(dgh.view(T * B, D * 3 * H), (D, 3 * H))
         return dgi, dwhh, dbhh, None
 
 
@@ -150,10 +166,9 @@ def bigru_forward(gru: torch.nn.GRU, x: torch.Tensor, training: bool, half_weigh
     out = x.transpose(0, 1).contiguous()        # time-major between the layers: the scans' order (one copy in, one view out)
     for layer in range(gru.num_layers):
         names = ['_l%d' % layer, '_l%d_reverse' % layer]
-        wih = torch.stack([getattr(gru, 'weight_ih' + n) for n in names])          # (D,3H,In)
-        whh = torch.stack([getattr(gru, 'weight_hh' + n) for n in names])          # (D,3H,H)
-        bih = torch.stack([getattr(gru, 'bias_ih' + n) for n in names])
-        bhh = torch.stack([getattr(gru, 'bias_hh' + n) for n in names])
+        from .nn_ops import stack_groups
+        wih, whh, bih, bhh = stack_groups([[getattr(gru, kind + n) for n in names]   # (D,3H,In), (D,3H,H), (D,3H), (D,3H):
+                                           for kind in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')])   # one copy launch
         if layer > 0 and training and gru.dropout > 0:
             out = torch.nn.functional.dropout(out, p=gru.dropout, training=True)
         gi = _InputProjection.apply(out, wih, bih) if (out.is_cuda and LEAN) else \

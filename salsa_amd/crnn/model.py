@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, freq_mean_sequence,
-                     invalidate_conv_caches, new_backward_generation)
+                     invalidate_conv_caches, new_backward_generation, stack_groups)
 
 
 GRU_FP32 = os.environ.get('SALSA_GRU_FP32', '1') == '1'
@@ -178,10 +178,9 @@ class Decoder(nn.Module):
         the reference's state dict has them (event / x / y / z . fc1 / fc2); they are stacked per call (four small copies)."""
         heads = (self.event, self.x, self.y, self.z)
         B, T, D = seq.shape
-        w1 = torch.stack([h.fc1.weight for h in heads])                    # (4, D/2, D)
-        b1 = torch.stack([h.fc1.bias for h in heads]).unsqueeze(1)         # (4, 1, D/2)
-        w2 = torch.stack([h.fc2.weight for h in heads])                    # (4, n_classes, D/2)
-        b2 = torch.stack([h.fc2.bias for h in heads]).unsqueeze(1)
+        w1, b1, w2, b2 = stack_groups([[h.fc1.weight for h in heads], [h.fc1.bias for h in heads],      # (4, D/2, D), (4, D/2),
+                                       [h.fc2.weight for h in heads], [h.fc2.bias for h in heads]])     # (4, n_classes, D/2), ...
+        b1, b2 = b1.unsqueeze(1), b2.unsqueeze(1)
         x = seq.reshape(1, B * T, D).expand(4, B * T, D)
         x = F.dropout(x, 0.2, self.training)                                # four independent masks (drop1 of each head)
         h = F.relu(torch.baddbmm(b1, x, w1.transpose(1, 2)), inplace=True)

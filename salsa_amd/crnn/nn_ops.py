@@ -210,6 +210,36 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         return y
 
 
+class _StackGroups(torch.autograd.Function):
+    """``[torch.stack(g) for g in groups]`` for consecutive groups of ``n`` same-shaped tensors with ONE multi-tensor copy
+    (``torch._foreach_copy_``) instead of one concatenation kernel per group; the backward hands out views of the incoming
+    gradients (no kernel).  The decoder stacks the two directions of every GRU parameter and the four heads' weights every step."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        ctx.n = n
+        outs = [torch.empty((n,) + tuple(tensors[i].shape), dtype=tensors[i].dtype, device=tensors[i].device)
+                for i in range(0, len(tensors), n)]
+        torch._foreach_copy_([o[j] for o in outs for j in range(n)], [t.detach() for t in tensors])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        n = ctx.n
+        return (None,) + tuple(None if g is None else g[j] for g in gouts for j in range(n))
+
+
+def stack_groups(groups):
+    """groups: lists of equally many same-shaped tensors -> the stacked tensor of every group (see _StackGroups)."""
+    n = len(groups[0])
+    assert all(len(g) == n for g in groups)
+    flat = [t for g in groups for t in g]
+    if not (USE_STACK_GROUPS and flat[0].is_cuda and hasattr(torch, '_foreach_copy_')):
+        return [torch.stack(list(g)) for g in groups]
+    return list(_StackGroups.apply(n, *flat))
+
+
+USE_STACK_GROUPS = os.environ.get('SALSA_STACK_GROUPS', '1') != '0'
 USE_HIP_FREQ_MEAN = os.environ.get('SALSA_HIP_FREQ_MEAN', '1') != '0'
 
 

@@ -601,6 +601,31 @@ __global__ __launch_bounds__(256) void freq_mean_bwd_kernel(const float *__restr
     *(uint4 *)(dx + rw * C + c8 * 8) = o;
 }
 
+// ------------------------------------------------------------------------------------------------------------ column sums
+// out[c] += sum over rows of x[row][c] for up to two float32 matrices of one shape (the GRU's two bias gradients: rows = T * B,
+// C = D * 3H); out must hold zeros.  Workgroup = 64 columns x 4 row lanes over a slice of the rows; one float atomic per column.
+__global__ __launch_bounds__(256) void colsum2_kernel(const float *__restrict__ xa, const float *__restrict__ xb, float *__restrict__ oa,
+                                                      float *__restrict__ ob, long M, int C, int rows_per_block)
+{
+    __shared__ float red[4][64];
+    const float *x = blockIdx.z ? xb : xa;
+    float *o = blockIdx.z ? ob : oa;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float acc = 0.f;
+    if (col < C) {
+        long r = r0 + rl;
+        for (; r + 12 < r1; r += 16) { // four rows in flight
+            const float v0 = x[r * C + col], v1 = x[(r + 4) * C + col], v2 = x[(r + 8) * C + col], v3 = x[(r + 12) * C + col];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; r < r1; r += 4) acc += x[r * C + col];
+    }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < C) atomicAdd(o + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
 // ------------------------------------------------------------------------------------------------------------ SELD loss
 // models/interfaces.py:304-355 in one launch: sed = mean BCE-with-logits(logit, sed_gt); doa = sum over the x / y / z blocks of
 // sum(|p - t| m) / sum(m) with m = sed_gt (the three blocks share sum(m)); loss = w_sed sed + w_doa doa -- and the gradients of
@@ -951,6 +976,16 @@ int salsa_nn_freq_mean_bwd(const float *g, void *dx, int64_t N, int H, int W, in
     const long rows = (long)N * H, n = rows * W * (C / 8);
     hipLaunchKernelGGL(freq_mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, g,
                        (unsigned short *)dx, rows, (int)N, H, W, C, time_major);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* out_a[c] += sum_rows a[row][c] (and out_b from b when b != NULL): float32 [M][C] row-major, the outputs must hold zeros. */
+int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b, int64_t M, int C, void *hip_stream)
+{
+    if (!a || !out_a || (b && !out_b) || M <= 0 || C <= 0) return -1;
+    const int rpb = 64; // rows per workgroup: 16 per row lane
+    hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((M + rpb - 1) / rpb), b ? 2u : 1u), dim3(256), 0,
+                       (hipStream_t)hip_stream, a, b, out_a, out_b, (long)M, C, rpb);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
