@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, freq_mean_sequence,
+from .nn_ops import (BatchNormAct2d, Conv1x1, Conv3x3, ConvFilterBank, avg_pool2x2, conv1x1, conv_bn_act, folded_shortcut, freq_mean_sequence,
                      invalidate_conv_caches, new_backward_generation, stack_groups)
 
 
@@ -68,6 +68,10 @@ class ResBlock(nn.Module):
         # dropout(relu(bn1(conv1(y)))), training only; ys is y for the shortcut branch (in training routed through conv1's
         # autograd node: the branch's gradient is added inside conv1's data-gradient kernel, not by a separate pass)
         out, ys = conv_bn_act(self.conv1, self.bn1, y, dropout_p=self.dropout_p, skip=True)
+        if self.short_conv is not None:
+            folded = folded_shortcut(self.short_conv, self.short_bn, ys)      # eval: BatchNorm folded into the 1x1 GEMM, its shift
+            if folded is not None:                                            # added by conv2's epilogue with the residual
+                return conv_bn_act(self.conv2, self.bn2, out, residual=folded[0], pool=self.pool_out, residual_shift=folded[1])
         sc = self.short_bn(conv1x1(self.short_conv, ys)) if self.short_conv is not None else ys
         return conv_bn_act(self.conv2, self.bn2, out, residual=sc, pool=self.pool_out)   # relu(bn2(conv2(out)) + shortcut) [-> pool]
 

@@ -906,11 +906,32 @@ def _folded(conv, bn, stem=False):
     return wf, shift
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False, skip=False):
+FOLD_SHORTCUT = os.environ.get('SALSA_FOLD_SHORTCUT', '1') != '0'
+
+
+def folded_shortcut(conv, bn, x):
+    """Eval-mode 1x1 shortcut + BatchNorm (models/model_utils.py:340-349) as ONE GEMM: the BatchNorm's scale goes into the 1x1
+    filter and its shift is RETURNED, to be added by the block's last convolution epilogue together with this residual
+    (conv_bn_act(..., residual=sc, residual_shift=shift)) -- no normalisation pass over the shortcut tensor.  None when the
+    layer does not qualify (the caller then runs bn(conv1x1(x)))."""
+    if not (FOLD_SHORTCUT and not bn.training and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine
+            and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    wf, shift = _folded(conv, bn)
+    N, Cin, H, W = x.shape
+    with torch.autocast('cuda', enabled=False):
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(N * H * W, Cin), wf.reshape(conv.out_channels, Cin))
+    return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2), shift    # (N, Cout, H, W) with channels-last strides
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False, skip=False, residual_shift=None):
     """``_conv_bn_act`` below; with ``skip=True`` returns (result, x'): x' is x for a branch that forks off x (residual,
     shortcut) -- in training on the MFMA kernels routed through the convolution's autograd node (Conv3x3.forward_skip)."""
     if not skip:
-        return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool)
+        return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool, residual_shift)
+    assert residual_shift is None
     if isinstance(conv, Conv3x3) and bn.training and torch.is_grad_enabled() and not pool:
         part = conv.stats_buffer(x) if isinstance(bn, BatchNormAct2d) else None
         c, xs = conv.forward_skip(x, part)
@@ -919,7 +940,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False
     return _conv_bn_act(conv, bn, x, residual, relu, dropout_p, pool), x
 
 
-def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False):
+def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=False, residual_shift=None):
     """dropout(relu(bn(conv(x)) + residual)) of the reference blocks (dropout in training only).  In eval mode, for the 64 -> 64 3x3 convolutions under bf16
     autocast, the BatchNorm is folded into the filter (scale) and a per-channel shift that the MFMA kernel applies -- with the
     residual add and the ReLU -- before its single rounding: the normalised activation never makes a round trip to HBM.
@@ -930,6 +951,8 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
             and (residual is None or (residual.dtype == torch.bfloat16 and residual.shape[1] == 64
                                       and residual.is_contiguous(memory_format=torch.channels_last)))):
         wf, shift = _folded(conv, bn)
+        if residual_shift is not None:
+            shift = shift + residual_shift               # the folded shortcut BatchNorm's shift rides in the same epilogue add
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, _, H, W = xb.shape
         fuse_pool = pool and H % 2 == 0 and W % 2 == 0
@@ -947,6 +970,8 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
                                       and residual.is_contiguous(memory_format=torch.channels_last)))):
         # the wide layers at inference: the same folding on conv_wide.hip's epilogue
         wf, shift = _folded(conv, bn)
+        if residual_shift is not None:
+            shift = shift + residual_shift
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         N, Cin, H, W = xb.shape
         y = torch.empty((N, conv.out_channels, H, W), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
@@ -956,6 +981,8 @@ def _conv_bn_act(conv, bn, x, residual=None, relu=True, dropout_p=0.0, pool=Fals
         if rc:
             raise RuntimeError('salsa_nn_conv3x3_wide_bias_act failed (%d)' % rc)
         return avg_pool2x2(y) if pool else y      # (pool: the last layer of a block before a stride-2 block)
+    if residual_shift is not None:                       # no folding epilogue on this path: the shift joins the residual here
+        residual = (residual.float() + residual_shift.view(1, -1, 1, 1)).to(residual.dtype)
     if (isinstance(conv, Conv3x3) and conv._stem_eligible(x) and residual is None and not bn.training
             and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine):
         wq, shift = _folded(conv, bn, stem=True)

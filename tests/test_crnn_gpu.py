@@ -889,3 +889,46 @@ def test_hip_frequency_mean_matches_torch_forward_and_backward():
         assert torch.equal(x.grad, want)
     xf = torch.randn(2, 64, 7, 5, device=dev)                                      # float32 input: the torch expression
     assert torch.equal(nn_ops.freq_mean_sequence(xf), xf.mean(dim=3).transpose(1, 2))
+
+
+def test_eval_shortcut_folding_matches_the_unfolded_block():
+    """Inference under bf16 autocast: the 1x1 shortcut's BatchNorm folded into its GEMM, its shift added by conv2's epilogue
+    (nn_ops.folded_shortcut) against bn(conv1x1(x)) as a separate pass -- per block to bf16 rounding of the two differently
+    rounded intermediates, and on the whole model's outputs."""
+    from salsa_amd.crnn import SeldCRNN, nn_ops
+    from salsa_amd.crnn.model import ResBlock
+    from salsa_amd.crnn.testing import seeded_fill
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    old = nn_ops.FOLD_SHORTCUT
+    try:
+        blk = ResBlock(64, 128, 2).to(dev).eval()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2, blk.short_bn):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+                bn.running_mean.uniform_(-0.3, 0.3)
+                bn.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(2, 64, 32, 20, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        outs = {}
+        for fold in (False, True):
+            nn_ops.FOLD_SHORTCUT = fold
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                outs[fold] = blk(x).float()
+        scale = float(outs[False].abs().max())
+        assert outs[True].shape == outs[False].shape and (outs[True] - outs[False]).abs().max() <= 0.02 * scale
+        assert (outs[True] - outs[False]).abs().mean() <= 2e-3 * scale
+        m = SeldCRNN()
+        seeded_fill(m, 7)
+        m = m.to(dev).eval()
+        xin = torch.randn(2, 7, 160, 200, device=dev)
+        res = {}
+        for fold in (False, True):
+            nn_ops.FOLD_SHORTCUT = fold
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                res[fold] = {k: v.float() for k, v in m(xin).items()}
+        for k in res[False]:
+            s = float(res[False][k].abs().max()) + 1e-6
+            assert (res[True][k] - res[False][k]).abs().max() <= 0.03 * s, k
+    finally:
+        nn_ops.FOLD_SHORTCUT = old
