@@ -65,6 +65,18 @@ def cpu_baseline(feature, fmt, fmax, n_samples):
     return cpu_bench.run(feature, fmt, fmax, n_samples)
 
 
+
+def _emit(line):
+    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
+    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(line) + '\n')
+    sys.stdout.flush()
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -391,7 +403,7 @@ def main():
         line['pcie_inclusive'] = pcie
     if pipelined:
         line['pipelined'] = pipelined
-    print(json.dumps(line))
+    _emit(line)
     if failures and not args.tolerate_crnn_failure:
         sys.stdout.flush()
         sys.exit(3)

@@ -113,7 +113,7 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
 
 
 def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False,
-                n_frames=640, amp_dtype='default'):
+                n_frames=640, amp_dtype='default', force_ddp=False):
     """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
     `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 torch DDP = bucketed gradient all-reduce on RCCL
     overlapped with the backward.  The process group must already be initialised for world > 1.  Every rank calls this;
@@ -128,6 +128,8 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
     on_gpu = dev.type == 'cuda'
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     kw = {} if amp_dtype == 'default' else {'amp_dtype': amp_dtype}
+    if force_ddp:
+        kw['ddp'] = True                          # (a 1-rank group: --force-ddp)
     tr = Trainer(dev, bf16_grad_allreduce=not fp32_grads, **kw)
     x, sed, doa = synthetic_batch(batch, dev, seed=2021 + rank, n_frames=n_frames)
     ex, audio = None, None
@@ -178,7 +180,7 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
     tflops = 3 * GFLOP_PER_CHUNK_FWD * cps / 1e3                     # fwd + bwd ~ 3x forward
     return {
         'metric': 'CRNN train clips/s', 'value': round(cps, 1), 'unit': '8-s chunks/s', 'n_gpus': world,
-        'rccl_ranks': ranks, 'backend': (dist.get_backend() if world > 1 else None), 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
+        'rccl_ranks': ranks, 'backend': (dist.get_backend() if (world > 1 or force_ddp) else None), 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * elapsed / steps, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,%d,200), batch %d per GPU, Adam'
                                % ('on-the-fly extracted MIC (raw [B][4][192000] audio -> SALSA-MIC on device, scaler fused)' if on_the_fly else 'precomputed-FOA-shaped', n_frames, batch)
@@ -190,6 +192,18 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
         'final_loss': float(loss)}
 
 
+
+def _emit(line):
+    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
+    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(line) + '\n')
+    sys.stdout.flush()
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,6 +214,9 @@ def main():
     ap.add_argument('--augment', action='store_true', help='apply the reference training augmentation on device every step')
     ap.add_argument('--fp32-grads', action='store_true', help='all-reduce fp32 gradients instead of bf16-compressed')
     ap.add_argument('--infer', action='store_true', help='config 5: batched inference, SALSA + CRNN forward on 60-s clips')
+    ap.add_argument('--force-ddp', action='store_true',
+                    help='one rank only: wrap the model in DistributedDataParallel over a 1-rank RCCL group anyway (what the N > 1 path '
+                         'costs BEFORE any communication: hooks, bucket copies, the bf16 compression)')
     ap.add_argument('--clips', type=int, default=32, help='--infer: 60-s clips per GPU per step')
     ap.add_argument('--sub-batch', type=int, default=32,
                     help='--infer: clips per extraction + CRNN forward (config 5 says 32; 8 gives a third of the latency at 77 %% of the rate)')
@@ -218,19 +235,25 @@ def main():
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
+    elif args.force_ddp:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if args.infer:
         from salsa_amd.crnn.train import Trainer
         line = infer_bench(args, rank, world, dev, Trainer(dev, ddp=False))
         if world > 1:
             dist.destroy_process_group()
         if line is not None:
-            print(json.dumps(line))
+            _emit(line)
         return
-    line = train_bench(rank, world, dev, args.batch, args.steps, args.warmup, args.on_the_fly, args.augment, args.fp32_grads)
-    if world > 1:
+    line = train_bench(rank, world, dev, args.batch, args.steps, args.warmup, args.on_the_fly, args.augment, args.fp32_grads,
+                       force_ddp=args.force_ddp)
+    if world > 1 or args.force_ddp:
         dist.destroy_process_group()
     if line is not None:
-        print(json.dumps(line))
+        _emit(line)
 
 
 if __name__ == '__main__':

@@ -609,7 +609,9 @@ class _Conv1x1(torch.autograd.Function):
             gx = _conv1x1_hip(gy, wbt if wbt is not None else wb.transpose(0, 1).contiguous())
         own_wrw = ctx.needs_input_grad[1] and bool(L.salsa_nn_conv1x1_wrw_supported(M, Cin, Cout))
         if own_wrw:
-            gw = _grad_zeros((Cout, Cin, 1, 1), x.device)
+            # (channels-last strides, like the trainer's weights: literally different strides for the same bytes of a 1 x 1 filter
+            # send DistributedDataParallel's bucket copy down its slow path -- 'Grad strides do not match bucket view strides')
+            gw = _grad_zeros((Cout, Cin, 1, 1), x.device).as_strided((Cout, Cin, 1, 1), (Cin, 1, Cin, Cin))
             with torch.cuda.device(x.device):
                 rc = L.salsa_nn_conv1x1_wrw(_ptr(x), _ptr(gy), _ptr(gw), M, Cin, Cout, _stream(x))
             if rc:
