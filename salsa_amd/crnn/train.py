@@ -1,8 +1,9 @@
 """Training step of the SELD CRNN on PyTorch-ROCm: bf16 autocast, channels-last activations, every convolution / BatchNorm /
 pool / GRU scan on the hand-written HIP kernels of salsa_amd/csrc (MIOpen only if they are switched off), Adam with the
 reference's piecewise-linear learning-rate schedule (utilities/learning_utils.py:17-52, experiments/configs/seld.yml:
-37-52), and data parallelism as one process per GPU with torch DDP = bucketed gradient all-reduce on RCCL over xGMI,
-overlapped with the backward pass (the reference only has Lightning's implicit ddp_spawn, experiments/train.py:98).
+37-52), and data parallelism as one process per GPU: bucketed gradient all-reduce on RCCL over xGMI overlapped with the backward
+pass (grad_sync.py; torch's DDP behind SALSA_GRAD_SYNC=ddp) -- the reference only has Lightning's implicit ddp_spawn,
+experiments/train.py:98.
 BatchNorm statistics stay per rank, as in the reference (no SyncBN)."""
 import os
 
@@ -54,7 +55,15 @@ class Trainer:
             model = model.to(memory_format=torch.channels_last)
         self.raw_model = model
         use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        if use_ddp:
+        self.grad_sync = None
+        if use_ddp and os.environ.get('SALSA_GRAD_SYNC', 'buckets') != 'ddp':
+            # bucketed all-reduce overlapped with the backward pass, a few multi-tensor kernels per step (grad_sync.py; torch's
+            # DDP wrapper costs this model +0.5 - 1.0 ms per 11-ms step on ONE rank: 143 device copies, one per gradient)
+            from .grad_sync import BucketedGradSync
+            wire = torch.bfloat16 if (bf16_grad_allreduce and self.device.type == 'cuda') else torch.float32
+            self.grad_sync = BucketedGradSync(list(model.parameters()), bucket_mb=25, wire_dtype=wire)
+            self.grad_sync.broadcast_parameters(0)           # (SALSA_GRAD_SYNC=ddp selects torch's DistributedDataParallel instead)
+        elif use_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             kw = dict(device_ids=[self.device.index], output_device=self.device.index) if self.device.type == 'cuda' else {}
             model = DDP(model, bucket_cap_mb=25, gradient_as_bucket_view=True, **kw)   # 56.4 MB fp32 -> 3 buckets
@@ -88,6 +97,8 @@ class Trainer:
             pred = self.model(x)
         loss, sed_l, doa_l = seld_loss(pred, sed, doa)
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()                # averaged gradients are in place
         self.opt.step()
         self.step_idx += 1
         return loss.detach(), sed_l.detach(), doa_l.detach()
