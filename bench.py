@@ -119,12 +119,18 @@ def main():
     from salsa_amd.extractor import SalsaExtractor
 
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
+    # SALSA_BENCH_SHARE_GPU=1 (functional test of the N > 1 path on a one-GPU box): ranks share the visible devices round-robin
+    # and the process group is gloo (RCCL refuses two ranks on one device) -- the timing means nothing then, the control flow
+    # (sharding, barriers, max over ranks, the gradient synchroniser, rank-0-only line) is the real one
+    share = os.environ.get('SALSA_BENCH_SHARE_GPU', '0') == '1'
+    if share:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     rccl_ranks = 1
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('gloo') if share else dist.init_process_group('nccl', device_id=dev)
         rccl_ranks = dist.get_world_size()          # read back from the process group, not from the command line
 
     ex = SalsaExtractor(audio_format=fmt, feature_type=args.feature, fmax_doa=fmax, device=dev)

@@ -10,7 +10,7 @@ paid at every N > 1 before the first byte crosses a link.
 Here: parameters are cut into buckets in reverse registration order (roughly the order their gradients appear); a
 post-accumulate-grad hook counts a bucket's gradients in; when the last one has arrived the bucket is gathered into ONE flat
 buffer by one multi-tensor copy, cast to the wire dtype (bf16 halves the bytes on xGMI; float32 selectable), and all-reduced
-asynchronously on a communication stream while the backward pass goes on.  ``finish()`` (before the optimizer step) waits for the
+asynchronously (on the process group's own stream) while the backward pass goes on.  ``finish()`` (before the optimizer step) waits for the
 buckets in launch order, scales by 1 / world and points every ``.grad`` at its slice of the bucket (no scatter pass).  Replicas start identical because every rank builds the model from the same seed; ``broadcast_parameters`` does it
 explicitly when asked.
 """
@@ -36,7 +36,8 @@ class BucketedGradSync:
         params = [p for p in params if p.requires_grad]
         assert params, 'no trainable parameters'
         self.device = params[0].device
-        self.wire_dtype = wire_dtype if self.device.type == 'cuda' else torch.float32   # (gloo: float32 on the wire)
+        nccl = self.device.type == 'cuda' and dist.get_backend(process_group) == 'nccl'
+        self.wire_dtype = wire_dtype if nccl else torch.float32                          # (gloo: float32 on the wire)
         self.buckets, self._bucket_of = [], {}
         cap, cur, cur_bytes = int(bucket_mb * 2 ** 20), [], 0
         for p in reversed(params):                       # gradients appear roughly in reverse registration order
@@ -48,7 +49,6 @@ class BucketedGradSync:
         if cur:
             self._add_bucket(cur)
         self._launched = []
-        self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
 
     def _add_bucket(self, plist):
@@ -86,12 +86,9 @@ class BucketedGradSync:
             torch._foreach_copy_(b.views, grads)
             if b.wire is not b.flat:
                 b.wire.copy_(b.flat)                     # float32 -> wire dtype, one kernel
-        if self._comm_stream is not None:
-            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._comm_stream):
-                b.work = dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        else:
-            b.work = dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # issued from the current stream: the process group runs the collective on ITS OWN stream, which first waits for what the
+        # current stream has queued so far (the gather and the cast above) -- the backward kernels that follow overlap it
+        b.work = dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._launched.append(b)
 
     # ---- before the optimizer step
@@ -104,7 +101,7 @@ class BucketedGradSync:
         inv = 1.0 / self.world
         with torch.no_grad():
             for b in self._launched:
-                b.work.wait()                            # (CUDA: makes the current stream wait for the communication stream's work)
+                b.work.wait()                            # (RCCL: makes the current stream wait for the collective's stream)
                 if b.wire is not b.flat:
                     b.flat.copy_(b.wire)                 # wire dtype -> float32
                 b.flat.mul_(inv)
