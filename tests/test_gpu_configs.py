@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -269,3 +270,62 @@ def test_bench_self_spawns_two_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2
     assert line['crnn']['n_gpus'] == 2 and line['crnn']['rccl_ranks'] == 2 and line['crnn']['value'] > 0
+
+
+def _shared_gpu_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    torch.cuda.set_device(0)
+    d = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)           # (RCCL refuses two ranks on one device)
+    out = {}
+    for k in range(2):                                                     # two Trainers one after the other, as bench.py's legs
+        tr = Trainer(d, total_steps=10)
+        assert tr.grad_sync is not None
+        x, sed, doa = synthetic_batch(2, d, seed=100 + rank + 10 * k)      # different chunks per rank
+        t0 = time.perf_counter()
+        for _ in range(3):
+            loss, _, _ = tr.train_step(x, sed, doa)
+        torch.cuda.synchronize()
+        out['after%d' % k] = torch.cat([p.detach().flatten() for p in tr.raw_model.parameters()]).cpu()
+        out['loss%d' % k], out['s%d' % k] = float(loss), time.perf_counter() - t0
+    torch.save(out, os.path.join(tmp, 'g%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_keep_replicas_identical(tmp_path):
+    """The N > 1 training path on the real HIP kernels with ONE GPU: two processes on cuda:0, gloo process group, the bucketed
+    gradient synchroniser (salsa_amd/crnn/grad_sync.py) on CUDA tensors, two Trainers in a row per process (bench.py's `crnn`
+    and `config4` legs).  Replicas stay bit-identical although the ranks see different chunks, and the second Trainer is as
+    fast as the first (a synchroniser that ran its collectives from a private stream made every second one 100x slower)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_shared_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    for k in range(2):
+        assert np.isfinite(r0['loss%d' % k]) and r0['loss%d' % k] != r1['loss%d' % k]
+        assert torch.equal(r0['after%d' % k], r1['after%d' % k])
+    assert r0['s1'] < 5 * r0['s0'] + 5.0, (r0['s0'], r0['s1'])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`SALSA_BENCH_SHARE_GPU=1 python bench.py --gpus 2` (no launcher: it re-executes itself under torch.distributed.run): the
+    whole N = 2 control flow of the driver's command on one device -- n_gpus = ranks = 2 in both halves, every leg present,
+    the JSON line last on stdout."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SALSA_BENCH_SHARE_GPU'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '2', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)                                                 # the result is the LAST line
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['value'] > 0
+    for leg in ('crnn', 'config4'):
+        assert line[leg]['n_gpus'] == 2 and line[leg]['rccl_ranks'] == 2 and line[leg]['value'] > 0, leg
+    assert line['inference']['value'] > 0
