@@ -329,3 +329,48 @@ def test_bench_two_ranks_on_one_gpu():
     for leg in ('crnn', 'config4'):
         assert line[leg]['n_gpus'] == 2 and line[leg]['rccl_ranks'] == 2 and line[leg]['value'] > 0, leg
     assert line['inference']['value'] > 0
+
+
+def _sharded_harness_worker(rank, world, port, cfg):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from salsa_amd.distributed import extract_features_sharded
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    extract_features_sharded(data_config=cfg, batch_size=2)
+    dist.destroy_process_group()
+
+
+def test_sharded_harness_with_two_ranks_on_one_gpu_equals_the_single_process_tree(tmp_path):
+    """salsa_amd.distributed.extract_features_sharded (rank r extracts the r-th contiguous range of every split's sorted file
+    list on ITS process's extractor; the scaler's partial sums are all-reduced, rank 0 writes it) run by two gloo ranks that share
+    cuda:0, against salsa_amd.features.extract_features in one process: the same files, bit-identical features, the same scaler."""
+    import torch.multiprocessing as mp
+    from salsa_amd import io as sio
+    from salsa_amd.features import extract_features
+    from test_gpu_parity import _make_tree
+    clips = {('dev|fold%d_clip%d' % (1 + i % 2, i)): synth_clip(900 + i, 24000 + 3000 * i) for i in range(5)}
+    clips['eval|mix001'] = synth_clip(950, 30000)
+    trees = {}
+    for mode in ('single', 'sharded'):
+        d = tmp_path / mode
+        d.mkdir()
+        cfg, feat_dir = _make_tree(str(d), 'foa', clips, 9000)
+        if mode == 'single':
+            extract_features(data_config=cfg, batch_size=2)
+        else:
+            mp.spawn(_sharded_harness_worker, args=(2, _free_port(), cfg), nprocs=2, join=True)
+        found = {}
+        for root, _, files in os.walk(feat_dir):
+            for f in files:
+                found[os.path.relpath(os.path.join(root, f), feat_dir)] = sio.load_arrays(os.path.join(root, f))
+        trees[mode] = found
+    assert sorted(trees['single']) == sorted(trees['sharded']) and len(trees['single']) == 7       # 6 clips + the scaler
+    for rel, arrs in trees['single'].items():
+        for k, v in arrs.items():
+            w = trees['sharded'][rel][k]
+            if rel.endswith('scaler.h5'):
+                np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-6)        # (float64 partial sums added in another order)
+            else:
+                assert np.array_equal(w, v), (rel, k)
