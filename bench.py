@@ -66,14 +66,20 @@ def cpu_baseline(feature, fmt, fmax, n_samples):
 
 
 
-def _emit(line):
-    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
-    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+def _flush_c_stdio():
+    """push out whatever native libraries (RCCL's version banner) left in libc's stdout buffer -- every rank, as soon as its
+    process group is gone, so that nothing of it can land after rank 0's result line"""
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+
+
+def _emit(line):
+    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
+    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+    _flush_c_stdio()
     sys.stdout.write(json.dumps(line) + '\n')
     sys.stdout.flush()
 
@@ -366,6 +372,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        _flush_c_stdio()
     if rank != 0:
         return
     # CPU baseline: rank 0 only, for every N (after the process group is gone, so the other ranks are not kept waiting on a

@@ -193,14 +193,20 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
 
 
 
-def _emit(line):
-    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
-    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+def _flush_c_stdio():
+    """push out whatever native libraries (RCCL's version banner) left in libc's stdout buffer -- every rank, as soon as its
+    process group is gone, so that nothing of it can land after rank 0's result line"""
     import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+
+
+def _emit(line):
+    """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
+    in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
+    _flush_c_stdio()
     sys.stdout.write(json.dumps(line) + '\n')
     sys.stdout.flush()
 
@@ -251,6 +257,7 @@ def main():
         line = infer_bench(args, rank, world, dev, Trainer(dev, ddp=False))
         if world > 1:
             dist.destroy_process_group()
+            _flush_c_stdio()
         if line is not None:
             _emit(line)
         return
@@ -258,6 +265,7 @@ def main():
                        force_ddp=args.force_ddp)
     if world > 1 or args.force_ddp:
         dist.destroy_process_group()
+        _flush_c_stdio()
     if line is not None:
         _emit(line)
 
