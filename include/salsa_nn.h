@@ -72,6 +72,13 @@ int salsa_nn_conv3x3_wide_wrw_supported(int64_t N, int H, int W, int Cin, int Co
 int64_t salsa_nn_conv3x3_wide_table_len(int64_t N, int H, int W);
 int64_t salsa_nn_conv3x3_wide_tile_count(int64_t N, int H, int W);
 int salsa_nn_conv3x3_wide_tables(int64_t N, int H, int W, int *vpos_host, int *inv_host, int *tile_bounds_host);
+/* Training forward of the wide layers that also leaves the per-channel sum / sum of squares of its (bf16-rounded) output as
+ * float64 partial rows stats_part[salsa_nn_conv3x3_wide_stats_blocks(...)][2][Cout] in its epilogue, like
+ * salsa_nn_conv3x3_c64_stats: the BatchNorm that follows (salsa_nn_bn_train_fwd: stats_part, stats_blocks) makes no statistics
+ * pass over y. */
+int salsa_nn_conv3x3_wide_stats_blocks(int64_t N, int H, int W, int Cin, int Cout);
+int salsa_nn_conv3x3_wide_stats(const void *x, const void *w, void *y, double *stats_part, int64_t N, int H, int W, int Cin, int Cout,
+                                void *hip_stream);
 int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *dw, const int *d_vpos, const int *d_inv, const int *d_tile_bounds,
                               int64_t N, int H, int W, int Cin, int Cout, void *hip_stream);
 /* Training forward of the 64 -> 64 layer that ALSO leaves the per-channel sum and sum of squares of its (bf16-rounded) output as

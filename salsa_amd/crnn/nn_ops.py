@@ -411,14 +411,18 @@ class _Conv3x3C64(torch.autograd.Function):
         return gx, gw, None, None, None, None
 
 
-def _conv_wide(x, w, add=None):
+def _conv_wide(x, w, add=None, stats_part=None):
     """salsa_nn_conv3x3_wide: x (N,Cin,H,W) bf16 channels-last, w (Cout,Cin,3,3) bf16 channels-last -> (N,Cout,H,W); ``add``
-    (the output's shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding."""
+    (the output's shape, bf16 channels-last) is added in the kernel's epilogue before the single rounding; ``stats_part``
+    (float64, salsa_nn_conv3x3_wide_stats_blocks x 2 x Cout) receives the output's per-channel partial sums (training)."""
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     y = torch.empty((N, Cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        if add is None:
+        if stats_part is not None:
+            assert add is None
+            rc = _lib.load().salsa_nn_conv3x3_wide_stats(_ptr(x), _ptr(w), _ptr(y), _ptr(stats_part), N, H, W, Cin, Cout, _stream(x))
+        elif add is None:
             rc = _lib.load().salsa_nn_conv3x3_wide(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, _stream(x))
         else:
             rc = _lib.load().salsa_nn_conv3x3_wide_bias_act(_ptr(x), _ptr(w), _ptr(_zero_shift(Cout, x.device)), _ptr(add), _ptr(y), 0,
@@ -474,11 +478,13 @@ class _Conv3x3Wide(torch.autograd.Function):
     gradient (transposing LDS reads, float32 result); shapes a kernel does not take fall back to torch / MIOpen."""
 
     @staticmethod
-    def forward(ctx, x, weight, wb=None, wbt=None, skip=False):
+    def forward(ctx, x, weight, wb=None, wbt=None, skip=False, stats_part=None):
         if wb is None:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         ctx.save_for_backward(x, wb, wbt)
-        return (_conv_wide(x, wb), x) if skip else _conv_wide(x, wb)       # (skip: see _Conv3x3C64)
+        # stats_part: a float64 buffer the kernel fills with its output's per-channel partial sums (not differentiated)
+        y = _conv_wide(x, wb, stats_part=stats_part)
+        return (y, x) if skip else y                                         # (skip: see _Conv3x3C64)
 
     @staticmethod
     def backward(ctx, gy, gskip=None):
@@ -504,7 +510,7 @@ class _Conv3x3Wide(torch.autograd.Function):
             gw = r[1].float() if need[1] else gw
             if need[0] and gskip is not None:
                 gx = gx + gskip
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 def _planar_rows(x):
@@ -804,6 +810,7 @@ def _bank_filters(conv):
 
 USE_FUSED_SKIP = os.environ.get('SALSA_FUSED_SKIP', '1') != '0'
 USE_CONV_STATS = os.environ.get('SALSA_CONV_STATS', '1') != '0'   # BatchNorm statistics from the 64 -> 64 convolution's epilogue
+USE_WIDE_CONV_STATS = os.environ.get('SALSA_WIDE_CONV_STATS', '1') != '0'   # the same in the wide kernels' epilogue
 
 
 class Conv3x3(torch.nn.Conv2d):
@@ -835,8 +842,11 @@ class Conv3x3(torch.nn.Conv2d):
                                                                 self.out_channels))
 
     def stats_buffer(self, x):
-        """A float64 buffer for the output's per-channel partial sums when this call will run the 64 -> 64 MFMA kernel in
-        training (salsa_nn_conv3x3_c64_stats), else None: pass it to forward / forward_skip and on to the BatchNorm."""
+        """A float64 buffer for the output's per-channel partial sums when this call will run the 64 -> 64 or the wide MFMA kernel
+        in training (salsa_nn_conv3x3_c64_stats / _wide_stats), else None: pass it to forward / forward_skip and on to the BatchNorm."""
+        if USE_CONV_STATS and USE_WIDE_CONV_STATS and torch.is_grad_enabled() and not self._hip_eligible(x) and self._wide_eligible(x):
+            nb = _lib.load().salsa_nn_conv3x3_wide_stats_blocks(x.shape[0], x.shape[2], x.shape[3], self.in_channels, self.out_channels)
+            return torch.empty(nb * 2 * self.out_channels, dtype=torch.float64, device=x.device) if nb > 0 else None
         if not (USE_CONV_STATS and torch.is_grad_enabled() and self._hip_eligible(x)):
             return None
         nb = _lib.load().salsa_nn_conv3x3_c64_stats_blocks(x.shape[0], x.shape[2], x.shape[3])
@@ -851,7 +861,7 @@ class Conv3x3(torch.nn.Conv2d):
                 xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 if self._hip_eligible(x):
                     return _Conv3x3C64.apply(xb, self.weight, *_bank_filters(self), True, stats_part)
-                return _Conv3x3Wide.apply(xb, self.weight, *_bank_filters(self), True)
+                return _Conv3x3Wide.apply(xb, self.weight, *_bank_filters(self), True, stats_part)
         return self.forward(x, stats_part), x
 
     def forward(self, x, stats_part=None):
@@ -862,7 +872,7 @@ class Conv3x3(torch.nn.Conv2d):
         if self._wide_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3Wide.apply(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), self.weight,
-                                          *_bank_filters(self))
+                                          *_bank_filters(self), False, stats_part)
         if self._stem_eligible(x):
             with torch.autocast('cuda', enabled=False):
                 return _Conv3x3Stem.apply(x, self.weight)

@@ -45,6 +45,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 // byte offset of 16-byte piece q of 64-byte row `row` (XOR swizzle, see the header)
 __device__ __forceinline__ unsigned swz_off(int row, int q) { return (unsigned)row * 64u + (unsigned)((q ^ ((row >> 2) & 3)) * 16); }
 
+template <int CTRL> __device__ __forceinline__ float wide_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // Staging is LDS-direct (global_load_lds_dwordx4: a wave-instruction fills 64 consecutive 16-byte LDS pieces, no staging
 // registers) and double-buffered: the loads of step i+1 -- the next filter row's weights, and at the first row of a channel
 // chunk the NEXT chunk's input pixels -- are issued right after the single barrier of step i and land while its MFMAs run.
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
                                                                int xl_bytes /* one input buffer, a multiple of 1024 */,
                                                                const float *__restrict__ shift /* [COUT] or NULL */,
                                                                const unsigned short *__restrict__ residual /* like y, or NULL */,
-                                                               int relu)
+                                                               int relu, double *__restrict__ stats_part /* training: see the epilogue */)
 {
     constexpr int CT = TN / 32;          // output-channel tiles per wave
     constexpr int NT = 64 * WV, TM = 64 * WV;
@@ -217,6 +222,70 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
             compute(r, (unsigned)(xb * xl_bytes), (unsigned)(2 * xl_bytes + wb * WL_BYTES));
         }
     }
+    // Training (stats_part != NULL): the per-channel sum and sum of squares of this tile's bf16-ROUNDED outputs -- what the
+    // BatchNorm that follows would otherwise read the whole tensor for (15 statistics passes, 0.17 ms per step) -- as ONE float64
+    // row pair stats_part[blockIdx.x][sum | sum of squares][COUT] (this workgroup's TN channels of it), the layout of the
+    // BatchNorm kernels' own partial table.  Per wave like conv64_stats (conv_mfma.hip): two DPP quad permutes sum neighbouring
+    // pixel columns, lane q of a quad keeps channel group g = q, three shuffles combine the 8 quads of a half-wave; the
+    // workgroup's waves meet in LDS (the tile buffers are free by then).
+    if (stats_part) {
+        const float m0 = pix[0] < P ? 1.f : 0.f, m1 = pix[1] < P ? 1.f : 0.f;
+        const int quad = l32 & 3;
+        float rs[CT][4], rq[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float t[4], q[4];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const unsigned u0 = pack_bf16(acc[ct][0][4 * g + 2 * k], acc[ct][0][4 * g + 2 * k + 1]);
+                    const unsigned u1 = pack_bf16(acc[ct][1][4 * g + 2 * k], acc[ct][1][4 * g + 2 * k + 1]);
+                    const float a0 = __uint_as_float(u0 << 16), a1 = __uint_as_float(u0 & 0xffff0000u);
+                    const float b0 = __uint_as_float(u1 << 16), b1 = __uint_as_float(u1 & 0xffff0000u);
+                    t[2 * k] = a0 * m0 + b0 * m1;
+                    t[2 * k + 1] = a1 * m0 + b1 * m1;
+                    q[2 * k] = fmaf(a0 * m0, a0, b0 * m1 * b0);
+                    q[2 * k + 1] = fmaf(a1 * m0, a1, b1 * m1 * b1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    t[j] += wide_dpp<0xB1>(t[j]); q[j] += wide_dpp<0xB1>(q[j]); // quad_perm [1,0,3,2]
+                    t[j] += wide_dpp<0x4E>(t[j]); q[j] += wide_dpp<0x4E>(q[j]); // quad_perm [2,3,0,1]
+                    if (g == 0) { rs[ct][j] = 0.f; rq[ct][j] = 0.f; }
+                    rs[ct][j] = quad == g ? t[j] : rs[ct][j];
+                    rq[ct][j] = quad == g ? q[j] : rq[ct][j];
+                }
+            }
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int d = 4; d <= 16; d <<= 1) {
+                    rs[ct][j] += __shfl_xor(rs[ct][j], d);
+                    rq[ct][j] += __shfl_xor(rq[ct][j], d);
+                }
+        float *lstats = (float *)lds; // [wave][sum | sum of squares][TN]
+        __syncthreads();              // every wave is done with the tile buffers
+        if (l32 < 4) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int c = ct * 32 + 8 * l32 + 4 * khalf + j; // (quad == l32 for these lanes)
+                    lstats[(wv * 2 + 0) * TN + c] = rs[ct][j];
+                    lstats[(wv * 2 + 1) * TN + c] = rq[ct][j];
+                }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * TN; i += NT) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < WV; w8++) sum += (double)lstats[w8 * 2 * TN + i];
+            stats_part[((long)blockIdx.x * 2 + i / TN) * COUT + co0 + i % TN] = sum;
+        }
+    }
     // D: column = lane&31 = pixel, row (= co within the tile) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane holds runs of 4
     // consecutive channels and its partner lane (the same pixel, lane +- 32) the other half of each 8-channel run.
     // v_permlane32_swap trades runs between the two so that each lane owns whole 8-channel runs: 16-byte stores, half as many
@@ -276,7 +345,7 @@ int wide_xl_bytes(int TM, int H, int W) { return ((wide_rows(TM, H, W) * (W + 2)
 
 template <int TN, int WV>
 int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int Cin, int Cout, hipStream_t st, const float *shift,
-                const void *residual, int relu)
+                const void *residual, int relu, double *stats_part)
 {
     constexpr int TM = 64 * WV;
     const long P = N * H * W;
@@ -288,7 +357,7 @@ int wide_launch(const void *x, const void *w, void *y, long N, int H, int W, int
         return -6;
     hipLaunchKernelGGL((conv3x3_wide_kernel<TN, WV>), dim3((unsigned)((P + TM - 1) / TM), (unsigned)(Cout / TN)), dim3(64 * WV), lds, st,
                        (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, Cin, Cout,
-                       wide_rows(TM, H, W), xlb, shift, (const unsigned short *)residual, relu);
+                       wide_rows(TM, H, W), xlb, shift, (const unsigned short *)residual, relu, stats_part);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -301,21 +370,47 @@ extern "C" int salsa_nn_conv3x3_wide_supported(int64_t N, int H, int W, int Cin,
     return wide_xl_bytes(256, H, W) <= MAX_XL_BYTES;
 }
 
+// tile choice: 512 pixels x 128 channels per workgroup when that still gives every CU a workgroup; smaller tiles for the small
+// maps (40 x 12 x 32 clips = 15 360 pixels: 30 tiles of 512).  Returns the pixels per tile (512 | 256), *tn the channels (128 | 64).
+static int wide_tile(int64_t N, int H, int W, int Cout, int *tn)
+{
+    const long P = (long)N * H * W;
+    const bool big_ok = wide_xl_bytes(512, H, W) <= MAX_XL_BYTES;
+    if (Cout % 128 == 0 && big_ok && (P + 511) / 512 * (Cout / 128) >= 192) { *tn = 128; return 512; }
+    if (Cout % 128 == 0 && (P + 255) / 256 * (Cout / 128) >= 192) { *tn = 128; return 256; }
+    *tn = 64;
+    return (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) ? 512 : 256;
+}
+
 static int wide_dispatch(const void *x, const void *w, void *y, int64_t N, int H, int W, int Cin, int Cout, void *hip_stream,
-                         const float *shift, const void *residual, int relu)
+                         const float *shift, const void *residual, int relu, double *stats_part = nullptr)
 {
     if (!x || !w || !y || x == y || !salsa_nn_conv3x3_wide_supported(N, H, W, Cin, Cout)) return -1;
-    const long P = (long)N * H * W;
     hipStream_t st = (hipStream_t)hip_stream;
-    // tile choice: 512 pixels x 128 channels per workgroup when that still gives every CU a workgroup; smaller tiles for the
-    // small maps (40 x 12 x 32 clips = 15 360 pixels: 30 tiles of 512)
-    const bool big_ok = wide_xl_bytes(512, H, W) <= MAX_XL_BYTES;
-    const long wg_big = (P + 511) / 512 * (Cout / 128);
-    if (Cout % 128 == 0 && big_ok && wg_big >= 192) return wide_launch<128, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
-    const long wg_mid = (P + 255) / 256 * (Cout / 128);
-    if (Cout % 128 == 0 && wg_mid >= 192) return wide_launch<128, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
-    if (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) return wide_launch<64, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
-    return wide_launch<64, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu);
+    int tn;
+    const int tm = wide_tile(N, H, W, Cout, &tn);
+    if (tn == 128 && tm == 512) return wide_launch<128, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu, stats_part);
+    if (tn == 128) return wide_launch<128, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu, stats_part);
+    if (tm == 512) return wide_launch<64, 8>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu, stats_part);
+    return wide_launch<64, 4>(x, w, y, N, H, W, Cin, Cout, st, shift, residual, relu, stats_part);
+}
+
+/* training: rows of partial statistics salsa_nn_conv3x3_wide_stats writes (= its pixel tiles), 0 if unsupported */
+extern "C" int salsa_nn_conv3x3_wide_stats_blocks(int64_t N, int H, int W, int Cin, int Cout)
+{
+    if (!salsa_nn_conv3x3_wide_supported(N, H, W, Cin, Cout)) return 0;
+    int tn;
+    const int tm = wide_tile(N, H, W, Cout, &tn);
+    return (int)(((long)N * H * W + tm - 1) / tm);
+}
+
+/* training: the plain convolution, which also leaves the per-channel sum / sum of squares of its (bf16-rounded) output as float64
+ * partial rows stats_part[blocks][2][Cout] for the BatchNorm that follows (salsa_nn_bn_train_fwd's stats_part / stats_blocks) */
+extern "C" int salsa_nn_conv3x3_wide_stats(const void *x, const void *w, void *y, double *stats_part, int64_t N, int H, int W, int Cin,
+                                           int Cout, void *hip_stream)
+{
+    if (!stats_part) return -1;
+    return wide_dispatch(x, w, y, N, H, W, Cin, Cout, hip_stream, nullptr, nullptr, 0, stats_part);
 }
 
 // x: [N][H][W][Cin] bf16, w: [Cout][3][3][Cin] bf16 (a channels-last torch.nn.Conv2d weight), y: [N][H][W][Cout] bf16

@@ -932,3 +932,30 @@ def test_eval_shortcut_folding_matches_the_unfolded_block():
             assert (res[True][k] - res[False][k]).abs().max() <= 0.03 * s, k
     finally:
         nn_ops.FOLD_SHORTCUT = old
+
+
+@pytest.mark.parametrize('shape', [(4, 128, 128, 40, 50), (3, 256, 512, 20, 12), (2, 64, 128, 33, 25), (5, 512, 512, 7, 12)])
+def test_wide_conv_statistics_epilogue_matches_sums_of_its_output(shape):
+    """salsa_nn_conv3x3_wide_stats: the convolution's output is bit-identical to the plain kernel's, and the float64 partial rows
+    it leaves add up to the per-channel sum / sum of squares of that (bf16-rounded) output -- every tile variant (512 / 256 pixels
+    x 128 / 64 channels), maps whose pixel count is not a multiple of the tile (masked tail)."""
+    from salsa_amd import _lib
+    from salsa_amd.crnn import nn_ops
+    N, cin, cout, H, W = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(sum(shape))
+    x = torch.randn((N, cin, H, W), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert _lib.load().salsa_nn_conv3x3_wide_supported(N, H, W, cin, cout)
+    nb = _lib.load().salsa_nn_conv3x3_wide_stats_blocks(N, H, W, cin, cout)
+    assert nb > 0
+    part = torch.full((nb, 2, cout), float('nan'), dtype=torch.float64, device=dev)
+    y_plain = nn_ops._conv_wide(x, w)
+    y = nn_ops._conv_wide(x, w, stats_part=part)
+    assert torch.equal(y, y_plain)
+    yf = y.double()
+    s, q = part[:, 0].sum(0), part[:, 1].sum(0)
+    ref_s, ref_q = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
+    assert torch.isfinite(part).all()
+    assert (s - ref_s).abs().max() <= 1e-5 * yf.abs().sum(dim=(0, 2, 3)).max()         # float32 partial sums inside a tile
+    assert ((q - ref_q).abs() / ref_q).max() <= 1e-5
