@@ -253,11 +253,19 @@ def draw_composite_cutout_batch(B, T, F, gen=None, p: float = 0.5, image_aspect_
     return top, h, left, w, u(B, 8).float()
 
 
+def sample_minmax(x):
+    """(min, max) of every sample of x (B, C, T, F) -- the cutout's fill range -- in ONE pass over x: aminmax along the
+    contiguous frequency rows, then the small (B, C, T) results.  (x.amin(dim=(1, 2, 3)) and x.amax(...) on the time-cropped view
+    of the extractor's output were two passes with 32 outputs each: 0.3 ms apiece of the 12-ms config-4 step.)"""
+    lo, hi = torch.aminmax(x, dim=3)
+    return lo.amin(dim=(1, 2)), hi.amax(dim=(1, 2))
+
+
 def random_composite_cutout(x, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0, n_zero_channels=3):
     """Batched CompositeCutout with torch operators; fill values uniform between the sample's min and max."""
     B, C, T, F = x.shape
     top, h, left, w, u = draw_composite_cutout_batch(B, T, F, gen, p, image_aspect_ratio)
-    lo, hi = x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))
+    lo, hi = sample_minmax(x)
     value = lo[:, None] + (hi - lo)[:, None] * u.to(x.device, x.dtype)
     return fill_rects(x, top, h, left, w, value, n_zero_channels=n_zero_channels)
 
@@ -296,7 +304,7 @@ def draw_augment(B, T, F, audio_format='foa', gen=None, p: float = 0.5, freq_shi
 def apply_augment_torch(x, y_doa, d, audio_format='foa', n_classes: int = 12):
     """The drawn augmentation with torch operators (any device): swap -> shift -> cutout; the cutout's fill range is the
     min / max of the sample BEFORE augmentation.  Returns (x', y_doa')."""
-    lo, hi = x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))
+    lo, hi = sample_minmax(x)
     if audio_format == 'foa':
         xn, yn = swap_channels_foa(x, y_doa, d['m'].to(x.device), n_classes)
     else:
@@ -327,7 +335,7 @@ def apply_augment_hip(x, d, audio_format='foa'):
     # pinned staging: a pageable host-to-device copy would make the host wait for the stream and serialise the step
     par = par.pin_memory().to(x.device, non_blocking=True)
     u = d['u'].float().contiguous().pin_memory().to(x.device, non_blocking=True)
-    minmax = torch.stack([x.amin(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3))], dim=1).contiguous()
+    minmax = torch.stack(sample_minmax(x), dim=1).contiguous()
     out = torch.empty((B, 7, T, F), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().salsa_augment_batch(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), C.c_void_p(out.data_ptr()), B, T, F,

@@ -20,17 +20,33 @@ def main():
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--only-small', action='store_true', help='list only the fills / copies / small elementwise ops')
+    ap.add_argument('--config4', action='store_true', help='on-the-fly SALSA-MIC extraction + device augmentation in front of the step')
     a = ap.parse_args()
     from salsa_amd.crnn.train import Trainer, synthetic_batch
     dev = torch.device('cuda:0')
     tr = Trainer(dev)
     x, sed, doa = synthetic_batch(a.batch, dev, seed=2021)
+    step = lambda: tr.train_step(x, sed, doa)   # noqa: E731
+    if a.config4:
+        import numpy as np
+        from salsa_amd.augment import augment_batch
+        from salsa_amd.extractor import SalsaExtractor
+        from salsa_amd.synth import synth_clip
+        ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
+        ex.set_scaler(torch.full((4, 1, 200), -60.0, device=dev), torch.full((4, 1, 200), 12.0, device=dev))
+        audio = torch.from_numpy(np.stack([synth_clip(4021 + i, 8 * 24000) for i in range(a.batch)])).to(dev)
+        gen = torch.Generator().manual_seed(2021)
+
+        def step():
+            xb = ex.extract(audio)[:, :, :640]
+            xb, sb, db = augment_batch(xb, sed, doa, 'mic', gen=gen)
+            return tr.train_step(xb, sb, db)
     for _ in range(4):
-        tr.train_step(x, sed, doa)
+        step()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         for _ in range(a.steps):
-            tr.train_step(x, sed, doa)
+            step()
         torch.cuda.synchronize()
     agg = collections.defaultdict(lambda: [0, 0.0])
     for ev in prof.events():
