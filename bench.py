@@ -10,7 +10,7 @@ shard across ranks with no collective on the data path (weak scaling: 32 clips p
 (box-to-box and run-to-run spread of a 24-ms region is several percent); every block's time is in `blocks_ms`.
 
 CRNN step (after the feature path, its own timed region) = forward + loss + backward + Adam on 32 chunks (7,640,200) per
-GPU, bf16 autocast, torch DDP over RCCL for N > 1 (bench_crnn.train_bench).
+GPU, bf16 autocast, bucketed gradient all-reduce over RCCL for N > 1 (bench_crnn.train_bench, salsa_amd/crnn/grad_sync.py).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python bench.py --gpus 8            # no launcher needed: re-executes itself under torch.distributed.run, one rank per GPU
@@ -332,7 +332,7 @@ def main():
                                   'note': 'HostPipeline(depth=3): pinned host slot -> device -> features -> pinned host slot, the transfers of neighbouring batches overlapped on separate streams'}
             del pipe
 
-    # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the DDP run)
+    # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the data-parallel run)
     infer_audio = audio if (args.feature == 'salsa' and fmt == 'foa' and args.batch == 32 and abs(args.seconds - 60) < 1e-9) else None
     del ex, out
     if infer_audio is None:

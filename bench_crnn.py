@@ -2,7 +2,7 @@
 """bench_crnn.py -- secondary bench (BASELINE.json config 3/4): SELD CRNN training throughput on N MI355X.
 
 A step = forward + loss + backward + Adam update on a batch of 32 synthetic 8-s SALSA chunks (7,640,200) per GPU, bf16
-autocast, channels-last; data-parallel ranks all-reduce gradients over RCCL (DDP, overlapped with backward).
+autocast, channels-last; data-parallel ranks all-reduce gradients over RCCL (salsa_amd/crnn/grad_sync.py, overlapped with backward).
 --on-the-fly adds the feature extraction in front of every step (config 4: SALSA-MIC from raw 8-s audio on device).
 Prints ONE JSON line on rank 0.  (The headline bench of this repo is bench.py: the feature path.)
 
@@ -115,10 +115,10 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
 def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False,
                 n_frames=640, amp_dtype='default', force_ddp=False):
     """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
-    `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 torch DDP = bucketed gradient all-reduce on RCCL
+    `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 a bucketed gradient all-reduce on RCCL (grad_sync.py; SALSA_GRAD_SYNC=ddp: torch DDP)
     overlapped with the backward.  The process group must already be initialised for world > 1.  Every rank calls this;
     rank 0 gets the result dict, the others None.  `n_frames` / `amp_dtype` / a CPU `dev` exist for the world-size-2 gloo test
-    of this very function (tests/test_crnn_cpu.py): the DDP branch, the barrier / max-over-ranks timing and the result dict are
+    of this very function (tests/test_crnn_cpu.py): the data-parallel branch, the barrier / max-over-ranks timing and the result dict are
     the ones the GPU run uses."""
     import torch
     import torch.distributed as dist
@@ -221,7 +221,7 @@ def main():
     ap.add_argument('--fp32-grads', action='store_true', help='all-reduce fp32 gradients instead of bf16-compressed')
     ap.add_argument('--infer', action='store_true', help='config 5: batched inference, SALSA + CRNN forward on 60-s clips')
     ap.add_argument('--force-ddp', action='store_true',
-                    help='one rank only: wrap the model in DistributedDataParallel over a 1-rank RCCL group anyway (what the N > 1 path '
+                    help='one rank only: run the data-parallel gradient path over a 1-rank RCCL group anyway (what the N > 1 path '
                          'costs BEFORE any communication: hooks, bucket copies, the bf16 compression)')
     ap.add_argument('--clips', type=int, default=32, help='--infer: 60-s clips per GPU per step')
     ap.add_argument('--sub-batch', type=int, default=32,
