@@ -43,12 +43,27 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
+// Addressing of a map in KERNEL coordinates: pixel (n, h, w) lives at element n * sn + h * sh + w * sw.  Normal: sh = W * 64, sw = 64.
+// TRANSPOSED (tap_t = 1): the kernel is handed the map with its axes swapped (its H = the image's width, its W = the image's
+// height, sh = 64, sw = image width * 64) and the filter taps swapped to match (conv(x)^T = conv_{w^T}(x^T)) -- nothing moves in
+// memory.  Why: a tile is 4 rows x 32 columns of kernel pixels (the MFMA's 32 columns), so a 100-column map wastes 28 of every
+// 128 columns and a 200-column one 24 of 224, while the CRNN's heights (640, 320, 4800, 2400) are multiples of 32 and its
+// widths of 4: transposed, every tile is full (320 x 100: 250 tiles per image instead of 320).  A pixel's 64 channels are one
+// contiguous 128-byte line either way.  psn / psh / psw: the same for the 2x2-pooled output of the POOL epilogue.
+struct Geo {
+    long sn;
+    int sh, sw, tap_t;
+    long psn;
+    int psh, psw;
+};
+__device__ __forceinline__ long geo_off(const Geo &g, long n, int h, int w) { return n * g.sn + (long)h * g.sh + (long)w * g.sw; }
+
 // x: [N][H][W][64] bf16, w: [64 co][3][3][64 ci] bf16 (torch's channels-last weight layout), y: [N][H][W][64] bf16.
 // Epilogue of one tile, shared by the two forward kernels: D -> (shift, residual, ReLU) -> bf16 stores, or the pooled variant.
 template <bool POOL>
 __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsigned short *__restrict__ y, const float *__restrict__ shift,
                                                 const float4 (&shv)[4], const unsigned short *__restrict__ residual, int relu, long n,
-                                                int th, int tw, int H, int W, int lane, int px, int mb, int rg)
+                                                int th, int tw, int H, int W, int lane, int px, int mb, int rg, const Geo &geo)
 {
     if (POOL) { // inference, RPW == 2: the 2x2 average pool that follows (stem, model_utils.py:224) taken on the float32 values
         // before the single rounding -- the wave's two rows are the vertical pair, the neighbouring lane the horizontal one;
@@ -64,7 +79,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
             for (int rr = 0; rr < RPW; rr++) {
                 float v4[4] = {acc[rr][4 * g] + sh.x, acc[rr][4 * g + 1] + sh.y, acc[rr][4 * g + 2] + sh.z, acc[rr][4 * g + 3] + sh.w};
                 if (residual) {
-                    const long roff = ((n * H + (inside ? h0 + rr : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
+                    const long roff = geo_off(geo, n, inside ? h0 + rr : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
                     const uint2 rv = *(const uint2 *)(residual + roff + 8 * g);
                     v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
                     v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
@@ -78,7 +93,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
             pk[g].y = pack_bf16(s4[2], s4[3]);
         }
         // 16-byte stores: runs traded with the partner lane (same pixel, lane +- 32), as in the plain epilogue below
-        unsigned short *o = y + ((n * (H / 2) + (inside ? h0 / 2 : 0)) * (W / 2) + (inside ? wcol / 2 : 0)) * CH + 32 * mb + 8 * (lane >> 5);
+        unsigned short *o = y + (n * geo.psn + (long)(inside ? h0 / 2 : 0) * geo.psh + (long)(inside ? wcol / 2 : 0) * geo.psw) + 32 * mb + 8 * (lane >> 5);
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
             const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
@@ -96,7 +111,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
     for (int rr = 0; rr < RPW; rr++) {
         const int h = th * TH + rg * RPW + rr, wcol = tw * TW + px;
         const bool inside = h < H && wcol < W;      // (the same for both lanes of a pair: they share the pixel)
-        const long off = ((n * H + (inside ? h : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 4 * (lane >> 5);
+        const long off = geo_off(geo, n, inside ? h : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -120,7 +135,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
 #if CONV_WIDE_STORE
         // swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B.  With A = run g (even), B = run g + 1: the low lane ends with
         // (own half of run g, partner's half of run g) = channels 8 g .. 8 g + 7, the high lane with the two halves of run g + 1
-        unsigned short *o = y + ((n * H + (inside ? h : 0)) * W + (inside ? wcol : 0)) * CH + 32 * mb + 8 * (lane >> 5);
+        unsigned short *o = y + geo_off(geo, n, inside ? h : 0, inside ? wcol : 0) + 32 * mb + 8 * (lane >> 5);
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
             const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
@@ -326,7 +341,8 @@ __global__ __launch_bounds__(256, CONV_WPS) void conv3x3_c64_fwd_kernel(const un
         // strip to get 16-byte stores of 64 contiguous bytes per pixel was measured SLOWER here, 1.59 -> 2.03 ms per training
         // step, twice: this kernel's epilogue competes with the next tile's MFMAs for LDS and registers.  The stem kernel
         // below, which has next to no MFMA work, does gain from it.)
-        conv64_epilogue<POOL>(acc, y, shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
+        conv64_epilogue<POOL>(acc, y, shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg,
+                              Geo{(long)H * W * CH, W * CH, CH, 0, (long)(H / 2) * (W / 2) * CH, (W / 2) * CH, CH});
     }
 }
 
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
                                                                        unsigned short *__restrict__ y, int N, int H, int W,
                                                                        const float *__restrict__ shift,
                                                                        const unsigned short *__restrict__ residual, int relu,
-                                                                       double *__restrict__ stats_part)
+                                                                       double *__restrict__ stats_part, const Geo geo)
 {
     static_assert(RPW == 2, "row sharing below is written for two rows per wave");
     static_assert(!(POOL && STATS), "statistics are a training feature, the fused pool an inference one");
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
 #pragma unroll
-        for (int kc = 0; kc < 4; kc++) af[tap][kc] = *(const bf16x8 *)(w + ((long)((mb * 32 + px) * 9 + tap) * CH + kc * 16 + kh));
+        for (int kc = 0; kc < 4; kc++) // (transposed geometry: tap (ky, kx) multiplies the filter's (kx, ky))
+            af[tap][kc] = *(const bf16x8 *)(w + ((long)((mb * 32 + px) * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + kc * 16 + kh));
     float4 shv[4]; // the lane's 16 folded-BatchNorm shifts (inference), loaded once: ordinary loads inside the tile loop would
                    // make the compiler drain every load in flight, the next tiles' included
 #pragma unroll
@@ -503,13 +520,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     const int p0 = tid >> 3, hh0 = p0 / HALO_W, ww0 = p0 - hh0 * HALO_W;
     const int blk8 = (((tid & 7) - p0) & 7) * 8; // channel offset of this thread's 16 bytes: slot (block + pixel) & 7
     auto fetch = [&](const Cursor &c, int buf) {
-        const unsigned short *origin = x + (((long)c.n * H + c.th * TH) * W + c.tw * TW) * CH; // pixel (0, 0) of the tile
+        const unsigned short *origin = x + geo_off(geo, c.n, c.th * TH, c.tw * TW); // pixel (0, 0) of the tile
         const int h_lo = -c.th * TH, h_hi = H - c.th * TH, w_lo = -c.tw * TW, w_hi = W - c.tw * TW; // valid (row, col) - origin
         int hh = hh0 - 1, ww = ww0 - 1; // halo pixel relative to the tile origin
 #pragma unroll
         for (int j = 0; j < AFETCH; j++) {
             const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
-            const unsigned short *src = inside ? origin + ((hh * W + ww) * CH + blk8) : (const unsigned short *)&conv_zero16;
+            const unsigned short *src = inside ? origin + (hh * geo.sh + ww * geo.sw + blk8) : (const unsigned short *)&conv_zero16;
             unsigned short *dst = xl + buf * ABUF + (j * 256 + wv * 64) * 8; // the wave's 64 slots (lane l -> + 16 l bytes)
 #ifndef CONV_NO_FETCH
             if (tid + j * 256 < HALO_PIECES)
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #ifdef CONV_NO_EPI // probe: the accumulators are kept alive, nothing is converted or stored
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
 #else
-        conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg);
+        conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg, geo);
         if (STATS) conv64_stats(acc, rs, rq, th, tw, H, W, px, rg);
 #endif
     }
@@ -631,15 +648,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 
 } // namespace
 
+#ifndef C64_TRANSPOSE
+#define C64_TRANSPOSE 1 // hand the 64 -> 64 kernels the map with its axes swapped when that needs >= 5 % fewer tiles (see struct Geo)
+#endif
+#if CONV_ASYNC
+#define C64_GEO_ARG(pl) , (pl).geo
+#else
+#define C64_GEO_ARG(pl)
+#endif
+namespace {
+struct C64Plan {
+    int Hk, Wk; // the map's extent in kernel coordinates
+    long tiles;
+    Geo geo;
+};
+C64Plan c64_plan(int64_t N, int H, int W, int th, int tw)
+{
+    const long tn = (long)N * ((H + th - 1) / th) * ((W + tw - 1) / tw), tt = (long)N * ((W + th - 1) / th) * ((H + tw - 1) / tw);
+    const bool tr = C64_TRANSPOSE && CONV_ASYNC && tt * 100 < tn * 95;
+    C64Plan p;
+    p.Hk = tr ? W : H;
+    p.Wk = tr ? H : W;
+    p.tiles = tr ? tt : tn;
+    p.geo.sn = (long)H * W * CH;
+    p.geo.sh = tr ? CH : W * CH;
+    p.geo.sw = tr ? W * CH : CH;
+    p.geo.tap_t = tr ? 1 : 0;
+    p.geo.psn = (long)(H / 2) * (W / 2) * CH;
+    p.geo.psh = tr ? CH : (W / 2) * CH;
+    p.geo.psw = tr ? (W / 2) * CH : CH;
+    return p;
+}
+} // namespace
+
 extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64_t N, int H, int W, void *hip_stream)
 {
     if (!x || !w || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
-    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const C64Plan pl = c64_plan(N, H, W, TH, TW);
     // persistent workgroups, two resident per CU: 512 or 1024 of them (multiples of 512 measured best), fewer for tiny inputs
-    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
+    const unsigned nb = (unsigned)(pl.tiles >= 16384 ? CONV_BIG_GRID : pl.tiles >= 512 ? 512 : pl.tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
-                       (const unsigned short *)nullptr, 0, (double *)nullptr);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, (const float *)nullptr,
+                       (const unsigned short *)nullptr, 0, (double *)nullptr C64_GEO_ARG(pl));
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -647,7 +697,7 @@ extern "C" int salsa_nn_conv3x3_c64(const void *x, const void *w, void *y, int64
 extern "C" int salsa_nn_conv3x3_c64_stats_blocks(int64_t N, int H, int W)
 {
     if (N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH || !CONV_ASYNC) return 0;
-    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const long tiles = c64_plan(N, H, W, TH, TW).tiles;
     return (int)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
 }
 
@@ -660,9 +710,10 @@ extern "C" int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y,
     if (!x || !w || !y || !stats_part || x == y || !salsa_nn_conv3x3_c64_stats_blocks(N, H, W)) return -1;
     const unsigned nb = (unsigned)salsa_nn_conv3x3_c64_stats_blocks(N, H, W);
 #if CONV_ASYNC
+    const C64Plan pl = c64_plan(N, H, W, TH, TW);
     hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
-                       (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, (const float *)nullptr,
-                       (const unsigned short *)nullptr, 0, stats_part);
+                       (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, (const float *)nullptr,
+                       (const unsigned short *)nullptr, 0, stats_part, pl.geo);
 #endif
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
@@ -672,11 +723,11 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
                                              int relu, int64_t N, int H, int W, void *hip_stream)
 {
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
-    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
+    const C64Plan pl = c64_plan(N, H, W, TH, TW);
+    const unsigned nb = (unsigned)(pl.tiles >= 16384 ? CONV_BIG_GRID : pl.tiles >= 512 ? 512 : pl.tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu,
-                       (double *)nullptr);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift, (const unsigned short *)residual, relu,
+                       (double *)nullptr C64_GEO_ARG(pl));
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -687,11 +738,11 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, 
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || RPW != 2 ||
         N * H * W >= INT32_MAX / CH)
         return -1;
-    const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const unsigned nb = (unsigned)(tiles >= 16384 ? CONV_BIG_GRID : tiles >= 512 ? 512 : tiles);
+    const C64Plan pl = c64_plan(N, H, W, TH, TW);
+    const unsigned nb = (unsigned)(pl.tiles >= 16384 ? CONV_BIG_GRID : pl.tiles >= 512 ? 512 : pl.tiles);
     hipLaunchKernelGGL(CONV_FWD_KERNEL<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)w, (unsigned short *)y, (int)N, H, W, shift, (const unsigned short *)residual, relu,
-                       (double *)nullptr);
+                       (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift, (const unsigned short *)residual, relu,
+                       (double *)nullptr C64_GEO_ARG(pl));
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -955,7 +1006,7 @@ __device__ __forceinline__ void wrw_steps(tr_frag (&fr)[WRW_DEPTH + 1], bf16x8 &
 
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned short *__restrict__ x,
                                                                  const unsigned short *__restrict__ dy,
-                                                                 float *__restrict__ dw, int N, int H, int W)
+                                                                 float *__restrict__ dw, int N, int H, int W, const Geo geo)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xl[WHALO_H * WHALO_W * ROW];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
@@ -990,8 +1041,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
     static_assert(WHALO_W == 34 && WHALO_H * WHALO_W + 31 < 236, "q / 34 == (q * 241) >> 13 holds for q < 236");
     auto fetch = [&](const Cursor &c) { // one tile's x (with halo, zeros outside the image) and dy into registers
         const int h0 = c.th * WT_H, w0 = c.tw * WT_W;
-        const unsigned short *xo = x + (((long)c.n * H + h0 - 1) * W + (w0 - 1)) * CH;   // halo pixel (0, 0); wave-uniform
-        const unsigned short *go = dy + (((long)c.n * H + h0) * W + w0) * CH;
+        const unsigned short *xo = x + geo_off(geo, c.n, h0 - 1, w0 - 1);   // halo pixel (0, 0); wave-uniform
+        const unsigned short *go = dy + geo_off(geo, c.n, h0, w0);
         const int p0 = tid >> 3, piece8 = (tid & 7) * 8;
 #pragma unroll
         for (int j = 0; j < XP; j++) {
@@ -1000,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
             const bool ok = q < WHALO_H * WHALO_W && (unsigned)(h0 - 1 + hh) < (unsigned)H && (unsigned)(w0 - 1 + ww) < (unsigned)W;
             px_[j] = make_uint4(0u, 0u, 0u, 0u);
 #ifndef WRW64_NO_FETCH // (probe builds: WRW64_NO_FETCH / WRW64_NO_LDSWRITE / WRW64_NO_MULT drop one phase each)
-            if (ok) px_[j] = *(const uint4 *)(xo + ((hh * W + ww) * CH + piece8));
+            if (ok) px_[j] = *(const uint4 *)(xo + (hh * geo.sh + ww * geo.sw + piece8));
 #endif
         }
 #pragma unroll
@@ -1008,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
             const int q = p0 + 32 * j, hh = q >> 5, ww = q & 31;
             pg_[j] = make_uint4(0u, 0u, 0u, 0u);
 #ifndef WRW64_NO_FETCH
-            if (h0 + hh < H && w0 + ww < W) pg_[j] = *(const uint4 *)(go + ((hh * W + ww) * CH + piece8));
+            if (h0 + hh < H && w0 + ww < W) pg_[j] = *(const uint4 *)(go + (hh * geo.sh + ww * geo.sw + piece8));
 #endif
         }
     };
@@ -1062,8 +1113,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #ifdef WRW64_NO_ATOMIC // (probe)
             if (acc[tap][reg] == 123.456f)
 #endif
-            atomicAdd(dw + ((long)(co * 9 + tap) * CH + ci), acc[tap][reg]);
-        }
+            atomicAdd(dw + ((long)(co * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + ci), acc[tap][reg]); // (transposed
+        }                                                                                  // geometry: tap (ky, kx) is the filter's (kx, ky))
 }
 
 } // namespace
@@ -1072,12 +1123,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream)
 {
     if (!x || !dy || !dw || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
-    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    const C64Plan pl = c64_plan(N, H, W, WT_H, WT_W);
+    const long tiles = pl.tiles;
     // persistent workgroups, two per CU; fewer when there are few tiles (every workgroup ends with 36 864 float atomics)
     // (mid sizes, 32 x 320 x 100: 256 workgroups 0.158 ms, 384: 0.141, 512: 0.149)
     const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
     hipLaunchKernelGGL(conv3x3_c64_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)dy, dw, (int)N, H, W);
+                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
