@@ -160,8 +160,9 @@ int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void
  * [rows][nc], doa, doa_gt [rows][3 nc] (blocks x | y | z), float32 contiguous.  out3 = {loss, sed loss, doa loss};
  * g_logit = d sed / d logit, g_doa = d doa / d prediction, unweighted.  salsa_nn_seld_loss_bwd scales them by the incoming
  * gradients (device scalars, NULL = 0): out_a = a (g_loss w_sed + g_sed), out_b = b (g_loss w_doa + g_doa). */
+#define SALSA_SELD_LOSS_WS 192 /* float64 values of scratch (partial_ws) salsa_nn_seld_loss needs: 64 workgroups x 3 partial sums */
 int salsa_nn_seld_loss(const float *logit, const float *doa, const float *sed_gt, const float *doa_gt, int64_t rows, int nc,
-                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, void *hip_stream);
+                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, double *partial_ws, void *hip_stream);
 int salsa_nn_seld_loss_bwd(const float *a, int64_t na, const float *b, int64_t nb, const float *g_loss, const float *g_sed,
                            const float *g_doa, float w_sed, float w_doa, float *out_a, float *out_b, void *hip_stream);
 

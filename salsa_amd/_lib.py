@@ -98,7 +98,7 @@ def load():
                                              vp, vp, vp, vp, vp, C.c_int, vp]
     L.salsa_nn_bn_bwd_pool.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.salsa_nn_conv_filter_bank.argtypes = [vp, C.c_int, C.c_int, vp]
-    L.salsa_nn_seld_loss.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp]
+    L.salsa_nn_seld_loss.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, vp, vp, vp, vp, vp]
     L.salsa_nn_seld_loss_bwd.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     L.salsa_nn_freq_mean_fwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.salsa_nn_freq_mean_bwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, vp]

@@ -39,10 +39,11 @@ class _SeldLoss(torch.autograd.Function):
         nc = sed_gt.shape[-1]
         rows = sed_gt.numel() // nc
         out = torch.empty(3, dtype=torch.float32, device=logit.device)
+        ws = torch.empty(192, dtype=torch.float64, device=logit.device)       # include/salsa_nn.h SALSA_SELD_LOSS_WS
         ga, gb = torch.empty_like(logit), torch.empty_like(doa)
         with torch.cuda.device(logit.device):
             rc = _lib.load().salsa_nn_seld_loss(_ptr(logit), _ptr(doa), _ptr(sed_gt), _ptr(doa_gt), rows, nc, w_sed, w_doa, _ptr(out),
-                                                _ptr(ga), _ptr(gb), _stream(logit))
+                                                _ptr(ga), _ptr(gb), _ptr(ws), _stream(logit))
         if rc:
             raise RuntimeError('salsa_nn_seld_loss failed (%d)' % rc)
         ctx.set_materialize_grads(False)          # unused outputs (the two detached parts) arrive as None, not as zero fills

@@ -627,19 +627,21 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------ SELD loss
-// models/interfaces.py:304-355 in one launch: sed = mean BCE-with-logits(logit, sed_gt); doa = sum over the x / y / z blocks of
+// models/interfaces.py:304-355: sed = mean BCE-with-logits(logit, sed_gt); doa = sum over the x / y / z blocks of
 // sum(|p - t| m) / sum(m) with m = sed_gt (the three blocks share sum(m)); loss = w_sed sed + w_doa doa -- and the gradients of
 // sed w.r.t. logit and of doa w.r.t. the predictions (unweighted: the backward launch scales them by what flows in).
-// One workgroup: 4 x rows x nc elements (123 k in the training step), float64 sums, fixed order = deterministic.
-__global__ __launch_bounds__(1024) void seld_loss_kernel(const float *__restrict__ logit, const float *__restrict__ doa,
-                                                         const float *__restrict__ sed_gt, const float *__restrict__ doa_gt,
-                                                         long rows, int nc, float w_sed, float w_doa, float *__restrict__ out3,
-                                                         float *__restrict__ g_logit, float *__restrict__ g_doa)
+// Two launches of SELD_BLOCKS workgroups (a single 1024-thread workgroup took 64 us for the 123 k elements of a training step):
+// partial sums per workgroup in float64, fixed order = deterministic; the second launch adds the partials (every workgroup for
+// itself), writes the three values and the gradients of its slice.
+constexpr int SELD_BLOCKS = 64;
+__global__ __launch_bounds__(256) void seld_loss_partial_kernel(const float *__restrict__ logit, const float *__restrict__ doa,
+                                                                const float *__restrict__ sed_gt, const float *__restrict__ doa_gt,
+                                                                long rows, int nc, double *__restrict__ partial /* [SELD_BLOCKS][3] */)
 {
-    __shared__ double red[3][1024];
+    __shared__ double red[3][256];
     const long n = rows * nc;
     double s_bce = 0.0, s_mask = 0.0, s_abs = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)SELD_BLOCKS * 256) {
         const long r = i / nc;
         const int c = (int)(i - r * nc);
         const float x = logit[i], z = sed_gt[i];
@@ -655,21 +657,38 @@ __global__ __launch_bounds__(1024) void seld_loss_kernel(const float *__restrict
     red[1][threadIdx.x] = s_mask;
     red[2][threadIdx.x] = s_abs;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
             for (int k = 0; k < 3; k++) red[k][threadIdx.x] += red[k][threadIdx.x + s];
         __syncthreads();
     }
-    const float sed = (float)(red[0][0] / (double)n);
-    const float msum = (float)red[1][0];
-    const float d = (float)red[2][0] / msum; // 0 / 0 = nan when no class is active anywhere, as in the reference
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void seld_loss_finish_kernel(const float *__restrict__ logit, const float *__restrict__ doa,
+                                                               const float *__restrict__ sed_gt, const float *__restrict__ doa_gt,
+                                                               long rows, int nc, float w_sed, float w_doa,
+                                                               const double *__restrict__ partial, float *__restrict__ out3,
+                                                               float *__restrict__ g_logit, float *__restrict__ g_doa)
+{
+    __shared__ double tot[3];
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int b = 0; b < SELD_BLOCKS; b++) t += partial[b * 3 + threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const long n = rows * nc;
+    const float sed = (float)(tot[0] / (double)n);
+    const float msum = (float)tot[1];
+    const float d = (float)tot[2] / msum; // 0 / 0 = nan when no class is active anywhere, as in the reference
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         out3[0] = w_sed * sed + w_doa * d;
         out3[1] = sed;
         out3[2] = d;
     }
     const float inv_n = 1.f / (float)n, inv_m = 1.f / msum;
-    for (long i = threadIdx.x; i < n; i += 1024) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)SELD_BLOCKS * 256) {
         const long r = i / nc;
         const int c = (int)(i - r * nc);
         const float x = logit[i], z = sed_gt[i];
@@ -938,13 +957,15 @@ int salsa_nn_conv_filter_bank(const void *desc, int n_layers, int n_blocks, void
 
 /* SELD training loss and its gradients (salsa_amd/crnn/loss.py; reference models/interfaces.py:304-355): logit, sed_gt
  * [rows][nc]; doa, doa_gt [rows][3 nc] float32 contiguous.  out3 = {loss, sed, doa}; g_logit / g_doa = d sed / d logit and
- * d doa / d prediction (unweighted). */
+ * d doa / d prediction (unweighted); partial_ws: SALSA_SELD_LOSS_WS float64 values of scratch. */
 int salsa_nn_seld_loss(const float *logit, const float *doa, const float *sed_gt, const float *doa_gt, int64_t rows, int nc,
-                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, void *hip_stream)
+                       float w_sed, float w_doa, float *out3, float *g_logit, float *g_doa, double *partial_ws, void *hip_stream)
 {
-    if (!logit || !doa || !sed_gt || !doa_gt || !out3 || !g_logit || !g_doa || rows <= 0 || nc <= 0) return -1;
-    hipLaunchKernelGGL(seld_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, logit, doa, sed_gt, doa_gt, (long)rows, nc,
-                       w_sed, w_doa, out3, g_logit, g_doa);
+    if (!logit || !doa || !sed_gt || !doa_gt || !out3 || !g_logit || !g_doa || !partial_ws || rows <= 0 || nc <= 0) return -1;
+    hipLaunchKernelGGL(seld_loss_partial_kernel, dim3(SELD_BLOCKS), dim3(256), 0, (hipStream_t)hip_stream, logit, doa, sed_gt, doa_gt,
+                       (long)rows, nc, partial_ws);
+    hipLaunchKernelGGL(seld_loss_finish_kernel, dim3(SELD_BLOCKS), dim3(256), 0, (hipStream_t)hip_stream, logit, doa, sed_gt, doa_gt,
+                       (long)rows, nc, w_sed, w_doa, partial_ws, out3, g_logit, g_doa);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
