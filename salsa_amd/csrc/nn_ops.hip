@@ -536,17 +536,29 @@ __global__ __launch_bounds__(256) void conv_filter_bank_kernel(const long long *
     const int Cout = (int)d[3], Cin = (int)d[4], taps = (int)d[10], rw = 32 * taps; // taps = 9 or 1
     const long s_co = d[5], s_ci = d[6], s_ky = d[7], s_kx = d[8];
     const int t = (int)(blockIdx.x - d[9]), tiles_ci = Cin / 32, co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
-    for (int e = threadIdx.x; e < 32 * rw; e += 256) { // consecutive threads walk the source's contiguous axis: ci when the
-        // master filter is channels-last (s_ci == 1), the taps when it is torch's default (co, ci, ky, kx)
-        const int co = e / rw, q = e % rw;
-        const int ci = s_ci == 1 ? q % 32 : q / taps, tap = s_ci == 1 ? q / 32 : q % taps;
-        tile[co][ci * taps + tap] = src[(co0 + co) * s_co + (ci0 + ci) * s_ci + (tap / 3) * s_ky + (tap % 3) * s_kx];
+    if (s_ci == 1 && !(s_co & 3) && !(s_ky & 3) && !(s_kx & 3)) { // channels-last master filter (the trainer's): 16-byte loads along ci
+        for (int e = threadIdx.x; e < 8 * rw; e += 256) {
+            const int co = e / (8 * taps), q = e % (8 * taps), ci = (q % 8) * 4, tap = q / 8;
+            const float4 v = *(const float4 *)(src + (co0 + co) * s_co + (ci0 + ci) + (tap / 3) * s_ky + (tap % 3) * s_kx);
+            tile[co][ci * taps + tap] = v.x;
+            tile[co][(ci + 1) * taps + tap] = v.y;
+            tile[co][(ci + 2) * taps + tap] = v.z;
+            tile[co][(ci + 3) * taps + tap] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < 32 * rw; e += 256) { // consecutive threads walk the source's contiguous axis: ci when the
+            // master filter is channels-last (s_ci == 1), the taps when it is torch's default (co, ci, ky, kx)
+            const int co = e / rw, q = e % rw;
+            const int ci = s_ci == 1 ? q % 32 : q / taps, tap = s_ci == 1 ? q / 32 : q % taps;
+            tile[co][ci * taps + tap] = src[(co0 + co) * s_co + (ci0 + ci) * s_ci + (tap / 3) * s_ky + (tap % 3) * s_kx];
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * rw; e += 256) {
-        const int a = e % 32, tap = (e / 32) % taps, b = e / rw;
-        fwd[((long)(co0 + b) * taps + tap) * Cin + ci0 + a] = __float2bfloat16(tile[b][a * taps + tap]);        // (co = b, ci = a)
-        if (bwd) bwd[((long)(ci0 + b) * taps + (taps - 1 - tap)) * Cout + co0 + a] = __float2bfloat16(tile[a][b * taps + tap]); // (ci = b, co = a)
+    for (int e = threadIdx.x; e < 16 * rw; e += 256) { // two neighbouring channels per thread: 4-byte stores, 64-byte runs per 16 lanes
+        const int a = (e % 16) * 2, tap = (e / 16) % taps, b = e / (16 * taps);
+        *(unsigned *)(fwd + ((long)(co0 + b) * taps + tap) * Cin + ci0 + a) = pack_bf16(tile[b][a * taps + tap], tile[b][(a + 1) * taps + tap]); // (co = b, ci = a)
+        if (bwd)
+            *(unsigned *)(bwd + ((long)(ci0 + b) * taps + (taps - 1 - tap)) * Cout + co0 + a) = pack_bf16(tile[a][b * taps + tap], tile[a + 1][b * taps + tap]); // (ci = b, co = a)
     }
 }
 
