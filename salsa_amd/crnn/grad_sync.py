@@ -72,6 +72,16 @@ class BucketedGradSync:
                 for p in b.params:
                     dist.broadcast(p.data, src, group=self.group)
 
+    def begin(self):
+        """Start of a training step: forget whatever an interrupted step (an exception between backward and finish) left behind."""
+        if self._launched or any(b.pending != len(b.params) for b in self.buckets):
+            for b in self._launched:
+                if b.work is not None:
+                    b.work.wait()
+            for b in self.buckets:
+                b.pending, b.work = len(b.params), None
+            self._launched = []
+
     # ---- backward-time half
     def _on_grad(self, p):
         b = self._bucket_of[p]

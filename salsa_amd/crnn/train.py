@@ -93,6 +93,8 @@ class Trainer:
             gparam['lr'] = lr
         x = self._input_layout(x)
         self.opt.zero_grad(set_to_none=True)
+        if self.grad_sync is not None:
+            self.grad_sync.begin()
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             pred = self.model(x)
         loss, sed_l, doa_l = seld_loss(pred, sed, doa)
