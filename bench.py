@@ -76,6 +76,45 @@ def _flush_c_stdio():
         pass
 
 
+
+_TERM_KEEP = []
+
+
+def _arm_termination(callback):
+    """Run `callback` (from a helper thread) as soon as this process receives SIGTERM -- also while the main thread sits in a
+    blocking native call (a collective whose peer died), where a Python signal handler would never get to run: the C-level handler
+    writes the signal number to a wake-up socket at once, and the helper thread is blocked on the other end.  torch.distributed.run
+    sends SIGTERM to the surviving ranks when one rank fails.  Returns a function that disarms."""
+    import signal
+    import socket
+    import threading
+    r, w = socket.socketpair()
+    _TERM_KEEP.append((r, w))      # (the wake-up descriptor must outlive this frame whether or not the caller keeps `disarm`)
+    w.setblocking(False)
+    old_handler = signal.signal(signal.SIGTERM, lambda *_: None)   # (a Python-level handler must exist for the wake-up byte)
+    old_fd = signal.set_wakeup_fd(w.fileno())
+    armed = [True]
+
+    def wait():
+        try:
+            data = r.recv(1)
+        except OSError:
+            return
+        if armed[0] and data:
+            callback()
+
+    threading.Thread(target=wait, daemon=True).start()
+
+    def disarm():
+        armed[0] = False
+        signal.set_wakeup_fd(old_fd)
+        signal.signal(signal.SIGTERM, old_handler if old_handler is not None else signal.SIG_DFL)
+        try:
+            w.close()      # wakes the helper thread (recv returns b'')
+        except OSError:
+            pass
+    return disarm
+
 def _emit(line):
     """print the ONE JSON line as the LAST thing on stdout: RCCL writes a version banner through C stdio, which on a pipe sits
     in libc's buffer until exit and would otherwise land after (and be taken for) the result line"""
@@ -339,17 +378,80 @@ def main():
         del audio
     torch.cuda.empty_cache()
     failures = []
+    done = {}                                    # the CRNN-side legs as they finish (what a bail-out can still report)
+
+    def make_line(cpu_, status=None):
+        audio_s = world * args.batch * args.seconds * args.steps
+        ln = {
+            'metric': 'SALSA feat-extract audio-s/s',
+            'value': round(audio_s / elapsed, 1),
+            'unit': 'audio-seconds/s',
+            'n_gpus': world,
+            'rccl_ranks': rccl_ranks,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'blocks_ms': [round(1e3 * b / args.steps, 4) for b in block_s],
+            'blocks_note': 'ms per step of each timed %d-step block (max over ranks); value / ms_per_step = the median block' % args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'Full SALSA %s (eigenvector path): batch %dx%.0f-s 4-ch 24 kHz clips per GPU, '
+                                   'feature-extract only, n_fft 512 hop 300 fmax_doa %d cond 5 tracking on'
+                                   % (fmt.upper(), args.batch, args.seconds, fmax) if args.feature == 'salsa' else
+                                   '%s MIC: batch %dx%.0f-s clips per GPU' % (args.feature, args.batch, args.seconds),
+                       'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'feature': args.feature,
+                       'format': fmt, 'sharding': 'clips/%d (no collective)' % world,
+                       'clip_groups': args.groups or 'default'},
+            'roofline': roofline,
+            'cpu_baseline': cpu_,
+            'crnn': done.get('crnn'),
+            'config4': done.get('config4'),
+            'inference': done.get('inference'),
+        }
+        if status or failures:
+            ln['status'] = status or 'partial: %s failed' % ', '.join(failures)
+        if pcie:
+            ln['pcie_inclusive'] = pcie
+        if pipelined:
+            ln['pipelined'] = pipelined
+        return ln
+
+    def bail(why):
+        """N > 1 only: a CRNN-side leg failed or hung on some rank.  The feature half of the line is complete by now, so rank 0
+        still prints it (the unfinished legs are null, `status` says why) before the job is torn down with a non-zero exit;
+        torch.distributed.run then ends the other ranks."""
+        if rank == 0:
+            _emit(make_line(None, status='partial: %s (the feature-path half above is complete)' % why))
+        os._exit(3)
+
+    watchdog, disarm_term = None, None
+    if world > 1 and not args.no_crnn and args.feature == 'salsa':
+        import threading
+        limit = float(os.environ.get('SALSA_BENCH_LEG_TIMEOUT', '600'))
+        watchdog = threading.Timer(limit, bail, args=('the CRNN-side legs did not finish within %.0f s at N = %d' % (limit, world),))
+        watchdog.daemon = True
+        watchdog.start()
+        disarm_term = _arm_termination(lambda: bail('terminated by the launcher: another rank failed in a CRNN-side leg'))
 
     def leg(name, fn):
         """One of the CRNN-side legs; a failure is recorded in the line AND makes the process exit non-zero (unless
-        --tolerate-crnn-failure): the CRNN number is half of BASELINE.json's metric."""
+        --tolerate-crnn-failure): the CRNN number is half of BASELINE.json's metric.  At N > 1 the ranks cannot go on after one of
+        them failed (the others sit in a collective): see bail()."""
         try:
-            return fn()
+            if os.environ.get('SALSA_BENCH_FAIL_LEG') == name and rank == world - 1:   # (test hook: tests/test_gpu_configs.py)
+                raise RuntimeError('injected failure')
+            done[name] = fn()
         except Exception as e:
             if world > 1:
-                raise
+                import traceback
+                traceback.print_exc()
+                bail('%s failed on rank %d: %s: %s' % (name, rank, type(e).__name__, e))
             failures.append(name)
-            return {'error': '%s: %s' % (type(e).__name__, e)}
+            done[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        return done[name]
 
     crnn = config4 = infer = None
     if not args.no_crnn and args.feature == 'salsa':
@@ -371,6 +473,9 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
+            disarm_term()
         dist.destroy_process_group()
         _flush_c_stdio()
     if rank != 0:
@@ -380,42 +485,7 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(args.feature, fmt, fmax, n_samples)
 
-    audio_s = world * args.batch * args.seconds * args.steps
-    line = {
-        'metric': 'SALSA feat-extract audio-s/s',
-        'value': round(audio_s / elapsed, 1),
-        'unit': 'audio-seconds/s',
-        'n_gpus': world,
-        'rccl_ranks': rccl_ranks,
-        'steps': args.steps,
-        'warmup': args.warmup,
-        'ms_per_step': round(1e3 * elapsed / args.steps, 4),
-        'blocks_ms': [round(1e3 * b / args.steps, 4) for b in block_s],
-        'blocks_note': 'ms per step of each timed %d-step block (max over ranks); value / ms_per_step = the median block' % args.steps,
-        'higher_is_better': True,
-        'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': 'f64',
-        'data': 'synthetic',
-        'config': {'workload': 'Full SALSA %s (eigenvector path): batch %dx%.0f-s 4-ch 24 kHz clips per GPU, '
-                               'feature-extract only, n_fft 512 hop 300 fmax_doa %d cond 5 tracking on'
-                               % (fmt.upper(), args.batch, args.seconds, fmax) if args.feature == 'salsa' else
-                               '%s MIC: batch %dx%.0f-s clips per GPU' % (args.feature, args.batch, args.seconds),
-                   'clips_per_gpu': args.batch, 'clip_seconds': args.seconds, 'feature': args.feature,
-                   'format': fmt, 'sharding': 'clips/%d (no collective)' % world,
-                   'clip_groups': args.groups or 'default'},
-        'roofline': roofline,
-        'cpu_baseline': cpu,
-        'crnn': crnn,
-        'config4': config4,
-        'inference': infer,
-    }
-    if failures:
-        line['status'] = 'partial: %s failed' % ', '.join(failures)
-    if pcie:
-        line['pcie_inclusive'] = pcie
-    if pipelined:
-        line['pipelined'] = pipelined
+    line = make_line(cpu)
     _emit(line)
     if failures and not args.tolerate_crnn_failure:
         sys.stdout.flush()

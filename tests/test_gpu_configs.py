@@ -374,3 +374,23 @@ def test_sharded_harness_with_two_ranks_on_one_gpu_equals_the_single_process_tre
                 np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-6)        # (float64 partial sums added in another order)
             else:
                 assert np.array_equal(w, v), (rel, k)
+
+
+def test_bench_n2_failure_in_a_crnn_leg_still_prints_the_feature_half():
+    """N = 2 (both ranks on the one GPU): the last rank fails in the `config4` leg while rank 0 waits in that leg's collectives.
+    The job must end non-zero AND rank 0 must still print the line -- feature-path half complete, `crnn` present, `config4`
+    null, `status` saying why -- instead of losing the headline number to a failure on the consumer side."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SALSA_BENCH_SHARE_GPU='1', SALSA_BENCH_FAIL_LEG='config4', SALSA_BENCH_LEG_TIMEOUT='45')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '2', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert lines, r.stderr[-2000:]
+    line = json.loads(lines[-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['roofline']['frac'] > 0
+    assert line['crnn'] is not None and line['crnn']['value'] > 0 and line['config4'] is None
+    assert line['status'].startswith('partial')

@@ -153,3 +153,30 @@ def test_three_instruction_division_by_three_is_ieee():
     for a in vals:
         a = float(a)
         assert div3(a) == a / 3.0, a.hex()
+
+
+def test_bench_termination_hook_fires_while_the_main_thread_is_blocked(tmp_path):
+    """bench._arm_termination: SIGTERM (what torch.distributed.run sends the surviving ranks when one rank fails) must reach the
+    bail-out callback even while the main thread sits in a blocking native wait -- a Python signal handler alone would never
+    run there.  The callback prints the partial line and leaves with exit code 3."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    prog = tmp_path / 'blocked.py'
+    prog.write_text(
+        "import os, sys, threading\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "def cb():\n"
+        "    sys.stdout.write('{\"status\": \"partial\"}\\n'); sys.stdout.flush(); os._exit(3)\n"
+        "bench._arm_termination(cb)\n"
+        "print('armed', flush=True)\n"
+        "threading.Event().wait()\n" % ROOT)
+    p = subprocess.Popen([sys.executable, str(prog)], stdout=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == 'armed'
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=30)
+    assert p.returncode == 3 and out.strip().splitlines()[-1] == '{"status": "partial"}'
