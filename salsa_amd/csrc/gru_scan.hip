@@ -125,6 +125,9 @@ __global__ __launch_bounds__(H) void gru_bwd_kernel(const float *__restrict__ dh
 // training keeps the float32 kernels above.  One barrier per step (h is double-buffered); nothing but the weights lives
 // in registers across steps (biases are re-read with the step's input projections: kept, they were spilled).
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#ifndef GRU_FILL
+#define GRU_FILL 16 // floats per register-fill chunk of the forward scan
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -139,11 +142,26 @@ __global__ __launch_bounds__(1024) void gru_fwd_regw_kernel(const float *__restr
     const int q = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int b = blockIdx.x, d = blockIdx.y;
     half2_t wp[3][KS / 2];
+    // register fill: 192 float32 weights -> 96 packed float16 pairs, in chunks of 16 floats that are converted before the next
+    // chunk's loads go out (all 48 16-byte loads at once need 192 registers next to the 96 being filled: the compiler spilled 84
+    // of them to scratch, ~45 us of a 103-us launch at T = 40)
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         const float *row = whh + ((long)d * 3 * H + g * H + q) * H + part * KS;
 #pragma unroll
-        for (int i = 0; i < KS / 2; i++) wp[g][i] = half2_t{(_Float16)row[2 * i], (_Float16)row[2 * i + 1]};
+        for (int c = 0; c < KS / GRU_FILL; c++) {
+            float4 v[GRU_FILL / 4];
+#pragma unroll
+            for (int u = 0; u < GRU_FILL / 4; u++) v[u] = *(const float4 *)(row + GRU_FILL * c + 4 * u);
+#pragma unroll
+            for (int u = 0; u < GRU_FILL / 4; u++) {
+                half2_t lo = half2_t{(_Float16)v[u].x, (_Float16)v[u].y}, hi = half2_t{(_Float16)v[u].z, (_Float16)v[u].w};
+                asm volatile("" : "+v"(lo), "+v"(hi)); // the conversion happens HERE (left alone the compiler keeps the float32
+                wp[g][(GRU_FILL / 2) * c + 2 * u] = lo; // values alive and converts at first use: every load then waits for itself
+                wp[g][(GRU_FILL / 2) * c + 2 * u + 1] = hi; // and goes to scratch)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (threadIdx.x < H) h[0][threadIdx.x] = (_Float16)0.f;
     float hq = 0.f;
@@ -245,10 +263,14 @@ __global__ __launch_bounds__(1024) void gru_bwd_regw_kernel(const float *__restr
     for (int i = 0; i < RS / 2; i++) {
         const float *w0 = whh + ((long)d * 3 * H + rs * RS + 2 * i) * H + 4 * cg;
         const float4 r0 = *(const float4 *)w0, r1 = *(const float4 *)(w0 + H);
-        wp[0][i] = half2_t{(_Float16)r0.x, (_Float16)r1.x};
-        wp[1][i] = half2_t{(_Float16)r0.y, (_Float16)r1.y};
-        wp[2][i] = half2_t{(_Float16)r0.z, (_Float16)r1.z};
-        wp[3][i] = half2_t{(_Float16)r0.w, (_Float16)r1.w};
+        half2_t c0 = half2_t{(_Float16)r0.x, (_Float16)r1.x}, c1 = half2_t{(_Float16)r0.y, (_Float16)r1.y};
+        half2_t c2 = half2_t{(_Float16)r0.z, (_Float16)r1.z}, c3 = half2_t{(_Float16)r0.w, (_Float16)r1.w};
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)); // convert HERE (see the forward kernel's register fill)
+        wp[0][i] = c0;
+        wp[1][i] = c1;
+        wp[2][i] = c2;
+        wp[3][i] = c3;
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four row pairs (eight 16-byte loads) in flight at a time
     }
     float carry = 0.f;
     for (int s = T - 1; s >= 0; s--) { // reverse of the forward scan order
