@@ -237,15 +237,20 @@ def main():
                 ts.append((time.perf_counter() - t0) / n * 1e3)
             return float(np.median(ts))
 
-        prefix = {}
+        prefix, prefix_note = {}, None
         if args.feature == 'salsa':
-            ex.set_timing(-1)
-            p1 = wall_ms(args.steps)
-            ex.set_timing(-2)
-            p2 = wall_ms(args.steps)
-            ex.set_timing(0)
-            p3 = 1e3 * elapsed / args.steps                    # the whole path: the timed blocks above
+            with ex.issue_prefix(1):                           # (restores plain issue on exit, exceptions included)
+                p1 = wall_ms(args.steps)
+            with ex.issue_prefix(2):
+                p2 = wall_ms(args.steps)
+            p3 = wall_ms(args.steps)                           # the whole path, timed the same way as its prefixes
             prefix = {'stft_logspec': p1, 'noise_floor_tracker': p2 - p1, 'cov_eig': p3 - p2}
+            scale = (1e3 * elapsed / args.steps) / p3          # ... then scaled so the three add up to the headline step
+            prefix = {k: v * scale for k, v in prefix.items()}
+            if min(prefix.values()) <= 0:                      # a noisy box: differences of separately timed loops can cross
+                prefix_note = 'prefix differences not monotone on this run (%s): event-pair times used instead' % \
+                    {k: round(v, 4) for k, v in prefix.items()}
+                prefix = {}
         ex.set_timing(1)
         tot, cnt = {}, {}
         for _ in range(n_t):
@@ -308,6 +313,7 @@ def main():
                     'traffic_source': traffic_src,
                     'kernel_ms_sum': round(sum(t_of(k) for k in kernels), 4),
                     'kernel_ms_sum_event_pairs': round(sum(k['ms_event_pair'] * k['launches_per_step'] for k in kernels), 4),
+                    'kernel_timing_note': prefix_note,
                     'kernel_timing': 'ms_per_launch = prefix differences of the real launch sequence (wall clock over %d issues of [STFT], [STFT, tracker], whole path; they add up to the step); ms_event_pair = HIP event pair around each launch of the plain sequence on the launch stream, %d calls' % (args.steps, n_t),
                     'scope': 'whole step: algorithmic bytes of the path (%d) / median wall time per step' % pipe_bytes,
                     'algorithmic_bytes': pipe_bytes, 'ms': round(step_ms, 4),

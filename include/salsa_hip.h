@@ -54,6 +54,8 @@ enum { SALSA_FLAG_FLEX = 1, SALSA_FLAG_NO_CLIP_FREQS = 2, SALSA_FLAG_CLIP_SPATIA
 
 enum {
     SALSA_OK = 0,
+    SALSA_PARTIAL = 1,     /* measurement mode only (salsa_plan_set_timing(plan, -1 | -2)): a PREFIX of the path was issued, the
+                            * output planes hold whatever an earlier full call left there -- never returned by a plain call */
     SALSA_EINVAL = -1,     /* bad argument (NULL pointer, negative size, ...) */
     SALSA_ENFFT = -2,      /* n_fft not in {256, 512}: the reference's assert, salsa_feature_extraction.py:152,306 */
     SALSA_EFORMAT = -3,    /* unknown audio format: the reference's ValueError, :125,:332 ; lite requires MIC, lite :72 */
@@ -156,6 +158,8 @@ int salsa_augment_batch(const float *d_in, int64_t in_batch_stride, int64_t in_c
  * enable = -1 / -2 (measurement only, no events): salsa_extract_batch issues only a PREFIX of the path -- the STFT launch
  * alone / STFT + tracker -- on the buffers a full call left behind, so a caller can time prefixes of the real launch
  * sequence with its own clock and attribute the step to its kernels by differences that add up to the step exactly.
+ * Such a call returns SALSA_PARTIAL (1), not SALSA_OK: its outputs are incomplete and no caller can mistake it for a plain
+ * call.  The mode persists on the plan until salsa_plan_set_timing(plan, >= 0).
  * salsa_plan_read_timing synchronises on the events and returns the milliseconds per launch of the last call's kernels
  * in issue order (n_out <= SALSA_MAX_KERNELS) and their names. */
 #define SALSA_MAX_KERNELS 32

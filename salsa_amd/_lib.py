@@ -19,6 +19,7 @@ FLAG_FLEX, FLAG_NO_CLIP_FREQS, FLAG_CLIP_SPATIAL_ALIAS = 1, 2, 4
 PIPE_SPLIT_PAIRS, PIPE_GRAPH = 1, 2
 MAX_KERNELS = 32
 
+PARTIAL = 1     # salsa_extract_batch in the prefix-issue measurement mode (include/salsa_hip.h: SALSA_PARTIAL)
 E_INVAL, E_NFFT, E_FORMAT, E_BINS, E_WORKSPACE, E_HIP = -1, -2, -3, -4, -5, -6
 
 

@@ -280,25 +280,39 @@ def freq_mean_sequence(feat):
 
 
 class _GradZeros:
-    """Zero-initialised float32 weight-gradient buffers for the atomically accumulating weight-gradient kernels, ONE allocation
-    and ONE fill per backward pass instead of one ``torch.zeros`` per layer (25 fills of ~4 us in the training step).
+    """Zero-initialised float32 weight-gradient buffers for the accumulating weight-gradient kernels, ONE allocation and ONE fill
+    per backward pass instead of one ``torch.zeros`` per layer (25 fills of ~4 us in the training step).
 
-    A *generation* is one backward pass: the encoder announces it at every training forward (``new_generation``).  The first
-    generation learns the plan -- how many buffers of which shape a pass asks for -- while falling back to ``torch.zeros``; later
-    generations carve every request out of one flat zero tensor allocated at the pass's first request.  A slice is handed out
-    once and never written again by this class (the flat tensor of a generation is dropped, not reused: the gradients that
-    view it keep it alive), so gradient accumulation, retained graphs and ``param.grad`` stealing see ordinary fresh tensors.
-    Requests beyond the plan (a second backward through the same forward, a direct call of an op) fall back to ``torch.zeros``
-    and extend the plan."""
+    A *generation* is one forward/backward pass: the encoder announces it at every forward that can be differentiated
+    (``new_generation``).  The plan -- how many buffers of which shape a pass asks for -- is LEARNED only during a learning
+    generation (the first announced one, and the one after a generation that met a shape the plan has never seen: a second
+    model), while every request falls back to ``torch.zeros``; it is installed when that generation is closed by the next
+    announcement and then frozen.  Later generations carve their requests out of one flat zero tensor allocated at the pass's
+    first request.  A slice is handed out once and never written again by this class (the flat tensor of a generation is
+    dropped, not reused: the gradients that view it keep it alive), so gradient accumulation, retained graphs and
+    ``param.grad`` stealing see ordinary fresh tensors.  Requests beyond the plan -- a second backward through the same forward,
+    a backward that no forward announced (a direct call of an op, a stand-alone fused GRU) -- are served by ``torch.zeros`` and
+    NEVER extend the plan, so the per-pass allocation cannot grow with the number of such passes (round-3 advice: 50 eval-mode
+    backward passes used to reserve 459 MiB for a 9-MiB gradient)."""
 
     def __init__(self):
-        self.plan = {}          # (shape, device) -> buffers per generation
+        self.plan = {}          # (shape, device) -> buffers per generation (frozen outside learning generations)
         self.taken = {}         # this generation's requests so far
         self.offsets = None     # (shape, device, i) -> offset into the flat tensor, floats
         self.total = {}         # device -> floats
         self.flat = {}          # device -> this generation's flat zero tensor
+        self.learning = None    # None: no generation announced yet; True: this generation's counts become the plan; False: frozen
+        self.relearn = False    # an announced generation asked for a shape the plan does not know
 
     def new_generation(self):
+        if self.learning:                                   # close the learning generation: its counts are the plan
+            if self.taken:                                  # (a forward that was never differentiated teaches nothing)
+                self.plan = dict(self.taken)
+                self.offsets = None
+                self.learning = False
+        elif self.learning is None or self.relearn:
+            self.learning = True
+        self.relearn = False
         self.taken = {}
         self.flat = {}
 
@@ -306,9 +320,9 @@ class _GradZeros:
         key = (tuple(shape), device)
         i = self.taken.get(key, 0)
         self.taken[key] = i + 1
-        if i >= self.plan.get(key, 0):
-            self.plan[key] = i + 1
-            self.offsets = None
+        if self.learning is not False or i >= self.plan.get(key, 0):
+            if self.learning is False and key not in self.plan:
+                self.relearn = True
             return torch.zeros(shape, dtype=torch.float32, device=device)
         if self.offsets is None:
             self.offsets, self.total = {}, {}

@@ -61,7 +61,7 @@ class Trainer:
             # DDP wrapper costs this model +0.5 - 1.0 ms per 11-ms step on ONE rank: 143 device copies, one per gradient)
             from .grad_sync import BucketedGradSync
             wire = torch.bfloat16 if (bf16_grad_allreduce and self.device.type == 'cuda') else torch.float32
-            self.grad_sync = BucketedGradSync(list(model.parameters()), bucket_mb=25, wire_dtype=wire)
+            self.grad_sync = BucketedGradSync(list(model.parameters()), bucket_mb=25, wire_dtype=wire, module=model)
             self.grad_sync.broadcast_parameters(0)           # (SALSA_GRAD_SYNC=ddp selects torch's DistributedDataParallel instead)
         elif use_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP

@@ -1571,7 +1571,8 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         int rc = SALSA_OK;
         for (int r = 0; r < reps && !rc; r++) rc = launch_stft(pl, gp, a, o, xs, s1);
         mark_end(pl, s1, m);
-        if (rc || !full || pl->stop_after == 1) return rc;
+        if (rc || !full) return rc;
+        if (pl->stop_after == 1) return SALSA_PARTIAL; // (measurement mode: the caller is told the outputs are NOT complete)
         if (s1 != s2) {
             HIP_TRY(hipEventRecord(after_first, s1));
             HIP_TRY(hipStreamWaitEvent(s2, after_first, 0));
@@ -1596,7 +1597,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
             mark_end(pl, s2, m);
             HIP_TRY(hipGetLastError());
         }
-        if (pl->stop_after == 2) return SALSA_OK;
+        if (pl->stop_after == 2) return SALSA_PARTIAL;
         if (two && s1 != s2) HIP_TRY(hipStreamWaitEvent(s2, after_second, 0));
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);

@@ -2,6 +2,7 @@
 
 torch is plumbing only (device memory, streams): every FLOP of the feature path runs in the hand-written HIP kernels
 of salsa_amd/csrc/salsa_kernels.hip behind the C ABI of include/salsa_hip.h."""
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -76,6 +77,7 @@ class SalsaExtractor:
             self._plan = None
             _raise(rc)
         self._ws = None
+        self._prefix_mode = False
 
     def __del__(self):
         if getattr(self, '_plan', None):
@@ -122,6 +124,8 @@ class SalsaExtractor:
         with torch.cuda.device(self.device):        # the plan's device must be current for the launches
             rc = self.L.salsa_extract_batch(self._plan, C.c_void_p(audio.data_ptr()), B, N, C.c_void_p(out.data_ptr()),
                                             C.c_void_p(ws.data_ptr()), ws.numel(), self._stream())
+        if rc == _lib.PARTIAL and self._prefix_mode:
+            return out                               # inside issue_prefix(): an incomplete issue the caller asked for
         if rc:
             _raise(rc)
         return out
@@ -183,7 +187,24 @@ class SalsaExtractor:
     def set_timing(self, enable):
         """False / 0: off.  True / 1: an event pair around every launch.  K > 1: every kernel of a call is launched K times back
         to back between one event pair and read_timing() reports elapsed / K (no event between launches)."""
+        if int(enable) < 0:
+            raise ValueError('set_timing takes 0, 1 or a repeat count; the prefix-issue measurement mode is issue_prefix()')
         self.L.salsa_plan_set_timing(self._plan, int(enable))
+
+    @contextlib.contextmanager
+    def issue_prefix(self, kernels: int):
+        """MEASUREMENT ONLY.  Inside this context extract() issues only the first ``kernels`` launches of the path (1: the STFT,
+        2: STFT + tracker) on the buffers an earlier full call left behind, so a bench can attribute the step to its kernels by
+        wall-clock differences; the output it returns is NOT a feature array.  The library reports such a call with the distinct
+        code SALSA_PARTIAL, which extract() accepts only here; the plan is put back to plain issue on exit, whatever happens."""
+        assert kernels in (1, 2)
+        self.L.salsa_plan_set_timing(self._plan, -kernels)
+        self._prefix_mode = True
+        try:
+            yield self
+        finally:
+            self._prefix_mode = False
+            self.L.salsa_plan_set_timing(self._plan, 0)
 
     def set_scaler(self, mean=None, std=None):
         """Attach (or detach with None) the feature scaler: extract() then returns the spectrogram channels already

@@ -296,7 +296,8 @@ def test_weight_gradient_buffer_pool_hands_out_fresh_zeros():
     """nn_ops._GradZeros (one allocation + one fill per backward pass for the atomically accumulating weight-gradient kernels):
     the first generation learns the plan through plain torch.zeros; later generations carve the requests out of ONE flat zero
     tensor; a slice is never handed out twice nor re-zeroed (gradient accumulation keeps earlier gradients intact); requests
-    beyond the plan fall back to torch.zeros and extend it."""
+    beyond the plan fall back to torch.zeros and do NOT extend it (round-3 advice: passes outside a generation used to grow the
+    per-pass allocation without bound); a shape the plan has never seen re-opens learning for one generation."""
     from salsa_amd.crnn import nn_ops
     g, dev = nn_ops._GradZeros(), torch.device('cpu')
     g.new_generation()
@@ -314,7 +315,26 @@ def test_weight_gradient_buffer_pool_hands_out_fresh_zeros():
     g.new_generation()
     a3 = g.take((4, 3), dev)
     assert (a3 == 0).all() and (a == 5).all() and a3.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
-    assert all((g.take((4, 3), dev) == 0).all() for _ in range(2))                   # the plan now holds three (4, 3) buffers
+    assert g.plan == {((4, 3), dev): 2, ((2, 2), dev): 1}                            # ... and the plan is what the learning pass saw
+    # backward passes that no forward announced (eval-mode fine-tuning, a stand-alone op): fresh tensors, frozen plan
+    for _ in range(50):
+        for _ in range(3):
+            assert (g.take((4, 3), dev) == 0).all()
+    assert g.plan == {((4, 3), dev): 2, ((2, 2), dev): 1}
+    g.new_generation()
+    a4 = g.take((4, 3), dev)
+    assert a4.untyped_storage().nbytes() == (64 + 64 + 64) * 4                       # still one flat tensor of the planned size
+    # a second model: an unknown shape re-opens learning for the NEXT announced generation only
+    n1 = g.take((7,), dev)
+    assert (n1 == 0).all() and g.relearn
+    g.new_generation()
+    assert g.learning is True
+    l = [g.take((4, 3), dev), g.take((7,), dev)]
+    assert len({t.untyped_storage().data_ptr() for t in l}) == 2
+    g.new_generation()
+    assert g.learning is False and g.plan == {((4, 3), dev): 1, ((7,), dev): 1}
+    p, q = g.take((4, 3), dev), g.take((7,), dev)
+    assert p.untyped_storage().data_ptr() == q.untyped_storage().data_ptr()
 
 
 def test_batched_heads_equal_the_four_separate_heads():
@@ -393,3 +413,78 @@ def test_bucketed_grad_sync_matches_torch_ddp(tmp_path):
         assert torch.equal(s0[mode], s1[mode]), mode
     diff = (s0['buckets'] - s0['ddp']).abs().max()
     assert diff <= 1e-5, float(diff)
+
+
+def _sync_contract_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import torch.nn as nn
+    from salsa_amd.crnn.grad_sync import BucketedGradSync
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(6, 5), nn.BatchNorm1d(5), nn.Linear(5, 4), nn.Linear(4, 3))
+    if rank == 1:                                                                  # replicas that do NOT start identical
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+            net[1].running_mean.add_(3.0)
+    sync = BucketedGradSync(list(net.parameters()), bucket_mb=4e-5, module=net)    # ~40-byte buckets: several of them
+    assert len(sync.buckets) >= 3
+    sync.broadcast_parameters(0)
+    flat = torch.cat([p.detach().flatten() for p in net.parameters()] + [net[1].running_mean])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])                                           # parameters AND buffers follow rank 0
+    g = torch.Generator().manual_seed(10 + rank)
+    xa, xb = torch.randn(8, 6, generator=g), torch.randn(8, 6, generator=g)
+    # (1) accumulation: micro-batch a under no_sync(), micro-batch b outside -> the average over ranks of (grad_a + grad_b)
+    net.zero_grad(set_to_none=True)
+    sync.begin()
+    with sync.no_sync():
+        net(xa).square().mean().backward()
+    net(xb).square().mean().backward()
+    sync.finish()
+    got = torch.cat([p.grad.flatten() for p in net.parameters()])
+    net.zero_grad(set_to_none=True)
+    with sync.no_sync():
+        net(xa).square().mean().backward()
+        net(xb).square().mean().backward()
+    local = torch.cat([p.grad.flatten() for p in net.parameters()])
+    dist.all_reduce(local)
+    assert torch.allclose(got, local / world, rtol=1e-5, atol=1e-7)
+    # (2) a second synchronised backward before finish() is an error, not a silently dropped gradient
+    net.zero_grad(set_to_none=True)
+    sync.begin()
+    net(xa).square().mean().backward()
+    raised = False
+    try:
+        net(xb).square().mean().backward()
+    except RuntimeError as e:
+        raised = 'no_sync' in str(e)
+    assert raised
+    sync.finish()                                                                  # (the first backward's collectives complete)
+    # (3) collectives go out in BUCKET order whatever order the gradients arrive in
+    net.zero_grad(set_to_none=True)
+    sync.begin()
+    order = []
+    real_launch = sync._launch
+    sync._launch = lambda b: (order.append(sync.buckets.index(b)), real_launch(b))[1]
+    loss = net(xa).square().mean()
+    grads = torch.autograd.grad(loss, list(net.parameters()))
+    for p, gr in (list(zip(net.parameters(), grads))[::-1] if rank == 0 else list(zip(net.parameters(), grads))):
+        p.grad = gr
+        sync._on_grad(p)                                                           # rank 0 and rank 1 see OPPOSITE arrival orders
+    sync.finish()
+    assert order == sorted(order) and len(order) == len(sync.buckets)
+    sync.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_sync_contract_accumulation_order_and_buffers():
+    """grad_sync.BucketedGradSync on a two-rank gloo job: broadcast_parameters carries parameters and BatchNorm buffers;
+    gradient accumulation through no_sync() reduces the accumulated sums; a second synchronised backward before finish()
+    raises; buckets launch in bucket order on every rank even when gradients arrive in opposite orders (round-3 advice)."""
+    port = _free_port()
+    mp.spawn(_sync_contract_worker, args=(2, port, ''), nprocs=2, join=True)
