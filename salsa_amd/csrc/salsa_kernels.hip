@@ -624,8 +624,18 @@ constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins
 // FAST (round 3; tracking on, compile-time window): the work-list loop compiles ONLY the gate and the column-0 eigenvector
 // (salsa_math.h, PATH 1); a gated bin whose column-0 pivot is too small (u_0 ~ 0: rare) is pushed onto a second LDS list and
 // solved after the loop by the general arg-max path (PATH 2), one frame at a time.
-template <bool FEAT, int NHOP, bool FAST = false>
-__global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+//
+// PK (round 4; FEAT + FAST, FOA / MIC, cond > 1): the two frames of a work item are solved TOGETHER as one packed-float32 pair
+// (salsa_math.h: herm4_gate_eigvec_pk -- every v_pk_*_f32 does useful work in both halves), on covariances accumulated in float32
+// in the (re, im) packing the spectra are loaded in (cov4pk_rank1: 16 packed FMAs per frame against 40 float64 instructions).
+// A frame whose gate margin, pivot or feature conditioning is inside the float32 error bound comes back `unsure` and joins the
+// float64 cold list, which recomputes its covariance in float64 from the spill (~1 % of the gated frames of the bench clips:
+// tools/pk_study.py), so every gate decision the packed solve keeps equals the float64 one.
+#ifndef SALSA_PK
+#define SALSA_PK 1
+#endif
+template <bool FEAT, int NHOP, bool FAST = false, bool PK = false>
+__global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned *__restrict__ valid32,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
@@ -805,6 +815,52 @@ __global__ __launch_bounds__(256) void cov_eig_kernel(const KParams kp, const fl
                                            {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
                 salsa::herm4_rank1_add(A, x);
             };
+            if constexpr (PK) {
+                static_assert(!PK || (G == 2 && FEAT && FAST), "the packed solve takes the two frames of a pair");
+                // float32 all the way: the (re, im)-packed covariance of the six shared frames, one more frame for each window
+                // (both windows, also when only one frame is gated in: the other half of every packed instruction is free),
+                // transposed into the frame-pair packing, solved as a pair
+                auto chans = [&](int k, salsa::pk2f *v) {
+                    v[0] = salsa::pk2f{xa[k].x, xa[k].y};
+                    v[1] = salsa::pk2f{xa[k].z, xa[k].w};
+                    v[2] = salsa::pk2f{xc[k].x, xc[k].y};
+                    v[3] = salsa::pk2f{xc[k].z, xc[k].w};
+                };
+                salsa::cov4pk Cc = {}, C0, C1;
+                salsa::pk2f v[4];
+#pragma unroll
+                for (int k = 1; k <= 2 * NHOP; k++) {
+                    chans(k, v);
+                    salsa::cov4pk_rank1(Cc, Cc, v);
+                }
+                chans(0, v);
+                salsa::cov4pk_rank1(C0, Cc, v);
+                chans(2 * NHOP + 1, v);
+                salsa::cov4pk_rank1(C1, Cc, v);
+                const int live = (i >> 12) & 3;
+                int odd;
+                const salsa::herm4<salsa::pk2f> A = salsa::herm4_pk_from_windows(C0, C1, odd);
+                salsa::pk2f e[3];
+                salsa::pk_eig r;
+                if (kp.format == SALSA_FORMAT_FOA) {
+                    r = salsa::herm4_gate_eigvec_pk<false>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
+                    if (r.pass) salsa::normalise_foa_pk(r, e);
+                } else {
+                    r = salsa::herm4_gate_eigvec_pk<true>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
+                    if (r.pass) salsa::normalise_mic_pk(r, (float)(kp.delta * (double)(bin + kp.lower)), e);
+                }
+                r.unsure |= odd & live;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    if ((r.unsure >> j) & 1) // float64 decides: the cold loop below
+                        slow[atomicAdd(&nslow, 1)] = (unsigned short)(((t + j - t0) << 8) | (bin - bin0));
+                    else if ((r.pass >> j) & 1) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) otile[(q * K3_FT + (t + j - t0)) * K3_OW + (bin - bin0)] = e[q][j];
+                    }
+                }
+                continue;
+            }
             salsa::herm4<double> Rc = {}; // the frames every window of the group contains
 #pragma unroll
             for (int k = G - 1; k <= 2 * NHOP; k++) frame(k, Rc);
@@ -876,7 +932,10 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
     const bool gated = kp.tracking || kp.flex; // (!ungated: the coherence test decides, so passing bins have a spectral gap)
-    if (kp.n_hop == 3 && gated && SALSA_COL0)
+    // (the packed pair solve: feature output only -- salsa_eigvec_batch keeps float64 results -- and never for contrib's variant)
+    if (FEAT && SALSA_PK && K3_GROUP == 2 && kp.n_hop == 3 && gated && SALSA_COL0 && !kp.flex && kp.cond > 1.0 && kp.cond < 1e6)
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true, FEAT && K3_GROUP == 2>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+    else if (kp.n_hop == 3 && gated && SALSA_COL0)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else if (kp.n_hop == 3)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);

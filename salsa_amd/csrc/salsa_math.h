@@ -517,6 +517,265 @@ template <typename T> SALSA_HD void normalise_mic(const cplx<T> *u, T dk, T *e)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Packed-float32 pair solve (round 4).  A K3 work item is TWO neighbouring frames of one TF bin, i.e. two independent 4 x 4
+// problems per lane.  pk2f holds one float32 of each (.x = frame t, .y = frame t + 1), so every arithmetic instruction below is
+// a v_pk_{mul,add,fma}_f32 doing useful work in BOTH halves (gfx950 issues a packed float32 VALU instruction in the slot of one
+// float64 or one scalar float32 instruction: this is the only float32 form that is faster than float64 there).  The covariance
+// is still accumulated in float64 (products of float32 spectra are exact there), scaled by an exact power of two to a trace in
+// [1, 2) and rounded ONCE to float32; the quartic, Newton, Budan-Fourier gate and column-0 adjugate then run as the float64
+// code above does, on pairs.  What float32 cannot decide or deliver is handed back, per frame, in `unsure`:
+//   * the gate, when a Taylor coefficient of q at mu1/cond that the sign-variation count depends on lies within
+//     SALSA_PK_GATE_TOL of zero (coefficient errors are <= ~3e-6 on the trace-1..2 scale);
+//   * the eigenvector, when the real pivot adj_00 = prod(mu_i - mu1) |u_0|^2 is below SALSA_PK_PIVOT_MIN (the column's relative
+//     error grows as 1 / |adj_00|), and -- in the normalisations below -- when the feature itself is ill-conditioned.
+// Those frames go to the kernel's float64 cold list; everything certified here agrees with the float64 gate bit for bit and
+// with its features to well inside the test bar (tests/test_kernel_math_hostemu.py::test_packed_float32_pair_solve_*).
+typedef float pk2f __attribute__((vector_size(8)));
+SALSA_HD pk2f pk_splat(float a)
+{
+    pk2f r = {a, a};
+    return r;
+}
+SALSA_HD float approx_rcpf(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+SALSA_HD float approx_rsqrtf(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+#ifndef SALSA_PK_GATE_TOL
+#define SALSA_PK_GATE_TOL 2e-5f
+#endif
+#ifndef SALSA_PK_NEWTON
+#define SALSA_PK_NEWTON 5        // packed Newton iterations (the last one's step certifies convergence)
+#endif
+#ifndef SALSA_PK_PIVOT_MIN
+#define SALSA_PK_PIVOT_MIN 1e-2f
+#endif
+#ifndef SALSA_PK_FOA_MIN
+#define SALSA_PK_FOA_MIN 1e-2f   // FOA: ||Re(column 0)[1:4]||^2 below this -> float64
+#endif
+#ifndef SALSA_PK_MIC_MIN
+#define SALSA_PK_MIC_MIN 1e-3f   // MIC: |column 0 entry|^2 below this -> float64 (the angle's error grows as 1 / |entry|)
+#endif
+
+struct pk_eig {
+    int pass;          // bit j: frame j passed the coherence test (certified) and its column is in ur / ui
+    int unsure;        // bit j: frame j must be solved again in float64
+    pk2f p00;          // real pivot adj_00
+    pk2f ur[3], ui[3]; // column 0 of adj(A - mu1 I), entries 1..3 (ui only when WANT_IMAG)
+};
+
+// Float32 covariance of ONE window in the (re, im) packing the spectra are loaded in: dsq[i] accumulates (re_i^2, im_i^2),
+// o[k] the complex entry (i, j), i < j, as (re, im).  x_i conj(x_j) = (xi.re xj.re + xi.im xj.im, xi.im xj.re - xi.re xj.im) is
+// two packed FMAs: splat(xi.re) * (xj.re, -xj.im) + splat(xi.im) * (xj.im, xj.re) -- the splat, the swap and the negation are
+// operand modifiers (op_sel / neg_hi) of v_pk_fma_f32, so a frame costs 16 instructions where the float64 form costs 40.
+struct cov4pk {
+    pk2f dsq[4], o[6];
+};
+// out = in + v v^H (v[i] = (re, im) of channel i); out may alias in
+SALSA_HD void cov4pk_rank1(cov4pk &out, const cov4pk &in, const pk2f *v)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) out.dsq[i] = in.dsq[i] + v[i] * v[i];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++, k++) {
+            const pk2f bn = {v[j][0], -v[j][1]}, bs = {v[j][1], v[j][0]};
+            out.o[k] = (in.o[k] + pk_splat(v[i][0]) * bn) + pk_splat(v[i][1]) * bs;
+        }
+}
+// 2^(-floor(log2 x)) for a normal positive float; `bad` set when x is zero / subnormal / huge / not finite
+SALSA_HD float pow2_unscalef(float x, bool &bad)
+{
+    const uint32_t e = (__builtin_bit_cast(uint32_t, x) >> 23) & 0xffu;
+    bad = bad || e < 2u || e > 252u;
+    return __builtin_bit_cast(float, (uint32_t)(254u - e) << 23);
+}
+// The two windows' covariances -> the frame-pair packing of the solver (.x = window 0, .y = window 1), each scaled by an exact
+// power of two to a trace in [1, 2).  Bit j of `odd` is set when window j's trace cannot be scaled in float32.
+SALSA_HD herm4<pk2f> herm4_pk_from_windows(const cov4pk &R0, const cov4pk &R1, int &odd)
+{
+    herm4<pk2f> A;
+#pragma unroll
+    for (int i = 0; i < 4; i++) A.d[i] = pk2f{R0.dsq[i][0] + R0.dsq[i][1], R1.dsq[i][0] + R1.dsq[i][1]};
+    const pk2f tr = (A.d[0] + A.d[1]) + (A.d[2] + A.d[3]);
+    bool bad0 = false, bad1 = false;
+    const pk2f sc = {pow2_unscalef(tr[0], bad0), pow2_unscalef(tr[1], bad1)};
+    odd = (bad0 ? 1 : 0) | (bad1 ? 2 : 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) A.d[i] = A.d[i] * sc;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        A.o[k].re = pk2f{R0.o[k][0], R1.o[k][0]} * sc;
+        A.o[k].im = pk2f{R0.o[k][1], R1.o[k][1]} * sc;
+    }
+    return A;
+}
+
+// Gate + column-0 eigenvector of two Hermitian PSD matrices whose traces were scaled into [1, 2).  `live`: bit j = frame j is
+// wanted (the other lane may hold anything, NaN included: it is carried along and ignored).  cond > 1.
+template <bool WANT_IMAG>
+SALSA_HD pk_eig herm4_gate_eigvec_pk(const herm4<pk2f> &A, float cond, float inv_cond, int live)
+{
+    pk_eig res;
+    res.pass = 0;
+    res.unsure = 0;
+    res.p00 = pk_splat(0.f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) res.ur[i] = res.ui[i] = pk_splat(0.f);
+    pk2f nrm = A.o[0].re * A.o[0].re + A.o[0].im * A.o[0].im;
+#pragma unroll
+    for (int k = 1; k < 6; k++) nrm = nrm + (A.o[k].re * A.o[k].re + A.o[k].im * A.o[k].im);
+    const pk2f e1 = (A.d[0] + A.d[1]) + (A.d[2] + A.d[3]);
+    const pk2f e2 = A.d[0] * A.d[1] + A.d[0] * A.d[2] + A.d[0] * A.d[3] + A.d[1] * A.d[2] + A.d[1] * A.d[3] + A.d[2] * A.d[3] - nrm;
+    const pk2f p2 = e1 * e1 - 2.f * e2; // tr(A^2)
+    // certain fail (see the float64 code): tr(A^2) >= (cond^2 + 3) / (cond + 3)^2 tr(A)^2 is necessary for passing; the float32
+    // p2 carries ~5e-7 relative error, hence the 1e-5 slack.  A NaN lane fails here too.
+    const float bound = (cond * cond + 3.f) / ((cond + 3.f) * (cond + 3.f)) * (1.f - 1e-5f);
+    const pk2f need = bound * e1 * e1;
+    int act = live;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        if (!(p2[j] >= need[j])) act &= ~(1 << j);
+    if (!act) return res;
+    const minors4<pk2f> m = herm4_minors(A);
+    pk2f dg[4];
+    herm4_adj_diag(A, m, dg);
+    const pk2f e3 = (dg[0] + dg[1]) + (dg[2] + dg[3]);
+    const pk2f e4 = m.s0 * m.c5 - re_mul(m.s1, m.c4) + re_mul(m.s2, m.c3) + re_mul(m.s3, m.c2) - re_mul(m.s4, m.c1) + re_mul(m.s5, m.c0);
+    const pk2f a3 = -e1, a2 = e2, a1 = -e3, a0 = e4;
+    // Newton from just above sqrt(tr A^2) >= mu1, a FIXED number of packed iterations with no per-lane control: from above the
+    // iterates descend monotonically onto mu1 (every one is an upper bound of it); a gated bin (mu2 < mu1 / cond) starts within
+    // 6 % of mu1 and is at float32 accuracy after three steps.  The last evaluation's step is the convergence certificate.
+    pk2f x;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        float x0 = p2[j] * approx_rsqrtf(p2[j]) * (1.f + 1.f / 65536.f); // (the seed and p2 are good to ~1e-6)
+        if (!(x0 < e1[j])) x0 = e1[j];
+        x[j] = x0;
+    }
+    const pk2f k3 = 3.f * a3, k2 = 2.f * a2;
+    pk2f last = pk_splat(0.f);
+#pragma unroll
+    for (int it = 0; it < SALSA_PK_NEWTON; it++) {
+        const pk2f q = (((x + a3) * x + a2) * x + a1) * x + a0;
+        const pk2f dq = ((4.f * x + k3) * x + k2) * x + a1;
+        const pk2f r = {approx_rcpf(dq[0]), approx_rcpf(dq[1])};
+        last = q * r;
+        x = x - last;
+    }
+    const pk2f mu1 = x;
+    const pk2f c = mu1 * inv_cond;
+    const pk2f t0 = (((c + a3) * c + a2) * c + a1) * c + a0;
+    const pk2f t1 = ((4.f * c + k3) * c + k2) * c + a1;
+    const pk2f t2 = (6.f * c + k3) * c + a2;
+    const pk2f t3 = 4.f * c + a3;
+    int pass = 0, unsure = 0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (!((act >> j) & 1)) continue;
+        const float tol = SALSA_PK_GATE_TOL;
+        // q(c) > 0 for certain: an even number of roots above c, and mu1 is one of them -> at least two -> fails.  (Holds for an
+        // unconverged x too: x >= mu1 puts c at or above the true threshold, which can only hide roots, not add them.)
+        if (t0[j] >= tol) continue;
+        const bool sure = fabsf(t0[j]) >= tol && fabsf(t1[j]) >= tol && fabsf(t2[j]) >= tol && fabsf(t3[j]) >= tol;
+        int var = (t3[j] < 0.f);                  // against the leading 1
+        var += (t2[j] < 0.f) != (t3[j] < 0.f);
+        var += (t1[j] < 0.f) != (t2[j] < 0.f);
+        var += (t0[j] < 0.f) != (t1[j] < 0.f);
+        if (sure && var >= 2) continue;           // three roots above an upper bound of the threshold: fails, converged or not
+        const bool conv = fabsf(last[j]) <= 4e-6f * mu1[j]; // (false for NaN)
+        if (!sure || !conv || !(mu1[j] > 0.f)) {
+            unsure |= 1 << j;
+            continue;
+        }
+        if (var == 1) pass |= 1 << j;
+    }
+    res.unsure = unsure;
+    if (!pass) return res;
+    // column 0 of adj(A - mu1 I), as in the float64 fast path
+    const pk2f b1 = A.d[1] - mu1, b2 = A.d[2] - mu1, b3 = A.d[3] - mu1;
+    const cplx<pk2f> a01 = A.o[0], a02 = A.o[1], a03 = A.o[2], a12 = A.o[3], a13 = A.o[4], a23 = A.o[5];
+    const pk2f c5 = b2 * b3 - (a23.re * a23.re + a23.im * a23.im);
+    const cplx<pk2f> c4 = {m.c4.re - mu1 * a12.re, m.c4.im + mu1 * a12.im};
+    const cplx<pk2f> c3 = {m.c3.re + mu1 * a13.re, m.c3.im - mu1 * a13.im};
+    const pk2f p00 = b1 * c5 - re_mul(a12, c4) + re_mul(a13, c3);
+    const cplx<pk2f> s3 = {m.s3.re + mu1 * a02.re, m.s3.im + mu1 * a02.im};
+    const cplx<pk2f> s4 = {m.s4.re + mu1 * a03.re, m.s4.im + mu1 * a03.im};
+    const cplx<pk2f> s5 = m.s5;
+    res.p00 = p00;
+    res.ur[0] = re_mul(a02, c4) - c5 * a01.re - re_mul(a03, c3);
+    res.ur[1] = re_mul(cconj(a13), s5) - re_mul(cconj(a23), s4) + b3 * s3.re;
+    res.ur[2] = b2 * s4.re - re_mul(cconj(a12), s5) - re_mul(a23, s3);
+    if (WANT_IMAG) {
+        res.ui[0] = -((a02.re * c4.im + a02.im * c4.re) - c5 * a01.im - (a03.re * c3.im + a03.im * c3.re));
+        res.ui[1] = -((a13.re * s5.im - a13.im * s5.re) - (a23.re * s4.im - a23.im * s4.re) + b3 * s3.im);
+        res.ui[2] = -(b2 * s4.im - (a12.re * s5.im - a12.im * s5.re) - (a23.re * s3.im + a23.im * s3.re));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+        if (((pass >> j) & 1) && !(fabsf(p00[j]) >= SALSA_PK_PIVOT_MIN)) {
+            pass &= ~(1 << j);
+            res.unsure |= 1 << j;
+        }
+    res.pass = pass;
+    return res;
+}
+
+// FOA feature of both frames from the packed column: e = sign(adj_00) Re(u[1:4]) / ||Re(u[1:4])|| (normalise_foa_col0).
+// Frames whose ||.||^2 is below SALSA_PK_FOA_MIN are moved from `pass` to `unsure`.
+SALSA_HD void normalise_foa_pk(pk_eig &r, pk2f *e)
+{
+    const pk2f ss = r.ur[0] * r.ur[0] + r.ur[1] * r.ur[1] + r.ur[2] * r.ur[2];
+    pk2f inv;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        if (((r.pass >> j) & 1) && !(ss[j] >= SALSA_PK_FOA_MIN)) {
+            r.pass &= ~(1 << j);
+            r.unsure |= 1 << j;
+        }
+        float y = approx_rsqrtf(ss[j]);
+        y = y * (1.5f - 0.5f * ss[j] * y * y); // one Newton step: the hardware seed is good to ~1 ulp already
+        inv[j] = r.p00[j] < 0.f ? -y : y;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = r.ur[i] * inv;
+}
+
+// MIC feature of both frames: angle(sign(adj_00) u_i) / dk (normalise_mic_col0), float32 atan2.
+SALSA_HD void normalise_mic_pk(pk_eig &r, float dk, pk2f *e)
+{
+    const float idk = 1.0f / dk;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float sg = r.p00[j] < 0.f ? -1.f : 1.f;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float re = r.ur[i][j], im = r.ui[i][j];
+            ok = ok && (re * re + im * im >= SALSA_PK_MIC_MIN);
+            e[i][j] = atan2f(sg * im, sg * re) * idk;
+        }
+        if (((r.pass >> j) & 1) && !ok) {
+            r.pass &= ~(1 << j);
+            r.unsure |= 1 << j;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Stockham autosort FFT addressing, radix R, N points, N/R threads per transform.  Pass with sub-transform length p
 // (p = 1, R, R^2, ... < N), thread i in [0, N/R), k = i & (p-1):
 //   reads   x[i + r*(N/R)]                      r = 0..R-1

@@ -166,3 +166,68 @@ int hostemu_feature(const double *d, const double *o, double cond, int gated, in
     return 0;
 }
 }
+
+extern "C" {
+// Round 4: the packed-float32 pair solve (herm4_gate_eigvec_pk) beside the float64 solve on the SAME float64 covariances, as
+// the kernel forms them: item i = 8 consecutive frames x 4 channels of complex64 spectra of one bin; frame windows 0..6 and
+// 1..7 are the pair.  format 0 = FOA, 1 = MIC (dk = delta * k).  Outputs per (item, frame j): rank64 (float64 gate),
+// margin64 (q(mu1 / cond) on the trace-1..2 scale), e64[3]; pass32 / unsure32 flags and e32[3] of the packed solve.
+int hostemu_pk_pairs(const float *X, long n, double cond, int format, double dk, int cov32, unsigned char *rank64,
+                     double *margin64, double *e64, unsigned char *pass32, unsigned char *unsure32, float *e32)
+{
+    for (long i = 0; i < n; i++) {
+        const float *x = X + i * 8 * 4 * 2;
+        auto frame = [&](int k, herm4<double> &A) {
+            cplx<double> v[4];
+            for (int c = 0; c < 4; c++) v[c] = {(double)x[(k * 4 + c) * 2], (double)x[(k * 4 + c) * 2 + 1]};
+            herm4_rank1_add(A, v);
+        };
+        herm4<double> Rc = {};
+        for (int k = 1; k <= 6; k++) frame(k, Rc);
+        herm4<double> R[2] = {Rc, Rc};
+        frame(0, R[0]);
+        frame(7, R[1]);
+        herm4<pk2f> A;
+        for (int j = 0; j < 2; j++) {
+            eig_result<double> er = herm4_gate_eigvec<0>(R[j], cond, 1.0 / cond, false, format != 0);
+            rank64[2 * i + j] = er.rank1;
+            margin64[2 * i + j] = er.margin;
+            double e[3] = {0, 0, 0};
+            if (er.rank1) {
+                if (er.col0) { if (format == 0) normalise_foa_col0(er.u, e); else normalise_mic_col0(er.u, dk, e); }
+                else if (format == 0) normalise_foa(er.u, e, false);
+                else normalise_mic(er.u, dk, e);
+            }
+            for (int c = 0; c < 3; c++) e64[(2 * i + j) * 3 + c] = e[c];
+            const double tr = R[j].d[0] + R[j].d[1] + R[j].d[2] + R[j].d[3];
+            const float sc = (float)pow2_unscale(tr); // (the kernel: convert, then scale by the power of two in float32)
+            for (int c = 0; c < 4; c++) A.d[c][j] = (float)R[j].d[c] * sc;
+            for (int k = 0; k < 6; k++) { A.o[k].re[j] = (float)R[j].o[k].re * sc; A.o[k].im[j] = (float)R[j].o[k].im * sc; }
+        }
+        int odd = 0;
+        if (cov32) { // the kernel's float32 covariance: (re, im)-packed accumulation, shared frames first, then one more each
+            auto fr = [&](int k, pk2f *v) { for (int c = 0; c < 4; c++) v[c] = pk2f{x[(k * 4 + c) * 2], x[(k * 4 + c) * 2 + 1]}; };
+            cov4pk Cc = {}, C0, C1;
+            pk2f v[4];
+            for (int k = 1; k <= 6; k++) { fr(k, v); cov4pk_rank1(Cc, Cc, v); }
+            fr(0, v); cov4pk_rank1(C0, Cc, v);
+            fr(7, v); cov4pk_rank1(C1, Cc, v);
+            A = herm4_pk_from_windows(C0, C1, odd);
+        }
+        pk_eig r = format ? herm4_gate_eigvec_pk<true>(A, (float)cond, (float)(1.0 / cond), 3 & ~odd)
+                          : herm4_gate_eigvec_pk<false>(A, (float)cond, (float)(1.0 / cond), 3 & ~odd);
+        r.unsure |= odd;
+        pk2f e[3] = {pk_splat(0.f), pk_splat(0.f), pk_splat(0.f)};
+        if (r.pass) {
+            if (format == 0) normalise_foa_pk(r, e);
+            else normalise_mic_pk(r, (float)dk, e);
+        }
+        for (int j = 0; j < 2; j++) {
+            pass32[2 * i + j] = (r.pass >> j) & 1;
+            unsure32[2 * i + j] = (r.unsure >> j) & 1;
+            for (int c = 0; c < 3; c++) e32[(2 * i + j) * 3 + c] = ((r.pass >> j) & 1) ? e[c][j] : 0.f;
+        }
+    }
+    return 0;
+}
+}

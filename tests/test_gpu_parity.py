@@ -576,8 +576,8 @@ def test_contrib_multichannel_batch_against_oracle(dev, oracle, n_ch):
 
 def test_timing_modes_leave_results_untouched(dev):
     """The measurement knobs of salsa_plan_set_timing (include/salsa_hip.h): an event pair per launch (1), K launches of every
-    kernel between one event pair (K > 1), and the plain issue of a PREFIX of the path (-1: STFT alone, -2: STFT + tracker) that
-    bench.py uses to attribute the step to its kernels.  Every kernel is idempotent on (audio, spill, masks), so the output of
+    kernel between one event pair (K > 1), and the plain issue of a PREFIX of the path (STFT alone, STFT + tracker; Python:
+    ``issue_prefix``, the library answers SALSA_PARTIAL) that bench.py uses to attribute the step to its kernels.  Every kernel is idempotent on (audio, spill, masks), so the output of
     any of them -- on buffers a full call left behind -- must be the plain call's bit for bit, and the timing modes must report
     one positive duration per kernel."""
     ys = np.stack([synth_clip(300 + i, 4 * 24000) for i in range(3)])
@@ -597,12 +597,20 @@ def test_timing_modes_leave_results_untouched(dev):
     spatial = out[:, 4:].clone()
     out[:, 4:] = 7.0                             # poison the channels the skipped kernel would have written
     out[:, :4] = 0.0
-    for mode in (-1, -2):
-        ex.set_timing(mode)
-        ex.extract(a, out=out)
-        torch.cuda.synchronize()
-        assert torch.equal(out[:, :4], ref[:, :4])                         # the STFT launch ran and rewrote the spectrograms
-        assert bool((out[:, 4:] == 7.0).all())                             # ... and the covariance kernel did not
-    ex.set_timing(0)
+    with pytest.raises(ValueError):
+        ex.set_timing(-1)                        # the prefix mode is not reachable through the timing switch any more
+    for kernels in (1, 2):
+        with ex.issue_prefix(kernels):
+            ex.extract(a, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(out[:, :4], ref[:, :4])                     # the STFT launch ran and rewrote the spectrograms
+            assert bool((out[:, 4:] == 7.0).all())                         # ... and the covariance kernel did not
+        # outside the context the plan is back to plain issue, and the library's PARTIAL code is never swallowed there
+    from salsa_amd import _lib
+    ex.L.salsa_plan_set_timing(ex._plan, -1)     # (raw ABI: what a careless caller could do)
+    with pytest.raises(RuntimeError):
+        ex.extract(a, out=out)                   # SALSA_PARTIAL (1) is not SALSA_OK: extract() refuses the incomplete result
+    assert _lib.PARTIAL == 1
+    ex.L.salsa_plan_set_timing(ex._plan, 0)
     ex.extract(a, out=out)
     assert torch.equal(out, ref) and torch.equal(out[:, 4:], spatial)
