@@ -634,8 +634,11 @@ constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins
 #ifndef SALSA_PK
 #define SALSA_PK 1
 #endif
+#ifndef K3_PK_WAVES
+#define K3_PK_WAVES 4 // waves per SIMD the register allocation is held to (4: 128 VGPRs, 3: 168)
+#endif
 template <bool FEAT, int NHOP, bool FAST = false, bool PK = false>
-__global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+__global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned *__restrict__ valid32,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
@@ -646,6 +649,10 @@ __global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams 
     __shared__ unsigned short list[K3_FT * 256];
     __shared__ unsigned short slow[FAST ? K3_FT * 256 : 1]; // (frame in tile) << 8 | bin in block
     __shared__ int count, nslow;
+    // byte offsets (into the clip's spill) of frames t0 - NHOP .. t0 + K3_FT - 1 + NHOP with np.pad's 'wrap' on the time axis
+    // (:43) applied, computed once per workgroup: done per lane and per frame in the work-list loop, the wrap compiled to an
+    // integer-division sequence plus a loop, ~40 instructions x 8 frames per item -- a quarter of the loop's issue slots
+    __shared__ __attribute__((aligned(16))) unsigned rowoff[NHOP >= 0 ? K3_FT + 2 * NHOP + 2 : 2];
     // FEAT: the tile's channels 4-6 are assembled in LDS (zeros + the gated bins' results) and written out as whole rows with
     // 16-byte stores at the end, instead of one 4-byte store per lane per (channel, frame) for the zeros plus three scattered
     // 4-byte stores per result
@@ -668,6 +675,12 @@ __global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams 
     const int bin0 = blockIdx.z * 256;
     const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
     if (tid == 0) count = 0, nslow = 0;
+    if (NHOP >= 0 && tid < K3_FT + 2 * NHOP) {
+        int tt = t0 - NHOP + tid;
+        while (tt < 0) tt += Tn;
+        while (tt >= Tn) tt -= Tn;
+        rowoff[tid] = (unsigned)tt * (16u * 2u * (unsigned)kp.nd);
+    }
     if (FEAT) {
         for (int i = tid; i < 3 * K3_FT * K3_OW / 4; i += 256) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -789,7 +802,71 @@ __global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams 
     };
     using hot_path = std::integral_constant<int, FAST ? 1 : 2>;
     using cold_path = std::integral_constant<int, 2>;
-    for (int s = tid; s < n; s += 256) {
+    if constexpr (PK) {
+        static_assert(!PK || (G == 2 && FEAT && FAST && NHOP >= 0), "the packed solve takes the two frames of a pair");
+        // Float32 all the way.  (Tried and dropped: issuing the NEXT item's sixteen gathers between this item's covariance and
+        // its solve.  The solve needs ~130 registers by itself, so the prefetched 64 push the loop to 195 VGPRs -- 2 waves per
+        // SIMD -- or, held to 128 / 168, into scratch: 0.50 - 0.88 ms against 0.38, profiles/r4_k3_pk_ab.txt.)
+        constexpr int NW = 2 * NHOP + 2;
+        const unsigned half = 16u * (unsigned)kp.nd;
+        for (int s = tid; s < n; s += 256) {
+            const int i = list[s];
+            const int ft = 2 * ((i >> 8) & 15), bl = i & 255; // entry = validity of the pair's frames << 12 | pair << 8 | bin
+            float4 xa[NW], xc[NW];
+            {
+                const unsigned *ro = rowoff + ft; // frames t - NHOP .. t + 1 + NHOP (np.pad(..., 'wrap') on the time axis, :43)
+                const unsigned boff = 16u * (unsigned)(bin0 + bl);
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    const unsigned r = ro[k];
+                    xa[k] = ld_off(xclip, r + boff);
+                    xc[k] = ld_off(xclip, r + boff + half);
+                }
+            }
+            auto chans = [&](int k, salsa::pk2f *v) {
+                v[0] = salsa::pk2f{xa[k].x, xa[k].y};
+                v[1] = salsa::pk2f{xa[k].z, xa[k].w};
+                v[2] = salsa::pk2f{xc[k].x, xc[k].y};
+                v[3] = salsa::pk2f{xc[k].z, xc[k].w};
+            };
+            // the (re, im)-packed covariance of the six shared frames, one more frame for each window (both windows, also when
+            // only one frame is gated in: the other half of every packed instruction is free)
+            salsa::cov4pk Cc = {}, C0, C1;
+            salsa::pk2f v[4];
+#pragma unroll
+            for (int k = 1; k <= 2 * NHOP; k++) {
+                chans(k, v);
+                salsa::cov4pk_rank1(Cc, Cc, v);
+            }
+            chans(0, v);
+            salsa::cov4pk_rank1(C0, Cc, v);
+            chans(2 * NHOP + 1, v);
+            salsa::cov4pk_rank1(C1, Cc, v);
+            const int live = (i >> 12) & 3;
+            int odd;
+            const salsa::herm4<salsa::pk2f> A = salsa::herm4_pk_from_windows(C0, C1, odd);
+            salsa::pk2f e[3];
+            salsa::pk_eig r;
+            if (kp.format == SALSA_FORMAT_FOA) {
+                r = salsa::herm4_gate_eigvec_pk<false>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
+                if (r.pass) salsa::normalise_foa_pk(r, e);
+            } else {
+                r = salsa::herm4_gate_eigvec_pk<true>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
+                if (r.pass) salsa::normalise_mic_pk(r, (float)(kp.delta * (double)(bin0 + bl + kp.lower)), e);
+            }
+            r.unsure |= odd & live;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if ((r.unsure >> j) & 1) // float64 decides: the cold loop below
+                    slow[atomicAdd(&nslow, 1)] = (unsigned short)(((ft + j) << 8) | bl);
+                else if ((r.pass >> j) & 1) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) otile[(q * K3_FT + ft + j) * K3_OW + bl] = e[q][j];
+                }
+            }
+        }
+    }
+    for (int s = tid; !PK && s < n; s += 256) {
         const int i = list[s];
         const int t = t0 + G * ((i >> 8) & 15); // entry = validity of the group's frames << 12 | group << 8 | bin
         const int bin = bin0 + (i & 255);
@@ -802,65 +879,18 @@ __global__ __launch_bounds__(256, PK ? 4 : 1) void cov_eig_kernel(const KParams 
             // slower: their latency is what this kernel hides.
             constexpr int NW = NHOP >= 0 ? 2 * NHOP + G : G;
             float4 xa[NW], xc[NW];
+            const unsigned *ro = rowoff + (t - t0); // frames t - NHOP .. (np.pad(..., 'wrap') on the time axis, :43: the table)
 #pragma unroll
             for (int k = 0; k < NW; k++) {
-                int tt = t + k - NHOP; // np.pad(..., 'wrap') on the time axis (:43)
-                while (tt < 0) tt += Tn;
-                while (tt >= Tn) tt -= Tn;
-                xa[k] = ld_off(xclip, (unsigned)tt * row + boff);
-                xc[k] = ld_off(xclip, (unsigned)tt * row + boff + half);
+                const unsigned r = ro[k];
+                xa[k] = ld_off(xclip, r + boff);
+                xc[k] = ld_off(xclip, r + boff + half);
             }
             auto frame = [&](int k, salsa::herm4<double> &A) {
                 const cplx<double> x[4] = {{(double)xa[k].x, (double)xa[k].y}, {(double)xa[k].z, (double)xa[k].w},
                                            {(double)xc[k].x, (double)xc[k].y}, {(double)xc[k].z, (double)xc[k].w}};
                 salsa::herm4_rank1_add(A, x);
             };
-            if constexpr (PK) {
-                static_assert(!PK || (G == 2 && FEAT && FAST), "the packed solve takes the two frames of a pair");
-                // float32 all the way: the (re, im)-packed covariance of the six shared frames, one more frame for each window
-                // (both windows, also when only one frame is gated in: the other half of every packed instruction is free),
-                // transposed into the frame-pair packing, solved as a pair
-                auto chans = [&](int k, salsa::pk2f *v) {
-                    v[0] = salsa::pk2f{xa[k].x, xa[k].y};
-                    v[1] = salsa::pk2f{xa[k].z, xa[k].w};
-                    v[2] = salsa::pk2f{xc[k].x, xc[k].y};
-                    v[3] = salsa::pk2f{xc[k].z, xc[k].w};
-                };
-                salsa::cov4pk Cc = {}, C0, C1;
-                salsa::pk2f v[4];
-#pragma unroll
-                for (int k = 1; k <= 2 * NHOP; k++) {
-                    chans(k, v);
-                    salsa::cov4pk_rank1(Cc, Cc, v);
-                }
-                chans(0, v);
-                salsa::cov4pk_rank1(C0, Cc, v);
-                chans(2 * NHOP + 1, v);
-                salsa::cov4pk_rank1(C1, Cc, v);
-                const int live = (i >> 12) & 3;
-                int odd;
-                const salsa::herm4<salsa::pk2f> A = salsa::herm4_pk_from_windows(C0, C1, odd);
-                salsa::pk2f e[3];
-                salsa::pk_eig r;
-                if (kp.format == SALSA_FORMAT_FOA) {
-                    r = salsa::herm4_gate_eigvec_pk<false>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
-                    if (r.pass) salsa::normalise_foa_pk(r, e);
-                } else {
-                    r = salsa::herm4_gate_eigvec_pk<true>(A, (float)kp.cond, (float)kp.inv_cond, live & ~odd);
-                    if (r.pass) salsa::normalise_mic_pk(r, (float)(kp.delta * (double)(bin + kp.lower)), e);
-                }
-                r.unsure |= odd & live;
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if ((r.unsure >> j) & 1) // float64 decides: the cold loop below
-                        slow[atomicAdd(&nslow, 1)] = (unsigned short)(((t + j - t0) << 8) | (bin - bin0));
-                    else if ((r.pass >> j) & 1) {
-#pragma unroll
-                        for (int q = 0; q < 3; q++) otile[(q * K3_FT + (t + j - t0)) * K3_OW + (bin - bin0)] = e[q][j];
-                    }
-                }
-                continue;
-            }
             salsa::herm4<double> Rc = {}; // the frames every window of the group contains
 #pragma unroll
             for (int k = G - 1; k <= 2 * NHOP; k++) frame(k, Rc);

@@ -273,3 +273,55 @@ def test_float32_solve_error_study(emu):
             worst = max(worst, float(np.max(np.abs(e32 - e64) / (1e-6 + 1e-5 * np.abs(e64)))))
     assert n > 400 and flips == 0
     assert worst < 0.5, worst                       # observed 0.03 - 0.05 of the bar
+
+
+def _pk_pairs(emu, X, cond, fmt, dk, cov32=1):
+    X = np.ascontiguousarray(X.astype(np.complex64))
+    n = X.shape[0]
+    o = dict(rank64=np.zeros(2 * n, np.uint8), margin=np.zeros(2 * n), e64=np.zeros((2 * n, 3)),
+             pass32=np.zeros(2 * n, np.uint8), unsure=np.zeros(2 * n, np.uint8), e32=np.zeros((2 * n, 3), np.float32))
+    emu.hostemu_pk_pairs.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 6
+    emu.hostemu_pk_pairs(X.ctypes.data, n, cond, fmt, dk, cov32, o['rank64'].ctypes.data, o['margin'].ctypes.data,
+                         o['e64'].ctypes.data, o['pass32'].ctypes.data, o['unsure'].ctypes.data, o['e32'].ctypes.data)
+    return o
+
+
+@pytest.mark.parametrize('fmt', ['foa', 'mic'])
+def test_packed_float32_pair_solve_is_certified(emu, fmt):
+    """Round 4's K3 hot loop (salsa_math.h: cov4pk_rank1 + herm4_pk_from_windows + herm4_gate_eigvec_pk + normalise_*_pk): the
+    two frames of a work item solved as one packed-float32 pair on float32 covariances.  Against the float64 solve of the same
+    windows: every frame the packed solve does NOT hand back (`unsure`) has the float64 gate decision, bit for bit, and its
+    feature within a fraction of the test bar (1e-6 + 1e-5 |ref|); what it hands back is a small part of the realistic windows.
+    Windows: a synthetic spectrogram block (directional events + noise: tracker-gated or not, all solved) and random steering
+    windows over 7 decades of level, with small |u_0| mixed in.  (The numbers at scale: tools/pk_study.py.)"""
+    code, dk = (0, 1.0) if fmt == 'foa' else (1, 0.858673 * 9)
+    S = synth_stft_block(77, 96, 400)                                   # (bins, frames, 4)
+    idx = (np.arange(0, 400, 2)[:, None] + np.arange(-3, 5)[None, :]) % 400
+    real = S[:, idx, :].reshape(-1, 8, 4)
+    rng = np.random.RandomState(5)
+    n = 40000
+    X = (rng.randn(n, 8, 4) + 1j * rng.randn(n, 8, 4)) * rng.uniform(0.02, 0.6, (n, 1, 1))
+    steer = rng.uniform(-1, 1, (n, 4)) * np.exp(1j * rng.uniform(-np.pi, np.pi, (n, 4)))
+    steer[:, 0] = rng.choice([1.0, 1.0, 0.3, 0.05, 1e-3], n)
+    X = X + (rng.randn(n, 8, 1) + 1j * rng.randn(n, 8, 1)) * 10 ** rng.uniform(-1, 1, (n, 1, 1)) * steer[:, None, :]
+    X = X * 10 ** rng.uniform(-4, 3, (n, 1, 1))
+    for name, W in (('block', real), ('random', X)):
+        o = _pk_pairs(emu, W, 5.0, code, dk)
+        cert = o['unsure'] == 0
+        r64, p32 = o['rank64'].astype(bool), o['pass32'].astype(bool)
+        assert r64.sum() > 2000, name
+        assert not (cert & (r64 != p32)).any(), name                    # no certified gate decision differs from float64's
+        both = cert & r64
+        ref, got = o['e64'][both], o['e32'][both].astype(np.float64)
+        err = np.abs(got - ref) / (1e-6 + 1e-5 * np.abs(ref))
+        assert np.isfinite(got).all() and err.max() < 0.5, (name, float(err.max()))      # observed <= 0.13
+        if name == 'block':
+            assert (~cert & r64).sum() < 0.05 * r64.sum(), name          # ~1 % of the gated frames go back to float64
+    # degenerate inputs never come back certified-and-wrong: silence, a non-finite sample, a huge level
+    Z = np.zeros((4, 8, 4), np.complex64)
+    Z[1, 3, 2] = np.nan
+    Z[2] = 1e25 * (1 + 1j)
+    Z[3] = 1e-30 * (1 + 1j)
+    o = _pk_pairs(emu, Z, 5.0, code, dk)
+    assert not (o['pass32'].astype(bool) & ~o['rank64'].astype(bool)).any()
+    assert o['unsure'][2:].all() or not o['pass32'][2:].any()
