@@ -113,12 +113,34 @@ __global__ __launch_bounds__(256) void avgpool2x2_bwd_kernel(const char *__restr
 #ifndef BN_RPT
 #define BN_RPT 32
 #endif
-constexpr int BN_ROWS_PER_THREAD = BN_RPT;
+constexpr int BN_ROWS_PER_THREAD = BN_RPT; // rows per thread of the reduction kernels on LARGE maps (bn_rpt below picks fewer on small ones)
 #ifndef BN_BATCH_N
 #define BN_BATCH_N 4
 #endif
 constexpr int BN_BATCH = BN_BATCH_N; // rows whose loads are in flight together in the reduction kernels
 static_assert(BN_RPT % BN_BATCH_N == 0, "row batches");
+// Rows per thread, by map size (round 4 experiment, OFF).  With the fixed 32 (reductions) / 16 (element-wise passes) rows per
+// thread the 33-MB and 16-MB maps of stages 3 / 4 are cut into 120 - 500 workgroups, and r3_bn_network_probe.txt shows 35 us forward /
+// 63 us backward per BatchNorm there "whatever the size".  Fewer rows per thread on small maps (~1000 / ~2000 workgroups) did NOT
+// help: forward unchanged, backward 0.063 -> 0.142 ms at 40 x 12 x 512 and 0.068 -> 0.183 at 80 x 25 x 256 (eight times the partial
+// rows for the finalize kernels and a block-reduction tree per 4 rows instead of per 32), step 10.78 -> 10.75 ms = noise
+// (profiles/r4_bn_adaptive_rows.txt).  The fixed cost of those passes is not their parallelism.
+#ifndef BN_ADAPTIVE_ROWS
+#define BN_ADAPTIVE_ROWS 0
+#endif
+__host__ __device__ inline int bn_rpt(long M, int rpi)
+{
+    int r = BN_ROWS_PER_THREAD;
+    while (BN_ADAPTIVE_ROWS && r > BN_BATCH && (M + (long)rpi * r - 1) / ((long)rpi * r) < 1024) r >>= 1;
+    return r;
+}
+constexpr int BN_APPLY_ROWS_MAX = 16;
+__host__ __device__ inline int bn_apply_rows(long M, int rpi)
+{
+    int r = BN_APPLY_ROWS_MAX;
+    while (BN_ADAPTIVE_ROWS && r > 2 && (M + (long)rpi * r - 1) / ((long)rpi * r) < 2048) r >>= 1;
+    return r;
+}
 
 template <int L, typename A = float>
 __device__ __forceinline__ void bn_block_reduce(A (&a)[L], A (&b)[L], A *red /*[2L][256]*/, int cv, A *part_a, A *part_b, int c0)
@@ -186,7 +208,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
     __shared__ double red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
-    const long chunk = (long)rpi * BN_ROWS_PER_THREAD;
+    const int rpt = bn_rpt(M, rpi);
+    const long chunk = (long)rpi * rpt;
     double s[L], ss[L];
 #pragma unroll
     for (int k = 0; k < L; k++) s[k] = ss[k] = 0.0;
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const char *__restrict__ 
         // BN_BATCH rows' loads are issued together, with no branch between them (a row past the end re-reads the last row
         // and is weighted 0): row-at-a-time code with its bounds test waited for every load before issuing the next
 #pragma unroll 1
-        for (int it0 = 0; it0 < BN_ROWS_PER_THREAD; it0 += BN_BATCH) {
+        for (int it0 = 0; it0 < rpt; it0 += BN_BATCH) {
             float v[BN_BATCH][L], wgt[BN_BATCH];
 #pragma unroll
             for (int u = 0; u < BN_BATCH; u++) {
@@ -275,7 +298,6 @@ template <int L> __device__ inline void drop_keep(long first_elem, DropArgs d, b
     }
 }
 
-constexpr int BN_APPLY_ROWS = 16;
 template <typename V, int L>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ x, char *__restrict__ y,
                                                        const char *__restrict__ residual, long M, int C,
@@ -293,9 +315,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
         ga[k] = gamma[cx * L + k];
         be[k] = beta[cx * L + k];
     }
-    const long row0 = (long)blockIdx.x * rpi * BN_APPLY_ROWS;
+    const int nrows = bn_apply_rows(M, rpi);
+    const long row0 = (long)blockIdx.x * rpi * nrows;
 #pragma unroll 4
-    for (int it = 0; it < BN_APPLY_ROWS; it++) {
+    for (int it = 0; it < nrows; it++) {
         const long r = row0 + (long)it * rpi + ry;
         if (r >= M) break;
         const long off = (r * cv + cx) * 16;
@@ -391,7 +414,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
     __shared__ float red[256 * 2 * L];
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
-    const long chunk = (long)rpi * BN_ROWS_PER_THREAD;
+    const int rpt = bn_rpt(M, rpi);
+    const long chunk = (long)rpi * rpt;
     float db[L], dg[L], mu[L], is[L], ga[L], be[L];
 #pragma unroll
     for (int k = 0; k < L; k++) {
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
     }
     for (long row0 = (long)blockIdx.x * chunk; row0 < M; row0 += (long)gridDim.x * chunk) {
 #pragma unroll 1
-        for (int it0 = 0; it0 < BN_ROWS_PER_THREAD; it0 += BN_BATCH) {
+        for (int it0 = 0; it0 < rpt; it0 += BN_BATCH) {
             float g[BN_BATCH][L], xv[BN_BATCH][L], yv[BN_BATCH][L];
             long vec[BN_BATCH];
             bool ok[BN_BATCH];
@@ -487,9 +511,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         be[k] = coef[5 * C + c];
         ga[k] = coef[6 * C + c];
     }
-    const long row0 = (long)blockIdx.x * rpi * BN_APPLY_ROWS;
+    const int nrows = bn_apply_rows(M, rpi);
+    const long row0 = (long)blockIdx.x * rpi * nrows;
 #pragma unroll 2
-    for (int it = 0; it < BN_APPLY_ROWS; it++) {
+    for (int it = 0; it < nrows; it++) {
         const long r = row0 + (long)it * rpi + ry;
         if (r >= M) break;
         const long off = (r * cv + cx) * 16;
@@ -775,13 +800,14 @@ constexpr unsigned BN_MAX_REDUCE_BLOCKS = BN_MAX_BLOCKS; // 4 per CU; a block ta
 static unsigned bn_reduce_blocks(int dtype, int64_t M, int C)
 {
     const int rpi = 256 / (C / (dtype == 1 ? 8 : 4));
-    const long per = (long)rpi * BN_ROWS_PER_THREAD;
+    const long per = (long)rpi * bn_rpt(M, rpi);
     const long n = (M + per - 1) / per;
     return (unsigned)(n < BN_MAX_REDUCE_BLOCKS ? n : BN_MAX_REDUCE_BLOCKS);
 }
 static unsigned bn_apply_blocks(int dtype, int64_t M, int C)
 {
-    const long per = (long)(256 / (C / (dtype == 1 ? 8 : 4))) * BN_APPLY_ROWS;
+    const int rpi = 256 / (C / (dtype == 1 ? 8 : 4));
+    const long per = (long)rpi * bn_apply_rows(M, rpi);
     return (unsigned)((M + per - 1) / per);
 }
 #define NN_LAUNCH(KERNEL, grid, block, ...)                                                               \

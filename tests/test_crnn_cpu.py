@@ -35,6 +35,39 @@ def test_forward_matches_reference_model():
     assert out['event_frame_logit'].shape == (2, 8, 12)              # 64 frames -> /16 -> x2 (label rate)
 
 
+def test_training_step_matches_reference_modules():
+    """TRAINING semantics pinned to the reference (fixture g16, tools/make_golden_crnn.py: the reference encoder + decoder in
+    train() mode -- batch-statistic BatchNorm, residual blocks of models/model_utils.py:345-367 -- the reference's own
+    compute_classwise_clareg_loss / compute_masked_reg_loss of models/interfaces.py:304-355, backward; dropout off): our model,
+    filled with the same seeded weights, fed the same seeded batch, must give the same three loss values, the same gradients on
+    seven named parameters, leave the same BatchNorm running statistics -- and a FRESH model must zero-initialise exactly the
+    parameters the reference zero-initialises (zero_init_residual)."""
+    from salsa_amd.crnn import SeldCRNN
+    from salsa_amd.crnn.loss import seld_loss
+    from salsa_amd.crnn.testing import dropout_off, g16_batch, seeded_fill
+    meta, a = load_golden('g16_crnn_train')
+    fresh = SeldCRNN()
+    zero = sorted(k for k, v in fresh.state_dict().items() if k.startswith('encoder.') and v.dtype.is_floating_point and v.numel() > 1
+                  and not k.endswith(('running_mean', 'bias')) and float(v.abs().max()) == 0.0)   # (the fixture scans the encoder)
+    assert zero == sorted(meta['zero_init']) and len(zero) == 8
+    m = SeldCRNN()
+    seeded_fill(m, meta['weight_seed'])
+    m.train()
+    x, sed, doa = g16_batch(meta)
+    with dropout_off(m):
+        loss, sed_l, doa_l = seld_loss(m(x), sed, doa)
+        loss.backward()
+    np.testing.assert_allclose([float(loss), float(sed_l), float(doa_l)], a['loss'], rtol=2e-5)
+    params = dict(m.named_parameters())
+    for k, st in meta['grad_strides'].items():
+        got = params[k].grad.reshape(-1)[::st].numpy()
+        ref = a['grad:' + k]
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, (k, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
+    sd = m.state_dict()
+    for k in (x_[5:] for x_ in a.keys() if x_.startswith('stat:')):
+        np.testing.assert_allclose(sd[k].numpy(), a['stat:' + k], rtol=2e-5, atol=1e-6, err_msg=k)
+
+
 def test_reference_checkpoint_round_trip():
     """Weights under the REFERENCE's key names (fixture g14: the reference SeldModel's own state-dict keys and shapes) load
     into SeldCRNN through the product loader -- as the whole Lightning-style checkpoint dict the reference reads at

@@ -959,3 +959,61 @@ def test_wide_conv_statistics_epilogue_matches_sums_of_its_output(shape):
     assert torch.isfinite(part).all()
     assert (s - ref_s).abs().max() <= 1e-5 * yf.abs().sum(dim=(0, 2, 3)).max()         # float32 partial sums inside a tile
     assert ((q - ref_q).abs() / ref_q).max() <= 1e-5
+
+
+def test_gpu_training_step_matches_reference_modules():
+    """Fixture g16 (the REFERENCE encoder + decoder in train() mode, the reference loss, backward; tools/make_golden_crnn.py) on
+    the product path: Trainer's bf16-autocast, channels-last model with every hand-written HIP layer on.  bf16 tolerance: the
+    loss to 2 %, the seven named gradients by direction (cosine > 0.98) and size (norm within 10 %), the BatchNorm running
+    statistics the fused kernels leave to 2 %.  (float32 tolerance: tests/test_crnn_cpu.py, the same fixture.)"""
+    from salsa_amd import _lib
+    from salsa_amd.crnn.loss import seld_loss
+    from salsa_amd.crnn.testing import dropout_off, g16_batch, seeded_fill
+    from salsa_amd.crnn.train import Trainer
+    meta, a = load_golden('g16_crnn_train')
+    tr = Trainer('cuda:0', total_steps=10)
+    seeded_fill(tr.raw_model, meta['weight_seed'])
+    from salsa_amd.crnn.nn_ops import invalidate_conv_caches
+    invalidate_conv_caches(tr.raw_model)
+    assert _lib.load() is not None
+    x, sed, doa = (t.cuda() for t in g16_batch(meta))
+    tr.model.train()
+    with dropout_off(tr.raw_model):
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            pred = tr.model(tr._input_layout(x))
+        loss, sed_l, doa_l = seld_loss(pred, sed, doa)
+        loss.backward()
+    np.testing.assert_allclose([float(loss), float(sed_l), float(doa_l)], a['loss'], rtol=2e-2)
+    params = dict(tr.raw_model.named_parameters())
+    for k, st in meta['grad_strides'].items():
+        got = params[k].grad.float().reshape(-1)[::st].cpu().numpy().astype(np.float64)
+        ref = a['grad:' + k].astype(np.float64)
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
+        ratio = float(np.linalg.norm(got) / np.linalg.norm(ref))
+        assert cos > 0.98 and 0.9 < ratio < 1.1, (k, cos, ratio)
+    sd = tr.raw_model.state_dict()
+    for k in (x_[5:] for x_ in a.keys() if x_.startswith('stat:')):
+        np.testing.assert_allclose(sd[k].float().cpu().numpy(), a['stat:' + k], rtol=2e-2, atol=2e-3, err_msg=k)
+
+
+def test_config5_sub_batch_is_batch_invariant():
+    """BASELINE config 5's REAL sub-batch -- 32 x (7, 4800, 200), the largest tensors any kernel here sees (3.9-GB stem output;
+    reference path models/seld_models.py:110-117) -- had a timing but no check (round-3 review): the eval forward of the first
+    two clips inside the batch of 32 must equal the forward of those two clips alone (the persistent tile walks, the folded
+    BatchNorm epilogues and the GRU scans all depend on the batch size; no output may)."""
+    from salsa_amd.crnn.testing import seeded_fill
+    from salsa_amd.crnn.train import Trainer
+    tr = Trainer('cuda:0', total_steps=10)
+    seeded_fill(tr.raw_model, 11)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(32, 7, 4800, 200, device='cuda', generator=g)
+    x[:, 4:] *= (torch.rand(32, 3, 4800, 200, device='cuda', generator=g) < 0.25)
+    p32, d32 = tr.infer(x)
+    p2, d2 = tr.infer(x[:2].contiguous())
+    assert p32.shape == (32, 600, 12) and d32.shape == (32, 600, 36)
+    assert bool(torch.isfinite(p32).all()) and bool(torch.isfinite(d32).all())
+    np.testing.assert_allclose(p32[:2].cpu().numpy(), p2.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(d32[:2].cpu().numpy(), d2.cpu().numpy(), rtol=0, atol=1e-6)
+    p_last, d_last = tr.infer(x[30:].contiguous())
+    np.testing.assert_allclose(p32[30:].cpu().numpy(), p_last.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(d32[30:].cpu().numpy(), d_last.cpu().numpy(), rtol=0, atol=1e-6)
