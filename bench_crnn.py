@@ -112,6 +112,9 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
                                'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}})
 
 
+N_ROT = 4          # distinct device-resident batches rotating through the timed training loops
+
+
 def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False,
                 n_frames=640, amp_dtype='default', force_ddp=False):
     """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
@@ -131,8 +134,12 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
     if force_ddp:
         kw['ddp'] = True                          # (a 1-rank group: --force-ddp)
     tr = Trainer(dev, bf16_grad_allreduce=not fp32_grads, **kw)
-    x, sed, doa = synthetic_batch(batch, dev, seed=2021 + rank, n_frames=n_frames)
-    ex, audio = None, None
+    # N_ROT distinct device-resident batches rotate through the loop (round-3 review: ONE 115-MB batch for all steps stays in the
+    # 256-MB Infinity Cache, and config 4 re-extracted the same 32 chunks every step): a step never sees the data of the step
+    # before, 4 x 115 MB of features / 4 x 98 MB of audio do not fit the cache.  Every rank draws its own batches.
+    n_rot = N_ROT if on_gpu else 1
+    data = [synthetic_batch(batch, dev, seed=2021 + rank + 1000 * j, n_frames=n_frames) for j in range(n_rot)]
+    ex, audios = None, None
     if on_the_fly:
         from salsa_amd.extractor import SalsaExtractor
         ex = SalsaExtractor(audio_format='mic', fmax_doa=4000, device=dev)
@@ -140,13 +147,17 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
         ex.set_scaler(torch.full((4, 1, 200), -60.0, device=dev), torch.full((4, 1, 200), 12.0, device=dev))
         import numpy as np
         from salsa_amd.synth import synth_clip                        # seeded 8-s chunks (bursts + noise), 32 per rank
-        audio = torch.from_numpy(np.stack([synth_clip(4021 + rank * batch + i, 8 * 24000) for i in range(batch)])).to(dev)
+        audios = [torch.from_numpy(np.stack([synth_clip(4021 + (rank * n_rot + j) * batch + i, 8 * 24000) for i in range(batch)])).to(dev)
+                  for j in range(n_rot)]
     aug_gen = torch.Generator().manual_seed(2021 + rank)
+    it = [0]
 
     def step():
-        xb, sb, db = x, sed, doa
+        j = it[0] % n_rot
+        it[0] += 1
+        xb, sb, db = data[j]
         if ex is not None:
-            xb = ex.extract(audio)[:, :, :640]                      # (B,7,641,200) -> 640 frames
+            xb = ex.extract(audios[j])[:, :, :640]                  # (B,7,641,200) -> 640 frames
         if augment:
             from salsa_amd.augment import augment_batch
             xb, sb, db = augment_batch(xb, sb, db, 'mic' if ex is not None else 'foa', gen=aug_gen)
@@ -184,7 +195,7 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'CRNN (ResNet22 + BiGRU) training on %s SALSA chunks (7,%d,200), batch %d per GPU, Adam'
                                % ('on-the-fly extracted MIC (raw [B][4][192000] audio -> SALSA-MIC on device, scaler fused)' if on_the_fly else 'precomputed-FOA-shaped', n_frames, batch)
-                               + (' + device augmentation' if augment else ''),
+                               + (' + device augmentation' if augment else '') + '; %d distinct device-resident batches rotate' % n_rot,
                    'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if fp32_grads else 'bf16'},
         'roofline': {'bound': 'mfma', 'achieved': round(tflops / world, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tflops / world / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,

@@ -104,7 +104,25 @@ def run(feature, fmt, fmax, n_samples, workers=None):
         configs.append({'cores': w, 'value': round(w * secs / max(per), 2), 'per_core': round(secs / (sum(per) / len(per)), 2),
                         'slowest_clip_s': round(max(per), 2), 'core_s_total': round(sum(per), 1), 'pool_wall_s': round(wall, 2)})
     best = max(configs, key=lambda c: c['value'])
+    # The reference Python cannot run on the GPU box (it never travels).  Its speed RELATIVE to this port was measured once, in the
+    # build container, both on the same clip, core and numpy (tools/time_reference.py -> profiles/ref_vs_port.json: a committed data
+    # file, read here); dividing the on-box port figure by that ratio quotes the port figure in "reference Python" terms.
+    ref_equiv = None
+    try:
+        import json
+        rv = json.load(open(os.path.join(ROOT, 'profiles', 'ref_vs_port.json')))
+        ratio = float(rv['ratio_port_over_reference'])
+        if feature == 'salsa' and ratio > 0:
+            ref_equiv = {'value': round(best['value'] / ratio, 2), 'single_core_value': round(best['per_core'] / ratio, 2),
+                         'ratio_port_over_reference': round(ratio, 3),
+                         'provenance': 'profiles/ref_vs_port.json: reference extract_features() %.2f vs oracle %.2f audio-s/s on one core of '
+                                       '%s (build container, clip seed %d, same numpy); assumes the ratio carries over to this host'
+                                       % (rv['reference_python']['audio_s_per_s'], rv['port_oracle']['audio_s_per_s'], rv['host']['cpu'],
+                                          rv['clip']['seed'])}
+    except Exception:
+        pass
     return {'value': best['value'], 'unit': 'audio-seconds/s', 'cores': best['cores'], 'kind': 'port',
+            'reference_python_equiv': ref_equiv,
             'cpu_model': model, 'physical_cores': phys, 'logical_cpus': logical,
             'effective_cores': cap, 'affinity_cpus': eff['affinity_cpus'], 'cgroup_cpu_quota': eff['cgroup_cpu_quota'],
             'cgroup_source': eff['cgroup_source'],
