@@ -66,6 +66,58 @@ def cpu_baseline(feature, fmt, fmax, n_samples):
 
 
 
+def harness_bench(fmt, fmax, batch, n_samples, host):
+    """file tree -> feature-file tree through salsa_amd.features.extract_features (the reference's Makefile entry point)"""
+    import shutil
+    import tempfile
+
+    import yaml
+
+    from salsa_amd import features
+    from salsa_amd import io as sio
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and shutil.disk_usage('/dev/shm').free > 12e9 else None
+    tmp = tempfile.mkdtemp(dir=base)
+    try:
+        n_clips = 2 * batch
+        d = os.path.join(tmp, 'data', fmt + '_dev')
+        os.makedirs(d)
+        os.makedirs(os.path.join(tmp, 'data', fmt + '_eval'))
+        for i in range(n_clips):
+            np.save(os.path.join(d, 'fold1_room1_mix%03d.npy' % i), host[i % batch])
+        cfg = {'data_dir': os.path.join(tmp, 'data'), 'feature_dir': os.path.join(tmp, 'feat'),
+               'data': {'format': fmt, 'fs': 24000, 'n_fft': 512, 'win_len': 512, 'hop_len': 300, 'fmin_doa': 50, 'fmax_doa': fmax}}
+        cfg_path = os.path.join(tmp, 'cfg.yml')
+        yaml.safe_dump(cfg, open(cfg_path, 'w'))
+        secs = n_clips * n_samples / 24000.0
+        res = {'clips': n_clips, 'tree': 'float32 .npy clips on %s, feature files %s' % ('tmpfs' if base else 'the temp dir', 'HDF5' if sio.HAVE_H5PY else '.npz (no h5py here)')}
+        for name, flag in (('pipelined', True), ('serial', False)):
+            features.USE_FILE_PIPELINE = flag
+            features.extract_features(data_config=cfg_path, task='feature', batch_size=batch)        # warm-up: plans, pinned slots
+            t0 = time.perf_counter()
+            features.extract_features(data_config=cfg_path, task='feature', batch_size=batch)
+            dt = time.perf_counter() - t0
+            res[name] = {'s': round(dt, 3), 'audio_s_per_s': round(secs / dt, 1)}
+        features.USE_FILE_PIPELINE = True
+        # the file system's share: read every clip, write every feature file, nothing else (one thread)
+        feat_dir = os.path.join(tmp, 'feat')
+        files = [os.path.join(r, f) for r, _, fs_ in os.walk(feat_dir) for f in fs_]
+        one = sio.load_arrays(files[0])['feature']
+        t0 = time.perf_counter()
+        for i in range(n_clips):
+            np.load(os.path.join(d, 'fold1_room1_mix%03d.npy' % i))
+        t_r = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(8):
+            sio.save_arrays(os.path.join(tmp, 'probe_%d.h5' % i), feature=one)
+        t_w = (time.perf_counter() - t0) / 8 * n_clips
+        res['file_io_alone'] = {'read_s': round(t_r, 3), 'write_s_one_thread': round(t_w, 3),
+                                'note': 'np.load of every clip; save_arrays of every feature file from one thread (the pipeline writes with 8)'}
+        res['pcie_bound_s'] = round(n_clips / batch * (host.nbytes + one.nbytes * batch) / 55e9, 3)
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _flush_c_stdio():
     """push out whatever native libraries (RCCL's version banner) left in libc's stdout buffer -- every rank, as soon as its
     process group is gone, so that nothing of it can land after rank 0's result line"""
@@ -376,6 +428,12 @@ def main():
             pcie['overlapped'] = {'ms_per_step': round(1e3 * tp, 3), 'audio_s_per_s': round(args.batch * args.seconds / tp, 1),
                                   'note': 'HostPipeline(depth=3): pinned host slot -> device -> features -> pinned host slot, the transfers of neighbouring batches overlapped on separate streams'}
             del pipe
+            # the drop-in harness itself, files to files (reference: salsa_feature_extraction.py:351-383): a synthetic tree of
+            # 2 x batch 60-s clips as float32 .npy files on tmpfs -> extract_features(task='feature') -> one feature file per
+            # clip.  Next to it: the same with the pipeline off (read, copy, extract, copy back, write, serially) and what the
+            # file system alone does with these bytes.
+            if args.feature == 'salsa':
+                pcie['harness'] = harness_bench(fmt, fmax, args.batch, n_samples, host)
 
     # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the data-parallel run)
     infer_audio = audio if (args.feature == 'salsa' and fmt == 'foa' and args.batch == 32 and abs(args.seconds - 60) < 1e-9) else None

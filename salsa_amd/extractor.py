@@ -79,6 +79,16 @@ class SalsaExtractor:
         self._ws = None
         self._prefix_mode = False
 
+    def kwargs(self):
+        """the constructor arguments of this extractor (to build further plans with the same parameters: one per pipeline slot)"""
+        p = self.params
+        inv = lambda d, v: [k for k, x in d.items() if x == v][0]
+        return dict(fs=p.fs, n_fft=p.n_fft, hop_len=p.hop_len, win_len=p.win_len, fmin_doa=p.fmin_doa, fmax_doa=p.fmax_doa,
+                    cond_num=p.cond_num, n_hopframes=p.n_hopframes, is_tracking=bool(p.is_tracking),
+                    is_compress_high_freq=bool(p.is_compress_high_freq), audio_format=inv(_lib.FORMAT, p.audio_format),
+                    feature_type=self.feature_type, audio_layout=self.audio_layout, device=self.device, flags=p.flags,
+                    floor_mask_ratio=p.floor_mask_ratio, fmax_spec=p.fmax_spec)
+
     def __del__(self):
         if getattr(self, '_plan', None):
             self.L.salsa_plan_destroy(self._plan)
