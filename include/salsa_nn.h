@@ -176,6 +176,19 @@ int salsa_nn_freq_mean_bwd(const float *g, void *dx, int64_t N, int H, int W, in
  * bias gradients db_ih = sum_(t,b) dgi, db_hh = sum_(t,b) dgh in one launch (torch's reduction / a ones-vector GEMV: ~17 us each). */
 int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b, int64_t M, int C, void *hip_stream);
 
+/* Deterministic weight gradients (round 4).  Every weight-gradient kernel (salsa_nn_conv3x3_c64_wrw, _stem_wrw, _stem_wrw_bn,
+ * _wide_wrw, salsa_nn_conv1x1_wrw) and salsa_nn_colsum2 is a reduction over pixels split across workgroups.  By default the
+ * workgroups combine their float32 partial sums with atomic adds: the order of arrival decides the rounding, so two identical
+ * training steps differ in the last bits.  salsa_nn_set_deterministic(ws, bytes) with a device workspace switches all of them to
+ * partial SLABS (every workgroup stores its partial sums into its own slab of `ws`) followed by one reduction launch that adds the
+ * slabs in slab order -- bit-identical results run to run, at the price of the slab traffic (<= 76 MB per call) and one more
+ * launch per call.  ws = NULL switches back to atomics.  The calls then return -5 when `bytes` is too small for a shape
+ * (SALSA_NN_DET_WS_BYTES covers every layer of the SELD CRNN at the bench's sizes).  The workspace is shared by all calls: use
+ * one stream at a time, as the trainer does.  salsa_nn_get_deterministic: 1 when on. */
+#define SALSA_NN_DET_WS_BYTES ((size_t)160 << 20)
+int salsa_nn_set_deterministic(void *ws, size_t bytes);
+int salsa_nn_get_deterministic(void);
+
 #ifdef __cplusplus
 }
 #endif

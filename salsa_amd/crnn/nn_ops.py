@@ -16,6 +16,30 @@ USE_HIP_CONV = os.environ.get('SALSA_HIP_CONV', '1') != '0'
 USE_HIP_CONV_WIDE = os.environ.get('SALSA_HIP_CONV_WIDE', '1') != '0'   # the 128 / 256 / 512-channel 3x3 layers (conv_wide.hip)
 
 
+_DET_WS = [None]
+DET_WS_BYTES = 160 << 20        # include/salsa_nn.h: SALSA_NN_DET_WS_BYTES
+
+
+def set_deterministic(on: bool, device=None) -> None:
+    """Bit-reproducible weight gradients (include/salsa_nn.h: salsa_nn_set_deterministic): every weight-gradient kernel and the GRU
+    bias column sums write per-workgroup partial slabs into one device workspace and a reduction launch adds them in slab order,
+    instead of float atomics in arrival order.  Slower by the slab traffic and one launch per weight gradient (the bench states how
+    much); off by default, like torch.use_deterministic_algorithms.  ``SALSA_DETERMINISTIC=1`` switches it on at the first
+    training forward.  One workspace per process: the current (or the given) device, one stream at a time."""
+    L = _lib.load()
+    if not on:
+        L.salsa_nn_set_deterministic(None, 0)
+        _DET_WS[0] = None
+        return
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    _DET_WS[0] = torch.empty(DET_WS_BYTES, dtype=torch.uint8, device=dev)
+    L.salsa_nn_set_deterministic(C.c_void_p(_DET_WS[0].data_ptr()), DET_WS_BYTES)
+
+
+def is_deterministic() -> bool:
+    return bool(_lib.load().salsa_nn_get_deterministic())
+
+
 def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -345,11 +369,14 @@ class _GradZeros:
 
 _GRAD_ZEROS = _GradZeros()
 USE_GRAD_ARENA = os.environ.get('SALSA_GRAD_ARENA', '1') != '0'
+_DET_ENV = os.environ.get('SALSA_DETERMINISTIC', '0') == '1'
 
 
 def new_backward_generation():
     """Announce a new forward/backward pass to the weight-gradient buffer pool (the encoder calls it per training forward)."""
     _GRAD_ZEROS.new_generation()
+    if _DET_ENV and _DET_WS[0] is None and torch.cuda.is_available():
+        set_deterministic(True)                      # SALSA_DETERMINISTIC=1
 
 
 def _grad_zeros(shape, device):

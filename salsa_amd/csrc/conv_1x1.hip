@@ -7,6 +7,7 @@
 // its cast / transpose helper kernels took 0.44 ms of a 13.4 ms training step for them.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "nn_det.h"
 
 namespace {
 
@@ -115,7 +116,8 @@ template <int KS> __device__ __forceinline__ void wrw1_steps(f32x16 (&acc)[2], c
 }
 
 __global__ __launch_bounds__(256) void conv1x1_wrw_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ dy,
-                                                          float *__restrict__ dw, long M, int K, int N, int tiles_per_wg)
+                                                          float *__restrict__ dw, long M, int K, int N, int tiles_per_wg,
+                                                          float *__restrict__ part /* deterministic mode: [gridDim.z][N*K] */)
 {
     __shared__ __attribute__((aligned(16))) unsigned short gl[WP * ROW_G];
     __shared__ __attribute__((aligned(16))) unsigned short xl[WP * ROW_X];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void conv1x1_wrw_kernel(const unsigned short *
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int co = co0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), ci = ci0 + 32 * t + (lane & 31);
-                atomicAdd(dw + (long)co * K + ci, acc[t][reg]);
+                salsa_nn_accumulate(dw, part, (long)N * K, (int)blockIdx.z, (long)co * K + ci, acc[t][reg]);
             }
     }
 }
@@ -218,8 +220,12 @@ int salsa_nn_conv1x1_wrw(const void *x, const void *dy, float *dw, int64_t M, in
     if (split < 1) split = 1;
     const int per = (int)((n_tiles + split - 1) / split);
     const unsigned bz = (unsigned)((n_tiles + per - 1) / per);
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)bz, (long)Cout * Cin, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv1x1_wrw_kernel, dim3(bx, by, bz), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)dy, dw, (long)M, Cin, Cout, per);
+                       (const unsigned short *)dy, dw, (long)M, Cin, Cout, per, part);
+    if (part) return salsa_nn_det_finish(part, (int)bz, (long)Cout * Cin, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

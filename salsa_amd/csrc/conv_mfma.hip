@@ -12,6 +12,7 @@
 // the 64 -> 64 weight gradient (transposing LDS reads; "weight gradient" below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "nn_det.h"
 
 namespace {
 
@@ -1006,7 +1007,8 @@ __device__ __forceinline__ void wrw_steps(tr_frag (&fr)[WRW_DEPTH + 1], bf16x8 &
 
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned short *__restrict__ x,
                                                                  const unsigned short *__restrict__ dy,
-                                                                 float *__restrict__ dw, int N, int H, int W, const Geo geo)
+                                                                 float *__restrict__ dw, int N, int H, int W, const Geo geo,
+                                                                 float *__restrict__ part /* deterministic mode: [gridDim.x][64*9*64] */)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xl[WHALO_H * WHALO_W * ROW];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #ifdef WRW64_NO_ATOMIC // (probe)
             if (acc[tap][reg] == 123.456f)
 #endif
-            atomicAdd(dw + ((long)(co * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + ci), acc[tap][reg]); // (transposed
+            salsa_nn_accumulate(dw, part, 64L * 9 * 64, (int)blockIdx.x, ((long)(co * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + ci), acc[tap][reg]); // (transposed
         }                                                                                  // geometry: tap (ky, kx) is the filter's (kx, ky))
 }
 
@@ -1128,8 +1130,12 @@ extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw
     // persistent workgroups, two per CU; fewer when there are few tiles (every workgroup ends with 36 864 float atomics)
     // (mid sizes, 32 x 320 x 100: 256 workgroups 0.158 ms, 384: 0.141, 512: 0.149)
     const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)nb, 64L * 9 * 64, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv3x3_c64_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo);
+                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo, part);
+    if (part) return salsa_nn_det_finish(part, (int)nb, 64L * 9 * 64, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -1172,7 +1178,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
                                                                const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                int N, int Cin, int H, int W,
                                                                const unsigned short *__restrict__ x1, const float *__restrict__ coef,
-                                                               int relu)
+                                                               int relu, float *__restrict__ part /* deterministic mode: [gridDim.x][64*Cin*9] */)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xs[SW_XS];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
@@ -1284,7 +1290,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__re
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            atomicAdd(dw + co * (Cin * 9) + c, acc[reg]);
+            salsa_nn_accumulate(dw, part, 64L * Cin * 9, (int)blockIdx.x, (long)co * (Cin * 9) + c, acc[reg]);
         }
     }
 }
@@ -1301,9 +1307,13 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles); // persistent, five per CU (30 KB of LDS each)
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)nb, 64L * Cin * 9, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
                        (long)x_channel_stride, (const unsigned short *)dy, dw, (int)N, Cin, H, W, (const unsigned short *)nullptr,
-                       (const float *)nullptr, 0);
+                       (const float *)nullptr, 0, part);
+    if (part) return salsa_nn_det_finish(part, (int)nb, 64L * Cin * 9, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
@@ -1319,7 +1329,11 @@ extern "C" int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stri
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles);
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)nb, 64L * Cin * 9, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
-                       (long)x_channel_stride, (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, coef, relu);
+                       (long)x_channel_stride, (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, coef, relu, part);
+    if (part) return salsa_nn_det_finish(part, (int)nb, 64L * Cin * 9, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

@@ -21,6 +21,7 @@
 // x 2*(TN/32) MFMAs per wave.  The data gradient is the same kernel on dy with the filter flipped and transposed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "nn_det.h"
 
 namespace {
 
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                   const int *__restrict__ vpos, const int *__restrict__ inv,
                                                                   const int2 *__restrict__ tbounds, long P, int W, int CIN, int COUT,
-                                                                  int n_shares)
+                                                                  int n_shares, float *__restrict__ part /* deterministic mode: [n_shares][COUT*9*CIN] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wave & 3, kq = wave >> 2;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
 #ifdef WRW_NO_ATOMIC
             if (acc[t][reg] == 123.456f)
 #endif
-            atomicAdd(dw + ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
+            salsa_nn_accumulate(dw, part, (long)COUT * 9 * CIN, (int)blockIdx.x, ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
         }
 }
 
@@ -697,8 +698,12 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
     if (shares < 1) shares = 1;
     if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return -6; // 120 KiB of dynamic LDS (per device: set on every launch)
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)shares, (long)Cout * 9 * Cin, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
     hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(WG_NT),
                        WG_LDS, (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
-                       (int)shares);
+                       (int)shares, part);
+    if (part) return salsa_nn_det_finish(part, (int)shares, (long)Cout * 9 * Cin, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

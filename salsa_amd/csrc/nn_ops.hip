@@ -4,6 +4,7 @@
 #include <hip/hip_bf16.h>
 
 #include "../../include/salsa_nn.h"
+#include "nn_det.h"
 
 namespace {
 
@@ -638,11 +639,53 @@ __global__ __launch_bounds__(256) void freq_mean_bwd_kernel(const float *__restr
     *(uint4 *)(dx + rw * C + c8 * 8) = o;
 }
 
+// ------------------------------------------------------------------------------------------------ deterministic reductions
+// dw[i] += ws[0][i] + ws[1][i] + ... in slab order: one thread per four consecutive elements, the slabs' rows read coalesced
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int slabs, long n, float *__restrict__ dw)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n && !(n & 3)) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 3 < slabs; s += 4) { // four loads in flight; the additions keep slab order
+            const float4 a = *(const float4 *)(ws + (long)s * n + i), b = *(const float4 *)(ws + (long)(s + 1) * n + i);
+            const float4 c = *(const float4 *)(ws + (long)(s + 2) * n + i), d = *(const float4 *)(ws + (long)(s + 3) * n + i);
+            acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x; acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
+            acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z; acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
+        }
+        for (; s < slabs; s++) {
+            const float4 a = *(const float4 *)(ws + (long)s * n + i);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        float4 o = *(const float4 *)(dw + i);
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *(float4 *)(dw + i) = o;
+    } else {
+        for (long k = i; k < n && k < i + 4; k++) {
+            float acc = 0.f;
+            for (int s = 0; s < slabs; s++) acc += ws[(long)s * n + k];
+            dw[k] += acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ column sums
+__global__ __launch_bounds__(256) void slab_reduce_strided_kernel(const float *__restrict__ ws, int slabs, int C, float *__restrict__ oa,
+                                                                  float *__restrict__ ob)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int s = 0; s < slabs; s++) acc += ws[((long)s * 2 + blockIdx.y) * C + c];
+    (blockIdx.y ? ob : oa)[c] += acc;
+}
+
 // out[c] += sum over rows of x[row][c] for up to two float32 matrices of one shape (the GRU's two bias gradients: rows = T * B,
 // C = D * 3H); out must hold zeros.  Workgroup = 64 columns x 4 row lanes over a slice of the rows; one float atomic per column.
 __global__ __launch_bounds__(256) void colsum2_kernel(const float *__restrict__ xa, const float *__restrict__ xb, float *__restrict__ oa,
-                                                      float *__restrict__ ob, long M, int C, int rows_per_block)
+                                                      float *__restrict__ ob, long M, int C, int rows_per_block,
+                                                      float *__restrict__ part /* deterministic mode: [gridDim.y][2][C] */)
 {
     __shared__ float red[4][64];
     const float *x = blockIdx.z ? xb : xa;
@@ -660,7 +703,11 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float *__restrict__ 
     }
     red[rl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rl == 0 && col < C) atomicAdd(o + col, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (rl == 0 && col < C) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (part) part[((long)blockIdx.y * 2 + blockIdx.z) * C + col] = v;
+        else atomicAdd(o + col, v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ SELD loss
@@ -756,6 +803,33 @@ __global__ __launch_bounds__(256) void seld_loss_scale_kernel(const float *__res
 }
 
 } // namespace
+
+static float *g_det_ws = nullptr;
+static size_t g_det_bytes = 0;
+extern "C" int salsa_nn_set_deterministic(void *ws, size_t bytes)
+{
+    g_det_ws = (float *)ws;
+    g_det_bytes = ws ? bytes : 0;
+    return 0;
+}
+extern "C" int salsa_nn_get_deterministic(void) { return g_det_ws != nullptr; }
+float *salsa_nn_det_begin(int slabs, long n, hipStream_t st, int *rc)
+{
+    *rc = 0;
+    if (!g_det_ws) return nullptr;
+    const size_t need = (size_t)slabs * (size_t)n * sizeof(float);
+    if (need > g_det_bytes) {
+        *rc = -5;
+        return nullptr;
+    }
+    if (hipMemsetAsync(g_det_ws, 0, need, st) != hipSuccess) *rc = -6; // (a slab element no workgroup writes must read as zero)
+    return g_det_ws;
+}
+int salsa_nn_det_finish(const float *ws, int slabs, long n, float *dw, hipStream_t st)
+{
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, ws, slabs, n, dw);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
 
 extern "C" {
 
@@ -1043,8 +1117,16 @@ int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b,
 {
     if (!a || !out_a || (b && !out_b) || M <= 0 || C <= 0) return -1;
     const int rpb = 64; // rows per workgroup: 16 per row lane
-    hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((M + rpb - 1) / rpb), b ? 2u : 1u), dim3(256), 0,
-                       (hipStream_t)hip_stream, a, b, out_a, out_b, (long)M, C, rpb);
+    const unsigned gy = (unsigned)((M + rpb - 1) / rpb);
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)gy, 2L * C, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum2_kernel, dim3((unsigned)((C + 63) / 64), gy, b ? 2u : 1u), dim3(256), 0,
+                       (hipStream_t)hip_stream, a, b, out_a, out_b, (long)M, C, rpb, part);
+    if (part) { // slab row = [out_a | out_b]: two strided reductions (the outputs are separate arrays)
+        hipLaunchKernelGGL(slab_reduce_strided_kernel, dim3((unsigned)((C + 255) / 256), b ? 2u : 1u), dim3(256), 0, (hipStream_t)hip_stream,
+                           part, (int)gy, C, out_a, out_b);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
