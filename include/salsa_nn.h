@@ -104,6 +104,25 @@ int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stride, int64_t
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 
+/* Round 4: a conv -> BatchNorm -> ReLU (-> dropout) -> conv chain of the reference blocks (models/model_utils.py:213-228, :345-367)
+ * without the normalised activation ever being stored.  The first convolution leaves its RAW output x1 and the per-workgroup
+ * statistics (salsa_nn_conv3x3_*_stats); salsa_nn_bn_train_finalize turns those into mean / invstd (and updates the running
+ * statistics) with no pass over x1; the SECOND convolution's forward (salsa_nn_conv3x3_c64_xform_stats: y = conv(a, w) + the
+ * statistics epilogue for the BatchNorm that follows) and weight gradient (salsa_nn_conv3x3_c64_wrw_xform) form
+ * a = dropout(relu(((x1 - mean) * invstd) * gamma + beta)) while they stage their operand -- as x1 * scale + shift with
+ * scale = invstd * gamma, shift = beta - mean * scale in float32, rounded once to bf16; the dropout mask is the one
+ * salsa_nn_bn_train_fwd would draw for (drop_p, drop_seed), so salsa_nn_bn_bwd regenerates the same.  The convolution's zero padding
+ * applies to a, not to x1.  All four vectors: float32 [64]. */
+int salsa_nn_bn_train_finalize(const double *stats_part, int stats_blocks, int64_t M, int C, float eps, float momentum,
+                               float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                               int64_t *batches_tracked, void *hip_stream);
+int salsa_nn_conv3x3_c64_xform_stats(const void *x1, const void *w, void *y, double *stats_part, const float *mean,
+                                     const float *invstd, const float *gamma, const float *beta, float drop_p, uint32_t drop_seed,
+                                     int64_t N, int H, int W, void *hip_stream);
+int salsa_nn_conv3x3_c64_wrw_xform(const void *x1, const void *dy, float *dw, const float *mean, const float *invstd,
+                                   const float *gamma, const float *beta, float drop_p, uint32_t drop_seed, int64_t N, int H, int W,
+                                   void *hip_stream);
+
 /* drop_p > 0 fuses the dropout that follows the ReLU in the upstream residual block (models/resnet.py:78): an element is kept
  * when a counter-based hash of (its index, drop_seed) says so and scaled by 1/(1-p), p quantised to 1/65536; the backward takes
  * the same (drop_p, drop_seed) and regenerates the mask, so none is stored.  M*C must be below 2^32. */

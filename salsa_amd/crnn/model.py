@@ -102,7 +102,7 @@ class Encoder(nn.Module):
         if self.training and torch.is_grad_enabled():
             self._filter_bank.mark_stale()                     # training: the bank is rebuilt every forward, unconditionally
         if torch.is_grad_enabled():
-            new_backward_generation()                          # weight-gradient buffers: one allocation + one fill per pass (any
+            new_backward_generation(x.device)                  # weight-gradient buffers: one allocation + one fill per pass (any
                                                                # differentiable forward, eval-mode fine-tuning / saliency included)
         x = self.stem(x)
         x = F.dropout(x, p=self.p_dropout, training=self.training)

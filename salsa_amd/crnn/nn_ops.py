@@ -16,24 +16,35 @@ USE_HIP_CONV = os.environ.get('SALSA_HIP_CONV', '1') != '0'
 USE_HIP_CONV_WIDE = os.environ.get('SALSA_HIP_CONV_WIDE', '1') != '0'   # the 128 / 256 / 512-channel 3x3 layers (conv_wide.hip)
 
 
-_DET_WS = [None]
+_DET_WS = {}                    # device -> workspace tensor
+_DET_ON = [None]                # the device the library's workspace pointer currently names (None: atomics)
 DET_WS_BYTES = 160 << 20        # include/salsa_nn.h: SALSA_NN_DET_WS_BYTES
+# Deterministic weight gradients are the DEFAULT (SALSA_DETERMINISTIC=0 opts out): measured at +0.04 - 0.09 ms of a 10.8-ms
+# training step (profiles/r4_ab_notes.txt) for bit-reproducible gradients.
+_DET_ENV = os.environ.get('SALSA_DETERMINISTIC', '1') != '0'
 
 
 def set_deterministic(on: bool, device=None) -> None:
     """Bit-reproducible weight gradients (include/salsa_nn.h: salsa_nn_set_deterministic): every weight-gradient kernel and the GRU
     bias column sums write per-workgroup partial slabs into one device workspace and a reduction launch adds them in slab order,
-    instead of float atomics in arrival order.  Slower by the slab traffic and one launch per weight gradient (the bench states how
-    much); off by default, like torch.use_deterministic_algorithms.  ``SALSA_DETERMINISTIC=1`` switches it on at the first
-    training forward.  One workspace per process: the current (or the given) device, one stream at a time."""
+    instead of float atomics in arrival order.  On by default: the first differentiable forward of a model on a CUDA device
+    switches it on for that device (``SALSA_DETERMINISTIC=0``, or ``set_deterministic(False)`` after it, selects the atomics).
+    One 160-MB workspace per device, shared by all calls: one stream at a time, as the trainer uses it."""
     L = _lib.load()
     if not on:
         L.salsa_nn_set_deterministic(None, 0)
-        _DET_WS[0] = None
+        _DET_ON[0] = None
+        _DET_USER[0] = False
         return
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
-    _DET_WS[0] = torch.empty(DET_WS_BYTES, dtype=torch.uint8, device=dev)
-    L.salsa_nn_set_deterministic(C.c_void_p(_DET_WS[0].data_ptr()), DET_WS_BYTES)
+    if dev not in _DET_WS:
+        _DET_WS[dev] = torch.empty(DET_WS_BYTES, dtype=torch.uint8, device=dev)
+    L.salsa_nn_set_deterministic(C.c_void_p(_DET_WS[dev].data_ptr()), DET_WS_BYTES)
+    _DET_ON[0] = dev
+    _DET_USER[0] = True
+
+
+_DET_USER = [None]              # None: never set by hand (the default applies); True / False: the caller's choice
 
 
 def is_deterministic() -> bool:
@@ -369,14 +380,17 @@ class _GradZeros:
 
 _GRAD_ZEROS = _GradZeros()
 USE_GRAD_ARENA = os.environ.get('SALSA_GRAD_ARENA', '1') != '0'
-_DET_ENV = os.environ.get('SALSA_DETERMINISTIC', '0') == '1'
 
 
-def new_backward_generation():
-    """Announce a new forward/backward pass to the weight-gradient buffer pool (the encoder calls it per training forward)."""
+def new_backward_generation(device=None):
+    """Announce a new forward/backward pass to the weight-gradient buffer pool (the encoder calls it per differentiable forward);
+    on a CUDA device this is also where the deterministic-gradient workspace of THAT device is (created and) selected."""
     _GRAD_ZEROS.new_generation()
-    if _DET_ENV and _DET_WS[0] is None and torch.cuda.is_available():
-        set_deterministic(True)                      # SALSA_DETERMINISTIC=1
+    if device is not None and device.type == 'cuda' and (_DET_USER[0] is True or (_DET_USER[0] is None and _DET_ENV)) \
+            and _DET_ON[0] != device:
+        user = _DET_USER[0]
+        set_deterministic(True, device)
+        _DET_USER[0] = user
 
 
 def _grad_zeros(shape, device):

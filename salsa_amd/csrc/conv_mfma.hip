@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "nn_det.h"
+#include "nn_common.h"
 
 namespace {
 
@@ -468,20 +469,42 @@ __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&
     }
 }
 
-template <bool POOL, bool STATS = false>
+// XF (round 4): the input is the RAW output of the convolution before (x1) and this kernel's real operand is
+// a = dropout(relu(batch_norm(x1))) -- the normalised activation is never written to HBM nor read back (524 MB each way for the
+// stem's first BatchNorm).  The tiles still arrive by LDS-direct loads; once a thread's own pieces of tile i+1 have landed (the
+// counted wait that already exists) it rewrites them in place -- a = relu(x * scale[c] + shift[c]), the dropout mask regenerated
+// from the element index exactly as bn_apply_kernel draws it (nn_common.h) -- and the barrier that opens tile i+1 publishes them.
+// A thread's pieces always hold the same eight channels, so its 16 coefficients come from a 512-byte LDS table once per tile;
+// halo pieces outside the image stay the zeros they were loaded as (the convolution pads the ACTIVATION with zeros).
+struct XformArgs {
+    const float *mean, *invstd, *gamma, *beta; // the BatchNorm's batch statistics and affine parameters, float32 [64]
+    DropArgs drop;
+};
+
+template <bool POOL, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const unsigned short *__restrict__ x,
                                                                        const unsigned short *__restrict__ w,
                                                                        unsigned short *__restrict__ y, int N, int H, int W,
                                                                        const float *__restrict__ shift,
                                                                        const unsigned short *__restrict__ residual, int relu,
-                                                                       double *__restrict__ stats_part, const Geo geo)
+                                                                       double *__restrict__ stats_part, const Geo geo,
+                                                                       const XformArgs xf = XformArgs{})
 {
     static_assert(RPW == 2, "row sharing below is written for two rows per wave");
     static_assert(!(POOL && STATS), "statistics are a training feature, the fused pool an inference one");
     __shared__ __attribute__((aligned(16))) unsigned short xl[NBUF * ABUF];
     __shared__ float lstats[STATS ? 2 * 128 : 1]; // [row-group wave][sum | sum of squares][64 channels], used once after the last tile
+    __shared__ __attribute__((aligned(16))) float xtab[XF ? 2 * 64 : 4]; // XF: scale[64] = invstd * gamma, shift[64] = beta - mean * scale
     float rs[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f}; // STATS: this lane's running sums (conv64_stats)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (XF) {
+        if (tid < 64) {
+            const float sc = xf.invstd[tid] * xf.gamma[tid];
+            xtab[tid] = sc;
+            xtab[64 + tid] = xf.beta[tid] - xf.mean[tid] * sc;
+        }
+        __syncthreads(); // (before any LDS-direct load is in flight)
+    }
     const int px = lane & 31, khalf = lane >> 5, kh = khalf * 8;
     const int mb = wv & 1, rg = wv >> 1;
     bf16x8 af[9][4];
@@ -542,6 +565,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
             hh += wrap;
         }
     };
+    // XF: rewrite this thread's own (landed) pieces of a tile in place
+    auto transform = [&](const Cursor &c, int buf) {
+        const int h_lo = -c.th * TH, h_hi = H - c.th * TH, w_lo = -c.tw * TW, w_hi = W - c.tw * TW;
+        const long origin = geo_off(geo, c.n, c.th * TH, c.tw * TW); // element offset of the tile's pixel (0, 0) in the tensor
+        const float4 s0 = *(const float4 *)(xtab + blk8), s1 = *(const float4 *)(xtab + blk8 + 4);
+        const float4 t0 = *(const float4 *)(xtab + 64 + blk8), t1 = *(const float4 *)(xtab + 64 + blk8 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        int hh = hh0 - 1, ww = ww0 - 1;
+#ifndef C64_XF_UNROLL
+#define C64_XF_UNROLL 1 // pieces rewritten at a time: the filter owns the register file (unrolled by 7: 256 bytes of scratch per lane)
+#endif
+#pragma unroll C64_XF_UNROLL
+        for (int j = 0; j < AFETCH; j++) {
+            const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
+            if (inside && tid + j * 256 < HALO_PIECES) {
+                uint4 *slot = (uint4 *)(xl + buf * ABUF + (j * 256 + tid) * 8);
+                const uint4 v = *slot;
+                const unsigned in[4] = {v.x, v.y, v.z, v.w};
+                unsigned out[4];
+                const long e0 = origin + (long)hh * geo.sh + (long)ww * geo.sw + blk8; // the piece's first element in the tensor
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float a = fmaxf(__uint_as_float(in[k] << 16) * sc[2 * k] + sh[2 * k], 0.f);
+                    float b = fmaxf(__uint_as_float(in[k] & 0xffff0000u) * sc[2 * k + 1] + sh[2 * k + 1], 0.f);
+                    if (xf.drop.thresh) { // one 32-bit hash per pair of neighbouring elements, 16 bits each (drop_keep)
+                        const unsigned hsh = drop_hash((unsigned)(e0 >> 1) + k, xf.drop.seed);
+                        a = (hsh & 0xFFFFu) >= xf.drop.thresh ? a * xf.drop.scale : 0.f;
+                        b = (hsh >> 16) >= xf.drop.thresh ? b * xf.drop.scale : 0.f;
+                    }
+                    out[k] = pack_bf16(a, b);
+                }
+                *slot = make_uint4(out[0], out[1], out[2], out[3]);
+            }
+            ww += 32;
+            const int wrap = ww >= HALO_W - 1 ? 1 : 0;
+            ww -= wrap ? HALO_W : 0;
+            hh += wrap;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the rewritten pieces are in LDS before this wave reaches the next barrier
+    };
     // Loads of ONE wave return in order, but its stores retire independently, so a counted wait is only exact where nothing
     // but loads is younger than the loads waited for.  Order per tile: barrier -> issue tile+2 -> multiply tile -> wait until
     // only tile+2's loads are outstanding (tile+1 has landed; the stores of the tile before retired during the multiply)
@@ -557,14 +620,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     TilePos pcur = tile_pos(walk, tile), pahead = pcur;
     if (tile < n_tiles) fetch(cursor_of(pahead), 0);
     tile_advance(walk, pahead);
+    TilePos pnext = pahead;                         // XF: one tile ahead of `pcur`
     if (tile + stride < n_tiles) {
         fetch(cursor_of(pahead), 1);
         WAIT_ALL_BUT_LAST_FETCH();
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (XF && tile < n_tiles) transform(cursor_of(pcur), 0);
     tile_advance(walk, pahead); // two tiles ahead of `pcur` from here on
-    for (int it = 0; tile < n_tiles; tile += stride, it++, tile_advance(walk, pcur), tile_advance(walk, pahead)) {
+    for (int it = 0; tile < n_tiles; tile += stride, it++, tile_advance(walk, pcur), tile_advance(walk, pahead), tile_advance(walk, pnext)) {
         const Cursor cur = cursor_of(pcur);
 #ifndef CONV_NO_BARRIER // (probe)
         __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
@@ -610,6 +675,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg, geo);
         if (STATS) conv64_stats(acc, rs, rq, th, tw, H, W, px, rg);
 #endif
+        // XF: tile i+1 -- this thread's pieces landed at the wait above; rewritten here, after the epilogue, where the accumulators
+        // are dead (before it: 108 bytes of scratch per lane)
+        if (XF && tile + stride < n_tiles) transform(cursor_of(pnext), (it + 1) % NBUF);
     }
 #undef WAIT_ALL_BUT_LAST_FETCH
     if (STATS) { // this workgroup's partial sums: [2][64] float64, row blockIdx.x of the BatchNorm kernels' partial table
@@ -715,6 +783,26 @@ extern "C" int salsa_nn_conv3x3_c64_stats(const void *x, const void *w, void *y,
     hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<false, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
                        (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, (const float *)nullptr,
                        (const unsigned short *)nullptr, 0, stats_part, pl.geo);
+#endif
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// training, round 4: y = conv(a, w) with a = dropout(relu(batch_norm(x1))) formed on the fly from the RAW output x1 of the
+// convolution before (XformArgs above) + the statistics epilogue of salsa_nn_conv3x3_c64_stats for the BatchNorm that follows
+extern "C" int salsa_nn_conv3x3_c64_xform_stats(const void *x1, const void *w, void *y, double *stats_part, const float *mean,
+                                                const float *invstd, const float *gamma, const float *beta, float drop_p,
+                                                uint32_t drop_seed, int64_t N, int H, int W, void *hip_stream)
+{
+    if (!x1 || !w || !y || !stats_part || x1 == y || !mean || !invstd || !gamma || !beta || drop_p < 0.f || drop_p >= 1.f ||
+        !salsa_nn_conv3x3_c64_stats_blocks(N, H, W))
+        return -1;
+    const unsigned nb = (unsigned)salsa_nn_conv3x3_c64_stats_blocks(N, H, W);
+#if CONV_ASYNC
+    const C64Plan pl = c64_plan(N, H, W, TH, TW);
+    const XformArgs xf = {mean, invstd, gamma, beta, drop_args(drop_p, drop_seed)};
+    hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<false, true, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const unsigned short *)x1, (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, (const float *)nullptr,
+                       (const unsigned short *)nullptr, 0, stats_part, pl.geo, xf);
 #endif
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
@@ -1005,10 +1093,14 @@ __device__ __forceinline__ void wrw_steps(tr_frag (&fr)[WRW_DEPTH + 1], bf16x8 &
     }
 }
 
+// XF (round 4): x is the RAW output x1 of the convolution before and the operand is a = dropout(relu(batch_norm(x1))), formed in
+// registers between the global load and the LDS write of each piece (this kernel stages through registers): see XformArgs.
+template <bool XF>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned short *__restrict__ x,
                                                                  const unsigned short *__restrict__ dy,
                                                                  float *__restrict__ dw, int N, int H, int W, const Geo geo,
-                                                                 float *__restrict__ part /* deterministic mode: [gridDim.x][64*9*64] */)
+                                                                 float *__restrict__ part /* deterministic mode: [gridDim.x][64*9*64] */,
+                                                                 const XformArgs xf)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xl[WHALO_H * WHALO_W * ROW];
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
@@ -1068,10 +1160,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
     const int n_local = walk.n_local;                // tiles of this workgroup's XCD; `tile` = position in that sequence
     int tile = (int)blockIdx.x / walk.nx;
     TilePos pcur = tile_pos(walk, tile);
+    __shared__ __attribute__((aligned(16))) float xtab[XF ? 2 * 64 : 4]; // XF: scale[64], shift[64]
+    if (XF) {
+        if (tid < 64) {
+            const float sc = xf.invstd[tid] * xf.gamma[tid];
+            xtab[tid] = sc;
+            xtab[64 + tid] = xf.beta[tid] - xf.mean[tid] * sc;
+        }
+    } // (the loop's first __syncthreads() publishes the table)
     if (tile < n_local) fetch(cursor_of(pcur));
     for (; tile < n_local; tile += stride_) {
         __syncthreads(); // the previous tile's LDS reads are done
 #ifndef WRW64_NO_LDSWRITE
+        if (XF) { // a = dropout(relu(x1 * scale + shift)) on the pieces inside the image (outside: the zero padding of the ACTIVATION)
+            const Cursor c = cursor_of(pcur);
+            const int h0 = c.th * WT_H, w0 = c.tw * WT_W;
+            const long origin = geo_off(geo, c.n, h0 - 1, w0 - 1);
+            const int p0 = tid >> 3, piece8 = (tid & 7) * 8;
+            const float4 s0 = *(const float4 *)(xtab + piece8), s1 = *(const float4 *)(xtab + piece8 + 4);
+            const float4 t0 = *(const float4 *)(xtab + 64 + piece8), t1 = *(const float4 *)(xtab + 64 + piece8 + 4);
+            const float xsc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, xsh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int j = 0; j < XP; j++) {
+                const int q = p0 + 32 * j;
+                const int hh = (q * 241) >> 13, ww = q - hh * WHALO_W;
+                const bool ok = q < WHALO_H * WHALO_W && (unsigned)(h0 - 1 + hh) < (unsigned)H && (unsigned)(w0 - 1 + ww) < (unsigned)W;
+                if (ok) {
+                    const long e0 = origin + (long)hh * geo.sh + (long)ww * geo.sw + piece8;
+                    const unsigned in[4] = {px_[j].x, px_[j].y, px_[j].z, px_[j].w};
+                    unsigned out[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float a = fmaxf(__uint_as_float(in[k] << 16) * xsc[2 * k] + xsh[2 * k], 0.f);
+                        float b = fmaxf(__uint_as_float(in[k] & 0xffff0000u) * xsc[2 * k + 1] + xsh[2 * k + 1], 0.f);
+                        if (xf.drop.thresh) {
+                            const unsigned hsh = drop_hash((unsigned)(e0 >> 1) + k, xf.drop.seed);
+                            a = (hsh & 0xFFFFu) >= xf.drop.thresh ? a * xf.drop.scale : 0.f;
+                            b = (hsh >> 16) >= xf.drop.thresh ? b * xf.drop.scale : 0.f;
+                        }
+                        out[k] = pack_bf16(a, b);
+                    }
+                    px_[j] = make_uint4(out[0], out[1], out[2], out[3]);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < XP; j++) {
             const int i = tid + j * 256;
@@ -1133,8 +1265,30 @@ extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * 9 * 64, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv3x3_c64_wrw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
-                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo, part);
+    hipLaunchKernelGGL(conv3x3_c64_wrw_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
+                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo, part, XformArgs{});
+    if (part) return salsa_nn_det_finish(part, (int)nb, 64L * 9 * 64, dw, (hipStream_t)hip_stream);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+// The same with x = the RAW output x1 of the convolution before and the operand a = dropout(relu(batch_norm(x1))) formed on the
+// fly (mean / invstd: the BatchNorm's batch statistics, salsa_nn_bn_train_finalize; drop_p / drop_seed as salsa_nn_bn_train_fwd).
+extern "C" int salsa_nn_conv3x3_c64_wrw_xform(const void *x1, const void *dy, float *dw, const float *mean, const float *invstd,
+                                              const float *gamma, const float *beta, float drop_p, uint32_t drop_seed, int64_t N, int H,
+                                              int W, void *hip_stream)
+{
+    if (!x1 || !dy || !dw || !mean || !invstd || !gamma || !beta || drop_p < 0.f || drop_p >= 1.f || N <= 0 || H <= 0 || W <= 0 ||
+        N * H * W >= INT32_MAX / CH)
+        return -1;
+    const C64Plan pl = c64_plan(N, H, W, WT_H, WT_W);
+    const long tiles = pl.tiles;
+    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
+    int rc = 0;
+    float *part = salsa_nn_det_begin((int)nb, 64L * 9 * 64, (hipStream_t)hip_stream, &rc);
+    if (rc) return rc;
+    const XformArgs xf = {mean, invstd, gamma, beta, drop_args(drop_p, drop_seed)};
+    hipLaunchKernelGGL(conv3x3_c64_wrw_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x1,
+                       (const unsigned short *)dy, dw, (int)N, pl.Hk, pl.Wk, pl.geo, part, xf);
     if (part) return salsa_nn_det_finish(part, (int)nb, 64L * 9 * 64, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

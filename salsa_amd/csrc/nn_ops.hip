@@ -5,6 +5,7 @@
 
 #include "../../include/salsa_nn.h"
 #include "nn_det.h"
+#include "nn_common.h"
 
 namespace {
 
@@ -274,21 +275,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
 // constants for every 16 bytes of payload and become instruction-bound).
 // Dropout fused behind the ReLU: a counter-based hash of the element index decides what is kept, so the backward regenerates
 // the mask instead of reading one.  One 32-bit hash serves two neighbouring elements (16 bits each).
-struct DropArgs {
-    unsigned thresh; // drop when the element's 16 bits < thresh ; 0 = no dropout
-    unsigned seed;
-    float scale;     // 65536 / (65536 - thresh)
-};
-__device__ inline unsigned drop_hash(unsigned pair, unsigned seed)
-{
-    unsigned h = pair * 0x9E3779B1u + seed;
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
-}
 template <int L> __device__ inline void drop_keep(long first_elem, DropArgs d, bool keep[L])
 {
 #pragma unroll
@@ -822,7 +808,9 @@ float *salsa_nn_det_begin(int slabs, long n, hipStream_t st, int *rc)
         *rc = -5;
         return nullptr;
     }
-    if (hipMemsetAsync(g_det_ws, 0, need, st) != hipSuccess) *rc = -6; // (a slab element no workgroup writes must read as zero)
+    // (no clearing pass: every kernel's workgroups cover every element of their slabs -- grids are sized so that no workgroup is
+    // idle -- and the GPU test runs on a NaN-poisoned workspace; a 75-MB memset per call was most of this mode's cost)
+    (void)st;
     return g_det_ws;
 }
 int salsa_nn_det_finish(const float *ws, int slabs, long n, float *dw, hipStream_t st)
@@ -890,17 +878,6 @@ static unsigned bn_apply_blocks(int dtype, int64_t M, int C)
         else hipLaunchKernelGGL((KERNEL<f32x4, 4>), grid, block, 0, st, __VA_ARGS__);                      \
     } while (0)
 
-static DropArgs drop_args(float p, unsigned seed)
-{
-    DropArgs d = {0u, seed, 1.f};
-    if (p > 0.f) {
-        d.thresh = (unsigned)(p * 65536.f + 0.5f);
-        if (d.thresh > 65535u) d.thresh = 65535u;
-        d.scale = 65536.f / (float)(65536u - d.thresh);
-    }
-    return d;
-}
-
 int salsa_nn_bn_supported(int dtype, int64_t M, int C) { return bn_geometry_ok(dtype, M, C); }
 /* bytes of the sums_ws scratch: 2*C float64 sums + one partial pair per reduction block (float64 forward, float32 backward) */
 size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
@@ -931,6 +908,19 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
               (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed));
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+/* Training statistics ONLY (round 4): mean / invstd, running statistics and the batch count from the per-workgroup partial rows
+ * the producing convolution left (stats_part[stats_blocks][2][C] float64) -- no normalisation pass: the CONSUMER of the activation
+ * applies relu(bn(x)) (+ dropout) while it stages its operand (salsa_nn_conv3x3_c64_xform, salsa_nn_conv3x3_c64_wrw_xform). */
+int salsa_nn_bn_train_finalize(const double *stats_part, int stats_blocks, int64_t M, int C, float eps, float momentum,
+                               float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                               int64_t *batches_tracked, void *hip_stream)
+{
+    if (!stats_part || stats_blocks <= 0 || M <= 0 || C <= 0 || !save_mean || !save_invstd) return -1;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)hip_stream, stats_part, stats_blocks, (long)M, C, eps,
+                       momentum, save_mean, save_invstd, running_mean, running_var, (long long *)batches_tracked);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 

@@ -1067,15 +1067,19 @@ def test_deterministic_mode_gives_bit_equal_weight_gradients():
         torch.cuda.synchronize()
         return [p.grad.detach().float().clone() for p in params]
 
-    assert not nn_ops.is_deterministic()
-    base = grads(5)
+    dev = torch.device('cuda', torch.cuda.current_device())
     try:
+        nn_ops.set_deterministic(False)                                          # the atomics, for comparison
+        assert not nn_ops.is_deterministic()
+        base = grads(5)
         nn_ops.set_deterministic(True)
         assert nn_ops.is_deterministic()
-        a, b = grads(5), grads(5)
+        nn_ops._DET_WS[dev].view(torch.float32).fill_(float('nan'))               # (the slabs are never cleared: every element of a slab
+        a = grads(5)                                                             #  is written by its workgroup before it is read)
+        nn_ops._DET_WS[dev].view(torch.float32).fill_(float('nan'))
+        b = grads(5)
     finally:
-        nn_ops.set_deterministic(False)
-    assert not nn_ops.is_deterministic()
+        nn_ops._DET_USER[0] = None                                               # back to the default (on, selected per forward)
     names = [n for n, _ in tr.raw_model.named_parameters()]
     for n, ga, gb, g0 in zip(names, a, b, base):
         assert torch.equal(ga, gb), n                                            # bit-equal, run to run
@@ -1091,3 +1095,4 @@ def test_deterministic_mode_gives_bit_equal_weight_gradients():
             grads(5)
     finally:
         nn_ops.set_deterministic(False)
+        nn_ops._DET_USER[0] = None               # back to the default: the next differentiable forward selects its device's workspace
