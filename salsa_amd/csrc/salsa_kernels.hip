@@ -611,7 +611,13 @@ constexpr int K3_FT = K3_FT_N; // frames per tile; divides TR_CH so a tile's gat
 #ifndef K3_GROUP
 #define K3_GROUP 2
 #endif
-constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins + the zero band above them when it fits
+#ifndef K3_NT_N
+#define K3_NT_N 128 // threads = bins per workgroup (a multiple of 64: every wave owns one 64-bin group of the tracker's masks).  Measured 256 / 128 / 64:
+                    // cov_eig 0.365 / 0.340 / 0.348 ms, step 1.023 / 1.000 / 1.013 (profiles/r4_ab_notes.txt): the work list of a tile is ~1.5 x 256
+                    // items, so with 256 threads half the waves sat out the second pass at the barrier; two waves share evenly
+#endif
+constexpr int K3_NT = K3_NT_N;
+constexpr int K3_OW = K3_NT + 8; // columns of the LDS output tile: a block's bins + the zero band above them when it fits
 // Tile order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8, each with its own L2), so with
 // tile = blockIdx.x two neighbouring 8-frame tiles -- which share 6 of the 14 spill frames they read -- always sit on
 // different XCDs and the shared frames are fetched from HBM twice.  Runs of K3_XCD_CHUNK consecutive tiles are instead given to
@@ -638,7 +644,7 @@ constexpr int K3_OW = 264; // columns of the LDS output tile: a block's 256 bins
 #define K3_PK_WAVES 4 // waves per SIMD the register allocation is held to (4: 128 VGPRs, 3: 168)
 #endif
 template <bool FEAT, int NHOP, bool FAST = false, bool PK = false>
-__global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
+__global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                       const unsigned *__restrict__ valid32,
                                                       float *__restrict__ out_feat, double *__restrict__ out_eig,
                                                       unsigned char *__restrict__ gate)
@@ -646,8 +652,8 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
     constexpr int G = NHOP >= 0 ? K3_GROUP : 1; // frames per work item (compile-time window only)
     constexpr bool PAIRED = G > 1;
     static_assert(K3_FT % G == 0 && G <= 4 && K3_FT / G <= 16, "work-list entry layout");
-    __shared__ unsigned short list[K3_FT * 256];
-    __shared__ unsigned short slow[FAST ? K3_FT * 256 : 1]; // (frame in tile) << 8 | bin in block
+    __shared__ unsigned short list[K3_FT * K3_NT];
+    __shared__ unsigned short slow[FAST ? K3_FT * K3_NT : 1]; // (frame in tile) << 8 | bin in block
     __shared__ int count, nslow;
     // byte offsets (into the clip's spill) of frames t0 - NHOP .. t0 + K3_FT - 1 + NHOP with np.pad's 'wrap' on the time axis
     // (:43) applied, computed once per workgroup: done per lane and per frame in the work-list loop, the wrap compiled to an
@@ -672,8 +678,8 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
     }
     const int t0 = tile * K3_FT;
     const int nft = Tn - t0 < K3_FT ? Tn - t0 : K3_FT;
-    const int bin0 = blockIdx.z * 256;
-    const int nbc = kp.nd - bin0 < 256 ? kp.nd - bin0 : 256; // bins of this tile
+    const int bin0 = blockIdx.z * K3_NT;
+    const int nbc = kp.nd - bin0 < K3_NT ? kp.nd - bin0 : K3_NT; // bins of this tile
     if (tid == 0) count = 0, nslow = 0;
     if (NHOP >= 0 && tid < K3_FT + 2 * NHOP) {
         int tt = t0 - NHOP + tid;
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
         rowoff[tid] = (unsigned)tt * (16u * 2u * (unsigned)kp.nd);
     }
     if (FEAT) {
-        for (int i = tid; i < 3 * K3_FT * K3_OW / 4; i += 256) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < 3 * K3_FT * K3_OW / 4; i += K3_NT) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float *of = FEAT ? out_feat + ((long)b * kp.OC + 4) * Tn * kp.F : nullptr; // channels 4-6 of this clip, [3][T][F]
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
     const int seg = (FEAT && blockIdx.z == gridDim.z - 1) ? (kp.F - bin0 < K3_OW ? kp.F - bin0 : K3_OW) : nbc;
     if (FEAT && blockIdx.z == gridDim.z - 1 && kp.F - bin0 > K3_OW) { // (wider than the LDS tile: the rest directly)
         const int first = bin0 + K3_OW, tail = kp.F - first;
-        for (int i = tid; i < nft * tail; i += 256) {
+        for (int i = tid; i < nft * tail; i += K3_NT) {
             const int ft = i / tail, f = first + (i - ft * tail);
 #pragma unroll
             for (int c = 0; c < 3; c++) st_off(of, 4u * (unsigned)((c * Tn + t0 + ft) * kp.F + f), 0.f);
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
         // SIMD -- or, held to 128 / 168, into scratch: 0.50 - 0.88 ms against 0.38, profiles/r4_k3_pk_ab.txt.)
         constexpr int NW = 2 * NHOP + 2;
         const unsigned half = 16u * (unsigned)kp.nd;
-        for (int s = tid; s < n; s += 256) {
+        for (int s = tid; s < n; s += K3_NT) {
             const int i = list[s];
             const int ft = 2 * ((i >> 8) & 15), bl = i & 255; // entry = validity of the pair's frames << 12 | pair << 8 | bin
             float4 xa[NW], xc[NW];
@@ -866,7 +872,7 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
             }
         }
     }
-    for (int s = tid; !PK && s < n; s += 256) {
+    for (int s = tid; !PK && s < n; s += K3_NT) {
         const int i = list[s];
         const int t = t0 + G * ((i >> 8) & 15); // entry = validity of the group's frames << 12 | group << 8 | bin
         const int bin = bin0 + (i & 255);
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
     if (FAST) { // cold loop: the few gated bins the hot loop could not finish, general path, one frame per item
         __syncthreads();
         const int ns = nslow;
-        for (int s = tid; s < ns; s += 256) {
+        for (int s = tid; s < ns; s += K3_NT) {
             const int i = slow[s];
             const int t = t0 + (i >> 8), bin = bin0 + (i & 255);
             const float4 *xb = xclip + bin;
@@ -944,12 +950,12 @@ __global__ __launch_bounds__(256, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(cons
         const bool vec = !(kp.F & 3) && !(seg & 3) && !(bin0 & 3); // rows start and end on 16-byte boundaries
         if (vec) {
             const int q = seg >> 2;
-            for (int i = tid; i < 3 * nft * q; i += 256) {
+            for (int i = tid; i < 3 * nft * q; i += K3_NT) {
                 const int row = i / q, col = i - row * q, c = row / nft, ft = row - c * nft;
                 *(float4 *)(of + ((long)(c * Tn + t0 + ft) * kp.F + bin0 + 4 * col)) = *(const float4 *)(otile + (c * K3_FT + ft) * K3_OW + 4 * col);
             }
         } else {
-            for (int i = tid; i < 3 * nft * seg; i += 256) {
+            for (int i = tid; i < 3 * nft * seg; i += K3_NT) {
                 const int row = i / seg, col = i - row * seg, c = row / nft, ft = row - c * nft;
                 of[(long)(c * Tn + t0 + ft) * kp.F + bin0 + col] = otile[(c * K3_FT + ft) * K3_OW + col];
             }
@@ -964,13 +970,13 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
     const bool gated = kp.tracking || kp.flex; // (!ungated: the coherence test decides, so passing bins have a spectral gap)
     // (the packed pair solve: feature output only -- salsa_eigvec_batch keeps float64 results -- and never for contrib's variant)
     if (FEAT && SALSA_PK && K3_GROUP == 2 && kp.n_hop == 3 && gated && SALSA_COL0 && !kp.flex && kp.cond > 1.0 && kp.cond < 1e6)
-        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true, FEAT && K3_GROUP == 2>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true, FEAT && K3_GROUP == 2>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else if (kp.n_hop == 3 && gated && SALSA_COL0)
-        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else if (kp.n_hop == 3)
-        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else
-        hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(256), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+        hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
 }
 
 // ------------------------------------------------------------------------------------------------------------ K3, N channels
@@ -1690,7 +1696,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         if (two && s1 != s2) HIP_TRY(hipStreamWaitEvent(s2, after_second, 0));
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
-        dim3 grid(ntile, (unsigned)gp.B, (unsigned)((gp.nd + 255) / 256));
+        dim3 grid(ntile, (unsigned)gp.B, (unsigned)((gp.nd + K3_NT - 1) / K3_NT));
         for (int r = 0; r < reps; r++) launch_cov_eig<true>(gp, grid, s2, xs, vm, o, (double *)nullptr, (unsigned char *)nullptr);
         mark_end(pl, s2, m);
         HIP_TRY(hipGetLastError());
@@ -1871,7 +1877,7 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
         HIP_TRY(hipGetLastError());
     }
     const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);
-    dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + 255) / 256));
+    dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + K3_NT - 1) / K3_NT));
     launch_cov_eig<false>(kp, grid, s, Xs, valid, (float *)nullptr, d_out, d_gate);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
