@@ -333,7 +333,13 @@ def main():
             if tj.get('batch_clips_per_launch') == args.batch and args.feature == 'salsa' and abs(args.seconds - 60) < 1e-9:
                 traffic = {k: v['hbm_bytes'] for k, v in tj['kernels'].items()}
                 valu = {k: v.get('valu_util') for k, v in tj['kernels'].items()}
-                traffic_src = 'offline PMC: profiles/traffic.json (%s), rocprofv3 --pmc passes of the same kernels on another run' % tj.get('source', 'tools/pmc_round.sh')
+                import hashlib
+                ksha = hashlib.sha256(b''.join(open(os.path.join(ROOT, 'salsa_amd', 'csrc', f), 'rb').read()
+                                               for f in ('salsa_kernels.hip', 'salsa_math.h'))).hexdigest()[:16]
+                fresh = tj.get('kernel_sources_sha16') == ksha
+                traffic_src = ('offline PMC: profiles/traffic.json, commit %s, %s; rocprofv3 --pmc passes (%s) of the same kernels on another run'
+                               % (tj.get('commit'), 'taken at EXACTLY the kernel sources this run executes' if fresh else
+                                  'STALE: the kernel sources changed since the counters were taken', tj.get('source', 'tools/pmc_round.sh')))
         except Exception:
             pass
         for k in kernels:

@@ -8,7 +8,8 @@ no factor (720 000 KiB written reports 720 000; the STFT kernel's row writes rep
 Also derives each kernel's VALU utilisation = SQ_ACTIVE_INST_VALU (quad-cycles, summed over the chip's SIMDs) x 4 /
 (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the fraction of SIMD cycles in which a vector instruction was executing -- for these
 float64 kernels the "what bounds it besides HBM" figure SURVEY section 8(d) asks for.
-usage: tools/pmc_traffic.py profiles/r1_v7_pmc_summary.csv [batch] [older_summary.csv]
+usage: tools/pmc_traffic.py profiles/r1_v7_pmc_summary.csv [batch] [older_summary.csv]   (run in the build container right after the
+counter passes: stamps the commit and a hash of salsa_kernels.hip + salsa_math.h, which bench.py compares with the sources it runs)
 (a counter missing from the first summary -- a pass that timed out -- is taken from the older one and named in 'source')"""
 import csv
 import json
@@ -21,11 +22,20 @@ name = {'stft_kernel': 'stft_logspec', 'tracker_kernel': 'noise_floor_tracker', 
 acc, origin = {}, {}
 for path in [src] + sys.argv[3:4]:
     for row in csv.DictReader(open(path)):
-        k = name.get(row['kernel'])
+        k = next((v for kk, v in name.items() if row['kernel'].startswith(kk)), None)   # (summaries may keep the template arguments)
         if k and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU') and row['counter'] not in acc.get(k, {}):
             acc.setdefault(k, {})[row['counter']] = float(row['mean_per_dispatch'])
             origin[row['counter']] = os.path.basename(path)
-out = {'source': ', '.join('%s from %s' % (c, f) for c, f in sorted(origin.items())), 'batch_clips_per_launch': batch, 'correction': 'FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1; valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
+import hashlib
+import subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:
+    commit = subprocess.check_output(['git', '-C', ROOT, 'rev-parse', '--short=12', 'HEAD']).decode().strip()
+except Exception:
+    commit = None
+ksha = hashlib.sha256(b''.join(open(os.path.join(ROOT, 'salsa_amd', 'csrc', f), 'rb').read() for f in ('salsa_kernels.hip', 'salsa_math.h'))).hexdigest()[:16]
+out = {'source': ', '.join('%s from %s' % (c, f) for c, f in sorted(origin.items())), 'batch_clips_per_launch': batch,
+       'commit': commit, 'kernel_sources_sha16': ksha, 'correction': 'FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1; valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
        'kernels': {}}
 for k, v in acc.items():
     rd, wr = v.get('FETCH_SIZE', 0) * 1024 * 2, v.get('WRITE_SIZE', 0) * 1024
