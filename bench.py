@@ -379,7 +379,7 @@ def main():
                     'peak_measured_note': '1 GiB device-to-device copy, read + write bytes / time',
                     'dominant': {'kernel': dom['name'], 'ms_per_launch': dom['ms_per_launch'], 'achieved': dom['GBps'],
                                  'frac': dom['frac'], 'traffic': dom.get('traffic')},
-                    'secondary_bound': {'unit': 'fraction of float64 VALU issue cycles (peak %.1f TFLOP/s)' % F64_VALU_PEAK_TFLOPS,
+                    'secondary_bound': {'unit': 'fraction of SIMD cycles issuing a VALU instruction (float64 in the STFT and the tracker: peak %.1f TFLOP/s; packed float32 in cov_eig since round 4)' % F64_VALU_PEAK_TFLOPS,
                                         'per_kernel': {k['name']: k['f64_valu_util'] for k in kernels}},
                     'kernels': kernels}
         if args.streams > 1:

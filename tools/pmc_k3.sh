@@ -18,7 +18,7 @@ out='$OUT'
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(out+'/p*/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):
-        k=row['Kernel_Name'].replace('void ','').replace('(anonymous namespace)::','').split('(')[0][:60]
+        k=row['Kernel_Name'].replace('void ','').replace('(anonymous namespace)::','').split('(')[0].split('<')[0]
         agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
 with open(out+'/pmc_summary.csv','w') as fo:
     fo.write('kernel,counter,mean_per_dispatch,n\n')

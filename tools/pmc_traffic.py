@@ -21,7 +21,12 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 name = {'stft_kernel': 'stft_logspec', 'tracker_kernel': 'noise_floor_tracker', 'cov_eig_kernel': 'cov_eig'}
 acc, origin = {}, {}
 for path in [src] + sys.argv[3:4]:
-    for row in csv.DictReader(open(path)):
+    rows = []
+    for ln in open(path).read().splitlines()[1:]:            # kernel names may carry commas (template arguments): split from the right
+        parts = ln.rsplit(',', 3)
+        if len(parts) == 4:
+            rows.append({'kernel': parts[0], 'counter': parts[1], 'mean_per_dispatch': parts[2]})
+    for row in rows:
         k = next((v for kk, v in name.items() if row['kernel'].startswith(kk)), None)   # (summaries may keep the template arguments)
         if k and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU') and row['counter'] not in acc.get(k, {}):
             acc.setdefault(k, {})[row['counter']] = float(row['mean_per_dispatch'])
