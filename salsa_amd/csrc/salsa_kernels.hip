@@ -444,12 +444,19 @@ constexpr int TR_BINS = 32;
 // VCC needs two wait states before v_writelane may read it, and only the compiler's hazard recogniser inserts them -- the
 // hand-written form read stale masks in 0.7 % of the frames.
 extern "C" __device__ int salsa_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
-static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + TR_BINS - 1) / TR_BINS)); }
+// TR_WIDE (round-3 review: "give the consumer 64 distinct bins per wave and report what that does"): a workgroup serves 64 bins,
+// lanes 32-63 run bins 32-63 instead of mirroring lanes 0-31, a frame's ballot is two mask words.  Measured (profiles/r4_ab_notes.txt):
+// see there; the mask layout valid32[b][32-bin group][t] is unchanged.
+#ifndef TR_WIDE
+#define TR_WIDE 0
+#endif
+constexpr int TR_WG_BINS = TR_WIDE ? 64 : TR_BINS;
+static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.nd + TR_WG_BINS - 1) / TR_WG_BINS)); }
 
 __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                                 unsigned *__restrict__ valid32)
 {
-    constexpr int BINS = TR_BINS, FS = 64 / BINS;                                         // FS frames per producer instruction
+    constexpr int BINS = TR_WG_BINS, FS = 64 / BINS;                                      // FS frames per producer instruction
     constexpr bool IDLE4 = TR_WAVES > 4 && TR_IDLE4;                                     // wave 4 shares the consumer's SIMD: keep it idle
     constexpr int NPROD = IDLE4 ? TR_WAVES - 2 : TR_WAVES - 1;
     constexpr int PER_ALL = (TR_CH + TR_WAVES * FS - 1) / (TR_WAVES * FS);               // prologue: all waves produce chunk 0
@@ -483,7 +490,9 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     double fl = 0.0;
     int cd = 3;
     const double snr = kp.snr_ratio;
-    unsigned *vout = valid32 + ((long)b * ng32 + g) * Tn; // [b][32-bin group][t]
+    const int n32 = (kp.nd + TR_BINS - 1) / TR_BINS;      // 32-bin mask groups of a clip
+    unsigned *vout = valid32 + ((long)b * n32 + (TR_WIDE ? 2 * g : g)) * Tn; // [b][32-bin group][t]
+    unsigned *vout_hi = (TR_WIDE && 2 * g + 1 < n32) ? vout + Tn : nullptr;     // TR_WIDE: the group of bins 32-63 of this workgroup
 #if TR_MASK_HISTORY
     // Round 3: the countdown never becomes a per-lane value either.  "countdown < 1 before this step's decrement" (:68-69: the
     // slow rise) holds exactly when the three steps before this one were all `above` (the countdown starts at 3, every `above`
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
             fl = 0.5 * (acc / (double)n0);
             if (kp.flex && fl < 1e-6) fl = 1e-6; // contrib's tracker clamps its initial floor (:118-120)
         }
-        unsigned word = 0; // lane i: indicator_sig mask (bit j = bin 32 g + j) of frame 64 c + i
+        unsigned word = 0, word_hi = 0; // lane i: indicator_sig mask (bit j = bin 32 g + j) of frame 64 c + i (TR_WIDE: + bins 32-63)
         const int nfr = Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH; // wave-uniform
         if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
 #pragma unroll
@@ -558,6 +567,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                 for (int i = 0; i < 16; i++) {
                     const unsigned long long bal = step(m[i]);
                     word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
+                    if (TR_WIDE) word_hi = (unsigned)salsa_writelane_i32((int)(unsigned)(bal >> 32), i0 + i, (int)word_hi);
                 }
 #endif
             }
@@ -565,9 +575,11 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
             for (int i = 0; i < nfr; i++) {
                 const unsigned long long bal = step(cur[i * BINS]);
                 word = lane == i ? (unsigned)bal : word; // (ragged last chunk only)
+                if (TR_WIDE) word_hi = lane == i ? (unsigned)(bal >> 32) : word_hi;
             }
         }
         if (lane < nfr) vout[c * TR_CH + lane] = word;
+        if (TR_WIDE && vout_hi && lane < nfr) vout_hi[c * TR_CH + lane] = word_hi;
     };
     // producers, iteration c: issue the loads of chunk c+2 into `nxt`, turn `now` (chunk c+1, loaded an iteration ago) into
     // magnitudes in the ring half the consumer is not reading
