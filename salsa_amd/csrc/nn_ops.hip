@@ -627,30 +627,32 @@ __global__ __launch_bounds__(256) void freq_mean_bwd_kernel(const float *__restr
 
 // ------------------------------------------------------------------------------------------------ deterministic reductions
 // dw[i] += sum over the slabs of ws[slab][i], in a FIXED order (what makes the result reproducible; it need not be slab order): a
-// workgroup owns 64 consecutive elements (16 threads x float4) and its 16 slab lanes each add every 16th slab in ascending order,
-// then the 16 partial sums are added in lane order.  (First version: one thread per four elements walking all slabs -- 4 to 36
+// workgroup owns 4 * 256 / SL consecutive elements and its SL slab lanes each add every SL-th slab in ascending order, then the SL
+// partial sums are added in lane order.  (First version: one thread per four elements walking all slabs -- 4 to 36
 // workgroups for the first layer's 1280 slabs and the 64 -> 64 layers' 384: 138 / 33 us per call.)
+template <int SL> // slab lanes per workgroup (16: many slabs -- the 64 -> 64 and first-layer gradients; 4: the wide layers' 4 - 64 slabs)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int slabs, long n, float *__restrict__ dw)
 {
-    __shared__ float4 red[16][16];
-    const int ex = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long i = ((long)blockIdx.x * 16 + ex) * 4;
+    constexpr int EX = 256 / SL;
+    __shared__ float4 red[SL][EX];
+    const int ex = threadIdx.x % EX, sl = threadIdx.x / EX;
+    const long i = ((long)blockIdx.x * EX + ex) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i + 3 < n) {
         int s = sl;
-        for (; s + 48 < slabs; s += 64) { // four loads in flight; the additions keep their order
-            const float4 a = *(const float4 *)(ws + (long)s * n + i), b = *(const float4 *)(ws + (long)(s + 16) * n + i);
-            const float4 c = *(const float4 *)(ws + (long)(s + 32) * n + i), d = *(const float4 *)(ws + (long)(s + 48) * n + i);
+        for (; s + 3 * SL < slabs; s += 4 * SL) { // four loads in flight; the additions keep their order
+            const float4 a = *(const float4 *)(ws + (long)s * n + i), b = *(const float4 *)(ws + (long)(s + SL) * n + i);
+            const float4 c = *(const float4 *)(ws + (long)(s + 2 * SL) * n + i), d = *(const float4 *)(ws + (long)(s + 3 * SL) * n + i);
             acc.x = (((acc.x + a.x) + b.x) + c.x) + d.x; acc.y = (((acc.y + a.y) + b.y) + c.y) + d.y;
             acc.z = (((acc.z + a.z) + b.z) + c.z) + d.z; acc.w = (((acc.w + a.w) + b.w) + c.w) + d.w;
         }
-        for (; s < slabs; s += 16) {
+        for (; s < slabs; s += SL) {
             const float4 a = *(const float4 *)(ws + (long)s * n + i);
             acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
         }
     } else if (i < n) { // (n not a multiple of 4: the last elements one by one)
         float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int s = sl; s < slabs; s += 16)
+        for (int s = sl; s < slabs; s += SL)
             for (int k = 0; k < 4 && i + k < n; k++) t[k] += ws[(long)s * n + i + k];
         acc = make_float4(t[0], t[1], t[2], t[3]);
     }
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
     if (sl == 0 && i < n) {
         float4 t = red[0][ex];
 #pragma unroll
-        for (int k = 1; k < 16; k++) {
+        for (int k = 1; k < SL; k++) {
             const float4 v = red[k][ex];
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
@@ -826,7 +828,8 @@ float *salsa_nn_det_begin(int slabs, long n, hipStream_t st, int *rc)
 }
 int salsa_nn_det_finish(const float *ws, int slabs, long n, float *dw, hipStream_t st)
 {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, slabs, n, dw);
+    if (slabs > 16) hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, slabs, n, dw);
+    else hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, slabs, n, dw);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
