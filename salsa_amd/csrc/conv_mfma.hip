@@ -860,10 +860,14 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
                                                                long x_channel_stride, const float *__restrict__ shift, int relu,
                                                                double *__restrict__ stats_part)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short xs[SHALO_H * HALO_W * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short xs2[2][SHALO_H * HALO_W * 8]; // double-buffered halo tile (round 4)
     __shared__ __attribute__((aligned(16))) unsigned short ys[4 * TW * ROW]; // per wave: one output row, [pixel][ROW]
+    __shared__ __attribute__((aligned(16))) float shs[64]; // the folded-BatchNorm shift (inference), read from LDS in the epilogue: as
+                                                           // global loads inside the tile loop they were 16 DEPENDENT round trips per
+                                                           // tile (`global_load_dwordx4; s_waitcnt vmcnt(0)` per channel group and row)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = lane & 31, khalf = lane >> 5;
+    if (tid < 64) shs[tid] = shift ? shift[tid] : 0.f; // (the first barrier of the tile loop publishes it)
     bf16x8 af[5][2]; // [K step][co half]: filter row co = 32*mt + (lane&31), tap 2*step + khalf, its 8 channels
 #pragma unroll
     for (int ks = 0; ks < 5; ks++)
@@ -872,30 +876,66 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
     const int tiles_w = (W + TW - 1) / TW, tiles_h = (H + STH - 1) / STH;
     const long n_tiles = (long)N * tiles_h * tiles_w;
     float rs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, rq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    if (tile != (long)blockIdx.x) __syncthreads(); // the previous tile's reads of xs are done
+    // Round 4.  Counters on the round-3 kernel (tools/probes/pmc_probe.sh): waves spent 65 % of their cycles waiting with the
+    // VALU 25 % and the matrix pipe 8 % busy, at ~2 resident waves per SIMD.  What they waited for: __syncthreads() is a fence + a
+    // barrier, i.e. `s_waitcnt vmcnt(0)` -- twice per tile every wave sat out the acknowledgement of the 32 KB it had just
+    // STORED (and, at the top of a tile, the whole latency of the halo loads it had just issued).  Now: the launch is persistent
+    // in both variants; the halo tile is double-buffered in LDS; the barriers are raw `s_barrier`s behind `s_waitcnt lgkmcnt(0)`
+    // (LDS visibility is all they have to order); and a tile's global loads are issued TWO tiles ahead and converted into the
+    // other LDS buffer between the MFMAs and the epilogue of the tile before -- the one place where everything older in the
+    // memory queue (the loads themselves, one tile old, and the stores of the tile before that) has long retired, so the
+    // compiler's vmcnt(0) in front of the conversion costs nothing and no wait ever follows a store.
+    constexpr int SPF = (SHALO_H * HALO_W + 255) / 256; // halo pixels per thread
+    float pv[SPF][8];
+    bool pin[SPF];
+    auto prefetch = [&](long tile) {
+        const int tw = (int)(tile % tiles_w);
+        const int th = (int)((tile / tiles_w) % tiles_h);
+        const long n = tile / ((long)tiles_w * tiles_h);
+        const float *xn = x + n * x_batch_stride;
+#pragma unroll
+        for (int j = 0; j < SPF; j++) { // neighbouring lanes = neighbouring columns: every plane's loads coalesce
+            const int p = tid + j * 256;
+            const int hh = p / HALO_W, ww = p - hh * HALO_W;
+            const int h = th * STH + hh - 1, wcol = tw * TW + ww - 1;
+            pin[j] = p < SHALO_H * HALO_W && h >= 0 && h < H && wcol >= 0 && wcol < W;
+            const float *src = xn + (pin[j] ? (long)h * W + wcol : 0);
+#pragma unroll
+            for (int c = 0; c < 8; c++) { // unconditional (valid) loads.  NOT `c < Cin ? c * stride : 0`: the compiler then re-used the
+                const int cc = c < Cin ? c : Cin - 1; // c = 0 load for the planes beyond Cin behind a `s_waitcnt vmcnt(0)` -- a full
+                pv[j][c] = src[cc * x_channel_stride]; // memory round trip in the middle of every prefetch
+            }
+        }
+    };
+    auto convert = [&](int buf) { // registers -> bf16 [pixel][8 channels] in LDS: one 16-byte write packs a pixel
+#pragma unroll
+        for (int j = 0; j < SPF; j++) {
+            const int p = tid + j * 256;
+            uint4 pk;
+            pk.x = pack_bf16((pin[j] && 0 < Cin) ? pv[j][0] : 0.f, (pin[j] && 1 < Cin) ? pv[j][1] : 0.f);
+            pk.y = pack_bf16((pin[j] && 2 < Cin) ? pv[j][2] : 0.f, (pin[j] && 3 < Cin) ? pv[j][3] : 0.f);
+            pk.z = pack_bf16((pin[j] && 4 < Cin) ? pv[j][4] : 0.f, (pin[j] && 5 < Cin) ? pv[j][5] : 0.f);
+            pk.w = pack_bf16((pin[j] && 6 < Cin) ? pv[j][6] : 0.f, (pin[j] && 7 < Cin) ? pv[j][7] : 0.f);
+            if (p < SHALO_H * HALO_W) *(uint4 *)(xs2[buf] + p * 8) = pk;
+        }
+    };
+#define STEM_BARRIER()                                       \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+    } while (0)
+    if ((long)blockIdx.x < n_tiles) {
+        prefetch(blockIdx.x);
+        convert(0);
+        if ((long)blockIdx.x + gridDim.x < n_tiles) prefetch((long)blockIdx.x + gridDim.x);
+    }
+    int it = 0;
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, it++) {
+    STEM_BARRIER(); // tile's LDS copy is complete (every wave's part), and the other buffer's readers (the tile before) are done
+    const unsigned short *xs = xs2[it & 1];
     const int tw = (int)(tile % tiles_w);
     const int th = (int)((tile / tiles_w) % tiles_h);
     const long n = tile / ((long)tiles_w * tiles_h);
-    const float *xn = x + n * x_batch_stride;
-    for (int p = tid; p < SHALO_H * HALO_W; p += 256) { // a thread = one halo pixel (neighbouring lanes, neighbouring columns):
-        const int hh = p / HALO_W, ww = p - hh * HALO_W; // its Cin loads go out together, one 16-byte LDS write packs them
-        const int h = th * STH + hh - 1, wcol = tw * TW + ww - 1;
-        const bool inside = h >= 0 && h < H && wcol >= 0 && wcol < W;
-        const float *src = xn + (inside ? (long)h * W + wcol : 0);
-        float v[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = src[c < Cin ? c * x_channel_stride : 0]; // unconditional (valid) loads, no branches
-#pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = (inside && c < Cin) ? v[c] : 0.f;
-        uint4 pk;
-        pk.x = pack_bf16(v[0], v[1]);
-        pk.y = pack_bf16(v[2], v[3]);
-        pk.z = pack_bf16(v[4], v[5]);
-        pk.w = pack_bf16(v[6], v[7]);
-        *(uint4 *)(xs + p * 8) = pk;
-    }
-    __syncthreads();
     f32x16 acc[2][2];
 #pragma unroll
     for (int rr = 0; rr < 2; rr++)
@@ -912,6 +952,10 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
             for (int mt = 0; mt < 2; mt++) acc[rr][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mt], b, acc[rr][mt], 0, 0, 0);
         }
     }
+    if (tile + gridDim.x < n_tiles) { // the next tile: its loads are one tile old -> the other LDS buffer; then the loads of the tile after
+        convert((it + 1) & 1);
+        if (tile + 2 * (long)gridDim.x < n_tiles) prefetch(tile + 2 * (long)gridDim.x);
+    }
     // Epilogue.  D gives a lane four groups of four consecutive output channels of ONE pixel: stored directly that is 8-byte
     // pieces, 16 store instructions per 128-byte pixel.  Each wave turns its row around through a private LDS strip
     // ([pixel][64 co], rows padded to 144 bytes) instead and writes 16 bytes per lane, 8 lanes per pixel: every store
@@ -925,7 +969,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
             for (int g = 0; g < 4; g++) { // D rows (reg&3) + 8*(reg>>2) + 4*(lane>>5): four consecutive output channels
                 float v4[4] = {acc[rr][mt][4 * g], acc[rr][mt][4 * g + 1], acc[rr][mt][4 * g + 2], acc[rr][mt][4 * g + 3]};
                 if (shift) {
-                    const float4 sh = *(const float4 *)(shift + 32 * mt + 4 * khalf + 8 * g);
+                    const float4 sh = *(const float4 *)(shs + 32 * mt + 4 * khalf + 8 * g);
                     v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
                     if (relu) {
 #pragma unroll
@@ -985,6 +1029,9 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
 
 } // namespace
 
+#ifndef STEM_FWD_GRID
+#define STEM_FWD_GRID 1536
+#endif
 /* number of partial rows salsa_nn_conv3x3_stem_stats writes (= its persistent workgroup count) */
 extern "C" int salsa_nn_conv3x3_stem_stats_blocks(int64_t N, int H, int W)
 {
@@ -1019,7 +1066,8 @@ extern "C" int salsa_nn_conv3x3_stem(const float *x, int64_t x_batch_stride, int
         return -1;
     const long tiles = (long)N * ((H + STH - 1) / STH) * ((W + TW - 1) / TW);
     if (tiles >= INT32_MAX) return -1;
-    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)hip_stream, x,
+    const unsigned nb = (unsigned)(tiles >= STEM_FWD_GRID ? STEM_FWD_GRID : tiles); // persistent: six workgroups per CU
+    hipLaunchKernelGGL(conv3x3_stem_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x,
                        (const unsigned short *)wq, (unsigned short *)y, (int)N, Cin, H, W, (long)x_batch_stride, (long)x_channel_stride,
                        shift, relu, (double *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -6;

@@ -126,7 +126,7 @@ template <bool LITE> struct k1_cfg {
 };
 
 template <int N, typename T, bool LITE, int NF, int NPAIRS = 2>
-__global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+__global__ __launch_bounds__(256, LITE ? 1 : 3) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
@@ -149,6 +149,15 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     // the window (pre-scaled by the unpack's exact 1/2) is shared by the block's waves through LDS.
     __shared__ T wins[N];
     for (int i = threadIdx.x; i < N; i += 256) wins[i] = (T)(0.5 * window[i]);
+    // the fused scaler's [4][F] mean / std tables, read from LDS in the store path (round 4: as global loads next to every store
+    // they were a `global_load; global_load; s_waitcnt vmcnt(0)` per value -- eight exposed L2 round trips per item)
+    __shared__ float sct[2][4 * (N / 2)];
+    if (kp.sc_mean) {
+        for (int i = threadIdx.x; i < 4 * kp.F; i += 256) {
+            sct[0][i] = kp.sc_mean[i];
+            sct[1][i] = kp.sc_std[i];
+        }
+    }
     __syncthreads(); // the only workgroup barrier, before any wave-uniform exit
     cplx<T> w1[NP];
     {
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const KParams kp, const float
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
         const float v = db10(p);
-        const unsigned off = 4u * (unsigned)(c * kp.F + f);
-        return kp.sc_mean ? (v - ld_off(kp.sc_mean, off)) / ld_off(kp.sc_std, off) : v;
+        const int i = c * kp.F + f;
+        return kp.sc_mean ? (v - sct[0][i]) / sct[1][i] : v;
     };
     const unsigned plane = 4u * (unsigned)(Tn * kp.F); // bytes of one output channel of a clip
     float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
