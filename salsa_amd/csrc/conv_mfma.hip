@@ -73,6 +73,15 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
         const bool inside = h0 < H && wcol < W;
         uint2 pk[4];
+        uint2 rvp[RPW][4];
+        if (residual) { // (all eight pieces requested together: see the plain epilogue below)
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++) {
+                const long roff = geo_off(geo, n, inside ? h0 + rr : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; g++) rvp[rr][g] = *(const uint2 *)(residual + roff + 8 * g);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -81,8 +90,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
             for (int rr = 0; rr < RPW; rr++) {
                 float v4[4] = {acc[rr][4 * g] + sh.x, acc[rr][4 * g + 1] + sh.y, acc[rr][4 * g + 2] + sh.z, acc[rr][4 * g + 3] + sh.w};
                 if (residual) {
-                    const long roff = geo_off(geo, n, inside ? h0 + rr : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
-                    const uint2 rv = *(const uint2 *)(residual + roff + 8 * g);
+                    const uint2 rv = rvp[rr][g];
                     v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
                     v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
                 }
@@ -115,6 +123,13 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         const bool inside = h < H && wcol < W;      // (the same for both lanes of a pair: they share the pixel)
         const long off = geo_off(geo, n, inside ? h : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
         uint2 pk[4];
+        // (round 4: the row's four residual pieces are requested together -- fetched inside the g loop the compiler waited
+        // `vmcnt(0)` after each one: four dependent round trips per row, in inference and in the data gradients that add a skip branch)
+        uint2 rvq[4] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+        if (shift && residual) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) rvq[g] = *(const uint2 *)(residual + off + 8 * g);
+        }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             float v4[4] = {acc[rr][4 * g], acc[rr][4 * g + 1], acc[rr][4 * g + 2], acc[rr][4 * g + 3]};
@@ -122,7 +137,7 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
                 const float4 sh = shv[g];
                 v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
                 if (residual) {
-                    const uint2 rv = *(const uint2 *)(residual + off + 8 * g);
+                    const uint2 rv = rvq[g];
                     v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
                     v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
                 }

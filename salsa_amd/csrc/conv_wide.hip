@@ -300,14 +300,31 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             uint2 pk[4];
+            // Round 4: the co-tile's four shift vectors and four residual pieces are requested TOGETHER, before any is used.  Fetched
+            // next to their use (inside the g loop, behind the `if`s) the compiler waited `vmcnt(0)` after every single load:
+            // 64 dependent memory round trips at the end of every workgroup, in the inference epilogue AND in the training
+            // step's data gradients that add the skip branch's gradient (tools/asm_serial_loads.py).
+            float4 shq[4];
+            uint2 rvq[4];
+            if (shift) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) shq[g] = *(const float4 *)(shift + co0 + 4 * khalf + ct * 32 + 8 * g);
+                if (residual) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) rvq[g] = *(const uint2 *)(residual + off + ct * 32 + 8 * g);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) rvq[g] = make_uint2(0u, 0u);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 float v4[4] = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
                 if (shift) {
-                    const float4 sh = *(const float4 *)(shift + co0 + 4 * khalf + ct * 32 + 8 * g);
+                    const float4 sh = shq[g];
                     v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-                    if (residual) {
-                        const uint2 rv = *(const uint2 *)(residual + off + ct * 32 + 8 * g);
+                    {
+                        const uint2 rv = rvq[g]; // (+0.0f when there is no residual)
                         v4[0] += __uint_as_float(rv.x << 16); v4[1] += __uint_as_float(rv.x & 0xffff0000u);
                         v4[2] += __uint_as_float(rv.y << 16); v4[3] += __uint_as_float(rv.y & 0xffff0000u);
                     }

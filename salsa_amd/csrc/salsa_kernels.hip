@@ -125,8 +125,11 @@ template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : 4;
 };
 
-template <int N, typename T, bool LITE, int NF, int NPAIRS = 2>
-__global__ __launch_bounds__(256, LITE ? 1 : 3) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+// SC (round 4): the instantiation launched when a scaler is attached keeps the [4][F] mean / std tables in LDS.  It is a separate
+// instantiation because the 8 KB of LDS and the 168-register cap cost the plain path 4 % (0.458 -> 0.477 ms) when they were
+// unconditional; SC = false is the round-3 kernel, bit for bit (and still honours a scaler, through global loads).
+template <int N, typename T, bool LITE, int NF, int NPAIRS = 2, bool SC = false>
+__global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
@@ -151,11 +154,12 @@ __global__ __launch_bounds__(256, LITE ? 1 : 3) void stft_kernel(const KParams k
     for (int i = threadIdx.x; i < N; i += 256) wins[i] = (T)(0.5 * window[i]);
     // the fused scaler's [4][F] mean / std tables, read from LDS in the store path (round 4: as global loads next to every store
     // they were a `global_load; global_load; s_waitcnt vmcnt(0)` per value -- eight exposed L2 round trips per item)
-    __shared__ float sct[2][4 * (N / 2)];
-    if (kp.sc_mean) {
+    extern __shared__ float sct_dyn[]; // SC only: [2][4 * N / 2] floats of DYNAMIC LDS (the launch passes the size), so that the plain
+    float *sct0 = sct_dyn, *sct1 = sct_dyn + 4 * (N / 2); // instantiation's static LDS layout is untouched: even an 8-byte dummy
+    if (SC && kp.sc_mean) {                               // array here moved the other arrays and cost the STFT 2.5 %
         for (int i = threadIdx.x; i < 4 * kp.F; i += 256) {
-            sct[0][i] = kp.sc_mean[i];
-            sct[1][i] = kp.sc_std[i];
+            sct0[i] = kp.sc_mean[i];
+            sct1[i] = kp.sc_std[i];
         }
     }
     __syncthreads(); // the only workgroup barrier, before any wave-uniform exit
@@ -231,8 +235,12 @@ __global__ __launch_bounds__(256, LITE ? 1 : 3) void stft_kernel(const KParams k
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
         const float v = db10(p);
-        const int i = c * kp.F + f;
-        return kp.sc_mean ? (v - sct[0][i]) / sct[1][i] : v;
+        if (SC) {
+            const int i = c * kp.F + f;
+            return kp.sc_mean ? (v - sct0[i]) / sct1[i] : v;
+        }
+        const unsigned off = 4u * (unsigned)(c * kp.F + f);
+        return kp.sc_mean ? (v - ld_off(kp.sc_mean, off)) / ld_off(kp.sc_std, off) : v;
     };
     const unsigned plane = 4u * (unsigned)(Tn * kp.F); // bytes of one output channel of a clip
     float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
@@ -598,6 +606,22 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
         tracker_mag<PER_PROD, BINS>(now, pfirst, ring[(c + 1) & 1], col, raw);
     };
     // (probe builds: TR_PROBE_NO_CONSUME / TR_PROBE_NO_PRODUCE drop one role -- wrong results, the other role's time)
+    // Round 4 experiment (TR_RAW_BARRIER 1): the chunk barriers order LDS traffic only (the ring), so they could be
+    // `s_waitcnt lgkmcnt(0); s_barrier` instead of __syncthreads() -- a fence + barrier = `s_waitcnt vmcnt(0)` as well, which makes
+    // every producer sit out the loads it has just issued for the chunk after next and the consumer the acknowledgement of its
+    // 256-byte mask store.  Bit-identical masks, and no faster (see below): kept off.
+#ifndef TR_RAW_BARRIER
+#define TR_RAW_BARRIER 0 // measured: tracker 0.1736 -> 0.1747 ms (event pair), 0.096 -> 0.101 (prefix): no gain -- the chunk time is the consumer's
+#endif                   // 64 dependent steps; the drains it skips were hidden behind them
+
+    auto chunk_barrier = [&]() {
+#if TR_RAW_BARRIER
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
+        __syncthreads();
+#endif
+    };
     for (int c = 0; c < nchunks; c += 2) {
 #ifndef TR_PROBE_NO_CONSUME
         if (w == 0) consume(c);
@@ -605,7 +629,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
 #ifndef TR_PROBE_NO_PRODUCE
         if (w != 0 && producer) produce(c, xa, xb);
 #endif
-        __syncthreads();
+        chunk_barrier();
         if (c + 1 < nchunks) {
 #ifndef TR_PROBE_NO_CONSUME
             if (w == 0) consume(c + 1);
@@ -614,7 +638,7 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
             if (w != 0 && producer) produce(c + 1, xb, xa);
 #endif
         }
-        __syncthreads();
+        chunk_barrier();
     }
 }
 
@@ -1622,7 +1646,11 @@ static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, 
     const int fpb = 4 * (lite ? NF_LITE : single ? NF_PAIR : NF_FULL); // frames per workgroup
     const unsigned nblk = (unsigned)((kp.T + fpb - 1) / fpb);
     dim3 grid(nblk, (unsigned)kp.B);
-    if (pl->p.n_fft == 512) {
+    if (pl->p.n_fft == 512 && kp.sc_mean && !single) { // a scaler is attached: the instantiation with the tables in LDS
+        constexpr size_t SCT_BYTES = 2 * 4 * 256 * sizeof(float);
+        if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    } else if (pl->p.n_fft == 512) {
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else if (single) hipLaunchKernelGGL((stft_kernel<512, double, false, NF_PAIR>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
