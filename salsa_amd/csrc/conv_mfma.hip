@@ -420,6 +420,14 @@ __device__ __forceinline__ void tile_coords(const TileWalk &w, const TilePos &p,
 // of a fragment are compile-time constants: eight per-lane base registers, one per value of the constant part mod 8).  Halo pixels outside the
 // image load from a 16-byte zero constant.
 __device__ uint4 conv_zero16; // zero-initialised
+// its address pinned in a scalar register pair (used in place it is re-loaded from the GOT -- s_getpc, s_load_dwordx2, s_waitcnt
+// lgkmcnt(0) -- in front of the halo loads of every tile; see conv_wide.hip wide_zero_ptr)
+__device__ __forceinline__ const unsigned short *conv_zero_ptr()
+{
+    const unsigned short *z = (const unsigned short *)&conv_zero16;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 
 constexpr int APIX = 64;                             // bf16 per pixel in LDS (no padding)
 constexpr int ABUF = HALO_H * HALO_W * APIX;         // one tile
@@ -522,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
     }
     const int px = lane & 31, khalf = lane >> 5, kh = khalf * 8;
     const int mb = wv & 1, rg = wv >> 1;
+    const unsigned short *const zero16 = conv_zero_ptr();
     bf16x8 af[9][4];
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #pragma unroll
         for (int j = 0; j < AFETCH; j++) {
             const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
-            const unsigned short *src = inside ? origin + (hh * geo.sh + ww * geo.sw + blk8) : (const unsigned short *)&conv_zero16;
+            const unsigned short *src = inside ? origin + (hh * geo.sh + ww * geo.sw + blk8) : zero16;
             unsigned short *dst = xl + buf * ABUF + (j * 256 + wv * 64) * 8; // the wave's 64 slots (lane l -> + 16 l bytes)
 #ifndef CONV_NO_FETCH
             if (tid + j * 256 < HALO_PIECES)

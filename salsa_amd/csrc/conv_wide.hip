@@ -21,6 +21,7 @@
 // x 2*(TN/32) MFMAs per wave.  The data gradient is the same kernel on dy with the filter flipped and transposed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "nn_det.h"
 
 namespace {
@@ -35,6 +36,16 @@ constexpr int MAX_XL_BYTES = 53248;   // input chunk: up to 832 slots of 64 byte
 #define WIDE_STORE16 1 // 16-byte epilogue stores through v_permlane32_swap (0: 8-byte stores)
 #endif
 __device__ uint4 wide_zero16; // zero-initialised: the source of every padding piece
+// Its address, pinned in a scalar register pair for the life of a kernel.  Referring to the variable at the point of use lets the
+// compiler re-materialise the address there, and for a __device__ variable that is a GOT load: s_getpc + s_load_dwordx2 +
+// s_waitcnt lgkmcnt(0) -- a scalar-memory round trip in FRONT of every staged wave-load, 9 per 128-pixel tile in the weight
+// gradient (found in the ISA in round 4; the counters only showed "waiting").
+__device__ __forceinline__ const unsigned short *wide_zero_ptr()
+{
+    const unsigned short *z = (const unsigned short *)&wide_zero16;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
@@ -76,6 +87,7 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
     unsigned char *xl0 = lds, *wl0 = lds + 2 * xl_bytes;            // xl[2], then wl[2]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, khalf = lane >> 5;
+    const unsigned short *const zero16 = wide_zero_ptr();
     const long P = (long)N * H * W;
     const long p0 = (long)blockIdx.x * TM;
     const int co0 = blockIdx.y * TN;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
 #pragma unroll
         for (int j = 0; j < X_INSTR; j++) {
             if ((j * NT + wv * 64) * 16 < xl_bytes && (j * NT + wv * 64) < n_pieces) { // wave-uniform: this wave-load lies inside the chunk
-                const unsigned short *src = src_off[j] >= 0 ? x + (long)src_off[j] + cc : (const unsigned short *)&wide_zero16;
+                const unsigned short *src = src_off[j] >= 0 ? x + (long)src_off[j] + cc : zero16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(xl0 + buf * xl_bytes + (j * NT + wv * 64) * 16), 16, 0, 0);
             }
@@ -474,6 +486,9 @@ __device__ __forceinline__ bf16x8 wtr_value(const wtr_frag &f)
 }
 #define WTR_ISSUE(f, a0, a1) asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"((f).lo), "=&v"((f).hi) : "v"(a0), "v"(a1))
 #define WTR_WAIT(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((f).lo), "+v"((f).hi))
+// the same with compile-time byte offsets in the instructions' offset fields (no address arithmetic per fragment)
+#define WTR_ISSUE_OFF(f, a0, a1, o0, o1) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%5" : "=&v"((f).lo), "=&v"((f).hi) : "v"(a0), "v"(a1), "n"(o0), "n"(o1))
+template <class F, int... I> __device__ __forceinline__ void wg_static_for(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
 // Every tile costs two dependent global round trips before its first MFMA (index tables, then the tiles themselves) against
 // ~1 us of multiply, so the loop is pipelined two deep: while tile i is multiplied, tile i+1's LDS-direct loads are in flight
@@ -491,6 +506,71 @@ constexpr int WG_LDS = WG_KQ == 2 && 2 * (WG_XL + WG_DL) < 9 * 16 * 256 * 4 ? 9 
                                                      // 1: 433, 2: 583, 3: 558, 4: 543 TFLOP/s on 256 -> 256
 #endif
 
+// End of a weight-gradient workgroup, shared by the two kernels below: the two k-halves of a channel group meet in LDS (the tile
+// buffers are free now), then the 128 x 9 x 32 block goes to dW (atomics, from the first half's waves) or to the workgroup's slab
+// (deterministic mode).  Probe builds (128 -> 128 at 160 x 50): the multiply loop alone 62 us, + this epilogue 87 -- 144 scattered
+// 4-byte stores per lane, the accumulator layout (lane = input channel, register = output channel) as it lies.  The slab path
+// therefore turns the block through LDS into its memory layout [co][tap][ci] and all eight waves write it as 16-byte stores
+// (18 per lane, whole 128-byte rows) -- round 4.
+__device__ __forceinline__ void wide_wrw_finish(f32x16 (&acc)[9], unsigned char *wlds, float *__restrict__ dw, float *__restrict__ part,
+                                                int CIN, int COUT, int co0, int ci0, int wv, int kq, int lane, int kh)
+{
+    static_assert(WG_KQ == 2, "the pair reduction below");
+    __syncthreads();
+    {   // 9 x 16 floats per lane, lane-major: 36 KiB per wave pair
+        float *red = (float *)wlds + (wv * 64 + lane) * 4;
+        if (kq == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    *(float4 *)(red + (t * 4 + g) * 1024) = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const float4 v = *(const float4 *)(red + (t * 4 + g) * 1024);
+                    acc[t][4 * g] += v.x; acc[t][4 * g + 1] += v.y; acc[t][4 * g + 2] += v.z; acc[t][4 * g + 3] += v.w;
+                }
+        }
+    }
+    // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the wave's 32
+#ifndef WRW_NO_ATOMIC // (probe)
+    if (part) {
+        __syncthreads(); // (the pair buffer has been read)
+        float *blk = (float *)wlds; // [128 co][9 taps][32 ci]
+        if (kq == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++)
+                    blk[((32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * kh) * 9 + t) * 32 + (lane & 31)] = acc[t][reg];
+        }
+        __syncthreads();
+        float *out = part + (long)blockIdx.x * ((long)COUT * 9 * CIN) + (long)co0 * 9 * CIN + ci0;
+        const int tid = threadIdx.x, seg = tid & 7;
+#pragma unroll 6
+        for (int r = 0; r < 128 * 9 * 8 / WG_NT; r++) {
+            const int row = (r * WG_NT + tid) >> 3; // = co * 9 + tap of the block
+            *(float4 *)(out + (long)row * CIN + seg * 4) = *(const float4 *)(blk + row * 32 + seg * 4);
+        }
+        return;
+    }
+    if (kq == 1) return;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int co = co0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * kh, ci = ci0 + (lane & 31);
+            atomicAdd(dw + ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
+        }
+#endif
+}
+
+template <int W2C /* W + 2 known at compile time (the CRNN's maps), or 0 */>
 __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsigned short *__restrict__ x,
                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                   const int *__restrict__ vpos, const int *__restrict__ inv,
@@ -500,13 +580,11 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[2][WG_XL], dl[2][WG_DL]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wave & 3, kq = wave >> 2;
     const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
+    const unsigned short *const zero16 = wide_zero_ptr();
     const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 32;
     const int W2 = W + 2;
     const unsigned lane_chunk = (unsigned)(cb * 32 + (i16 & 3) * 8);   // this lane's 4 channels inside a 64-byte slot
     const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)wlds;
-    int tapoff[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) tapoff[t] = ((t / 3 - 1) * W2 + (t % 3 - 1) + W2 + 1) * 64; // bytes, >= 0 (slot 0 = tap (-1,-1) of pixel 0)
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) acc[t] = f32x16{};
@@ -551,7 +629,7 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
         for (int j = 0; j < WG_XP; j++) {
             if (j * WG_NT + wave * 64 < L.ns * 4) { // wave-uniform: this wave's 64 pieces (16 slots) hold slots of the tile
                 const int piece = tid & 3;
-                const unsigned short *src = L.pix[j] >= 0 ? x + ((long)L.pix[j] * CIN + ci0 + piece * 8) : (const unsigned short *)&wide_zero16;
+                const unsigned short *src = L.pix[j] >= 0 ? x + ((long)L.pix[j] * CIN + ci0 + piece * 8) : zero16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(xl + (j * WG_NT + wave * 64) * 16), 16, 0, 0);
             }
@@ -559,7 +637,7 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
 #pragma unroll
         for (int k = 0; k < WG_DL / 16 / WG_NT; k++) {
             const int idx = k * WG_NT + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
-            const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : (const unsigned short *)&wide_zero16;
+            const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : zero16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dl + (k * WG_NT + wave * 64) * 16), 16, 0, 0);
         }
@@ -581,31 +659,44 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
         constexpr int NQ = WG_KS * 10, RING = WG_DEPTH + 1;
         wtr_frag fr[RING];
         bf16x8 a;
-        auto issue = [&](const int q1) {
-            const int ks1 = q1 / 10, j1 = q1 % 10;
-            if (j1 == 0) WTR_ISSUE(fr[q1 % RING], d_lane + (unsigned)(ks1 * 16 * 64), d_lane + (unsigned)(ks1 * 16 * 64 + 4 * 64));
-            else WTR_ISSUE(fr[q1 % RING], xa[ks1][0] + (unsigned)tapoff[j1 - 1], xa[ks1][1] + (unsigned)tapoff[j1 - 1]);
+        // Fragment q = (k-step q / 10, j = q % 10): j = 0 the dy fragment, j = 1..9 the x fragment of tap j - 1.  Every address is a
+        // per-k-step base register plus a COMPILE-TIME offset in the instruction (round 4; before: two v_add per fragment, 235
+        // VALU instructions per tile and wave against 36 MFMAs): the dy fragments of all k-steps hang off one register; an x
+        // fragment is its k-step's row base + (tap row * W2 + tap column) * 64 -- an immediate when the map width is a template
+        // parameter (W2C), otherwise the tap row is added once per three fragments and only the column is immediate.
+        unsigned cr0 = 0, cr1 = 0;
+        const unsigned rowb = (unsigned)(W2 * 64);
+        auto issue = [&fr, &xa, &cr0, &cr1, d_lane, rowb](auto q1c) {
+            constexpr int q1 = decltype(q1c)::value, ks1 = q1 / 10, j1 = q1 % 10;
+            if constexpr (j1 == 0) {
+                WTR_ISSUE_OFF(fr[q1 % RING], d_lane, d_lane, ks1 * 16 * 64, ks1 * 16 * 64 + 4 * 64);
+            } else {
+                constexpr int t = j1 - 1, dh = t / 3, dwc = t % 3;
+                if constexpr (W2C > 0) {
+                    WTR_ISSUE_OFF(fr[q1 % RING], xa[ks1][0], xa[ks1][1], (dh * W2C + dwc) * 64, (dh * W2C + dwc) * 64);
+                } else {
+                    if constexpr (dwc == 0) {
+                        cr0 = xa[ks1][0] + (unsigned)dh * rowb;
+                        cr1 = xa[ks1][1] + (unsigned)dh * rowb;
+                    }
+                    WTR_ISSUE_OFF(fr[q1 % RING], cr0, cr1, dwc * 64, dwc * 64);
+                }
+            }
         };
-#pragma unroll
-        for (int q = 0; q < WG_DEPTH; q++) issue(q);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            if (q + WG_DEPTH < NQ) issue(q + WG_DEPTH);
+        wg_static_for([&issue](auto qc) { issue(qc); }, std::make_integer_sequence<int, WG_DEPTH>{});
+        wg_static_for([&issue, &fr, &a, &acc](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q + WG_DEPTH < NQ) issue(std::integral_constant<int, q + WG_DEPTH>{});
             __builtin_amdgcn_sched_barrier(0);
             {   // fragment q has landed when at most the 2 * min(WG_DEPTH, NQ - 1 - q) younger reads are outstanding
-                constexpr int full = 2 * WG_DEPTH;
-                const int younger = 2 * (NQ - 1 - q < WG_DEPTH ? NQ - 1 - q : WG_DEPTH);
-                if (younger == full) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi) : "n"(full));
-                else if (younger == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
-                else if (younger == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
-                else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi));
+                constexpr int younger = 2 * (NQ - 1 - q < WG_DEPTH ? NQ - 1 - q : WG_DEPTH);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi) : "n"(younger));
             }
-            const int j = q % 10;
-            if (j == 0) a = wtr_value(fr[q % RING]);
+            constexpr int j = q % 10;
+            if constexpr (j == 0) a = wtr_value(fr[q % RING]);
             else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q % RING]), acc[j - 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        }, std::make_integer_sequence<int, NQ>{});
     };
     // software pipeline over this workgroup's tiles, tile(i) = blockIdx.x + i * n_shares: at iteration i the data of tile i is
     // in buffer i & 1 with its tables in Lcur, tile i+1's tables are in Lnext
@@ -629,41 +720,228 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
         Lcur = Lnext;
         Lnext = Lnn;
     }
-#if WG_KQ == 2
-    // the two k-halves of a channel group meet in LDS (9 x 16 floats per lane, lane-major: 36 KiB per wave pair, the tile
-    // buffers are free now) and the first half's waves issue the atomics
-    __syncthreads();
-    {
-        float *red = (float *)wlds + (wv * 64 + lane) * 4;
-        if (kq == 1) {
+    wide_wrw_finish(acc, wlds, dw, part, CIN, COUT, co0, ci0, wv, kq, lane, kh);
+}
+
+
+// ---- round 4: THREE tile buffers, index tables through LDS.
+// Probe builds of the kernel above (128 -> 128 at 160 x 50, batch 32, inputs from HBM): whole 139 us; without the staging 97; without
+// the multiply 88; without the final atomics 118.  Staging and multiplying each need ~70 us and together 118: the two-buffer
+// pipeline hides one tile time (~1.1 us of MFMAs) of a load chain -- table look-up, then the tile itself, mostly L2 misses --
+// that is longer than that.  (Deeper LDS-read pipelining inside the multiply, WG_DEPTH 3 / 4: no change.)  Here tile i + 2 is
+// staged while tile i is multiplied, and the look-ups run four tiles ahead.  What makes that possible:
+//  * every load is LDS-direct, the tables included (4-byte global_load_lds into small LDS rings: inv[] of a tile's slots, 3
+//    entries; vpos[] of its 128 pixels, 5 entries), so no load returns into a register and the compiler inserts no vmcnt wait of
+//    its own; the kernel waits by COUNT at the top of an iteration -- everything but the loads of the previous iteration --
+//    and every wave issues a launch-constant number of loads per iteration (x: nx = 1..3 by wave, dy: 4, tables: 1);
+//  * the x buffers are sized for the map (W = 50: 304 slots instead of 448): 3 x (19 + 32) KiB + rings = 159 KiB of LDS.
+// Maps too wide for that keep the kernel above.
+constexpr int W3_VP_RING = 5, W3_INV_RING = 3;
+constexpr int W3_LDS_MAX = 160 * 1024;
+
+// upper bound of a tile's slot count (tile_bounds[].y of salsa_nn_conv3x3_wide_tables), rounded up to whole 16-slot wave-loads
+static int wrw3_slots(int H, int W)
+{
+    const int W2 = W + 2, rc = (WG_TM - 1 + W - 1) / W, ic = (WG_TM - 1 + H * W - 1) / (H * W);
+    return (WG_TM - 1 + 2 * rc + W2 * ic + 2 * W2 + 3 + 15) & ~15;
+}
+static int wrw3_lds_bytes(int H, int W)
+{
+    const int xs = wrw3_slots(H, W), n_inv_w = (xs + 63) / 64;
+    return 3 * (xs * 64 + WG_DL) + W3_INV_RING * n_inv_w * 256 + W3_VP_RING * 512 + 256;
+}
+static bool wrw3_supported(int H, int W)
+{
+    return WG_KQ == 2 && (wrw3_slots(H, W) + 63) / 64 + 2 <= 8 && wrw3_slots(H, W) / 16 <= 24 && wrw3_lds_bytes(H, W) <= W3_LDS_MAX;
+}
+
+template <int W2C>
+__global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw3_kernel(const unsigned short *__restrict__ x,
+                                                                   const unsigned short *__restrict__ dy, float *__restrict__ dw,
+                                                                   const int *__restrict__ vpos, const int *__restrict__ inv,
+                                                                   const int2 *__restrict__ tbounds, long P, int W, int CIN, int COUT,
+                                                                   int n_shares, float *__restrict__ part, int xs /* slots per x buffer */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[]; // xl[3][xs * 64], dl[3][WG_DL], inv ring, vpos ring, dump
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wave & 3, kq = wave >> 2;
+    const int i16 = lane & 15, cb = (lane >> 4) & 1, kh = lane >> 5;
+    const unsigned short *const zero16 = wide_zero_ptr();
+    const int co0 = blockIdx.y * 128, ci0 = blockIdx.z * 32;
+    const int W2 = W2C > 0 ? W2C : W + 2;
+    const unsigned lane_chunk = (unsigned)(cb * 32 + (i16 & 3) * 8);
+    const unsigned lbase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)wlds;
+    const int XB = xs * 64, n_inv_w = (xs + 63) >> 6, n_xw = xs >> 4;       // bytes of an x buffer; wave-loads of a tile's inv[] / x slots
+    const int o_dl = 3 * XB, o_inv = o_dl + 3 * WG_DL, o_vp = o_inv + W3_INV_RING * n_inv_w * 256, o_dump = o_vp + W3_VP_RING * 512;
+    const int nx = (n_xw - wave + 7) >> 3;                                   // this wave's x wave-loads per tile (q = wave, wave + 8, ...)
+    f32x16 acc[9];
 #pragma unroll
-            for (int t = 0; t < 9; t++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    *(float4 *)(red + (t * 4 + g) * 1024) = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+    for (int t = 0; t < 9; t++) acc[t] = f32x16{};
+    const long n_tiles = (P + WG_TM - 1) / WG_TM;
+    const int n_mine = (int)((n_tiles - (long)blockIdx.x + n_shares - 1) / n_shares);       // tiles blockIdx.x, + n_shares, ...
+    auto tile_of = [&](int i) { return (long)blockIdx.x + (long)i * n_shares; };
+
+    // tables of tile i: ONE 4-byte LDS-direct load per wave
+    auto lookup = [&](int i) {
+        const long tile = tile_of(i);
+        const int2 tb = tbounds[__builtin_amdgcn_readfirstlane((int)tile)];
+        const int *src;
+        int dst;
+        if (wave < n_inv_w) {           // inv[first slot + sl]: the pixel of slot sl (clamped address; the value is ignored beyond the tile's count)
+            const int sl = wave * 64 + lane;
+            src = inv + tb.x + (sl < tb.y ? sl : 0);
+            dst = o_inv + ((i % W3_INV_RING) * n_inv_w + wave) * 256;
+        } else if (wave < n_inv_w + 2) { // vpos[p]: the slot of each of the tile's 128 pixels
+            const int h = wave - n_inv_w;
+            long p = tile * WG_TM + h * 64 + lane;
+            if (p >= P) p = P - 1;      // (dy is zero there: no contribution)
+            src = vpos + p;
+            dst = o_vp + (i % W3_VP_RING) * 512 + h * 256;
+        } else {                        // (a wave without a share: the same number of loads in flight as everyone else)
+            src = vpos + lane;
+            dst = o_dump;
         }
-        __syncthreads();
-        if (kq == 1) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(wlds + dst), 4, 0, 0);
+    };
+    // tile i into buffer b; its inv[] table has landed in the ring
+    auto stage = [&](int i, int b) {
+        const long tile = tile_of(i), p0 = tile * WG_TM;
+        const int ns = tbounds[__builtin_amdgcn_readfirstlane((int)tile)].y;
+        const unsigned tinv = lbase + (unsigned)(o_inv + (i % W3_INV_RING) * n_inv_w * 256);
+        int pix[3];
 #pragma unroll
-        for (int t = 0; t < 9; t++)
+        for (int j = 0; j < 3; j++) {
+            const int sl = (wave + 8 * j) * 16 + (lane >> 2);
+            pix[j] = -1;
+            if (j < nx) asm volatile("ds_read_b32 %0, %1" : "=v"(pix[j]) : "v"(tinv + (unsigned)(sl * 4)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pix[0]), "+v"(pix[1]), "+v"(pix[2]));
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const float4 v = *(const float4 *)(red + (t * 4 + g) * 1024);
-                acc[t][4 * g] += v.x; acc[t][4 * g + 1] += v.y; acc[t][4 * g + 2] += v.z; acc[t][4 * g + 3] += v.w;
+        for (int j = 0; j < 3; j++) {
+            if (j < nx) { // wave-uniform
+                const int q = wave + 8 * j, sl = q * 16 + (lane >> 2), piece = lane & 3;
+                const unsigned short *src = (sl < ns && pix[j] >= 0) ? x + ((long)pix[j] * CIN + ci0 + piece * 8) : zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(wlds + b * XB + q * 1024), 16, 0, 0);
             }
-    }
-#endif
-    // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the wave's 32
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int co = co0 + 32 * wv + (reg & 3) + 8 * (reg >> 2) + 4 * kh, ci = ci0 + (lane & 31);
-#ifdef WRW_NO_ATOMIC
-            if (acc[t][reg] == 123.456f)
-#endif
-            salsa_nn_accumulate(dw, part, (long)COUT * 9 * CIN, (int)blockIdx.x, ((long)(co * 9 + t) * CIN + ci), acc[t][reg]);
         }
+#pragma unroll
+        for (int k = 0; k < WG_DL / 16 / WG_NT; k++) {
+            const int idx = k * WG_NT + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
+            const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(wlds + o_dl + b * WG_DL + (k * WG_NT + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto multiply = [&](int i, int b) {
+        const int vb = tbounds[__builtin_amdgcn_readfirstlane((int)tile_of(i))].x;
+        const unsigned xbase = lbase + (unsigned)(b * XB), dbase = lbase + (unsigned)(o_dl + b * WG_DL);
+        const unsigned d_lane = dbase + (unsigned)((wv * WG_TM + 16 * WG_KS * kq + 8 * kh + (i16 >> 2)) * 64) + lane_chunk;
+        // the padded slot of each of this lane's fragment pixel rows: vpos ring entry, pixel 16 (kq KS + ks) + 8 kh + (i16 >> 2) (+ 4)
+        const unsigned tvp = lbase + (unsigned)(o_vp + (i % W3_VP_RING) * 512 + (16 * WG_KS * kq + 8 * kh + (i16 >> 2)) * 4);
+        int2 vp[WG_KS];
+        wg_static_for([&vp, tvp](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(vp[ks]) : "v"(tvp), "n"(ks * 16), "n"(ks * 16 + 4));
+        }, std::make_integer_sequence<int, WG_KS>{});
+        static_assert(WG_KS == 4, "the wait below names four registers");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vp[0]), "+v"(vp[1]), "+v"(vp[2]), "+v"(vp[3]));
+        unsigned xa[WG_KS][2];
+#pragma unroll
+        for (int ks = 0; ks < WG_KS; ks++) {
+            xa[ks][0] = xbase + (unsigned)((vp[ks].x - vb - (W2 + 1)) * 64) + lane_chunk;
+            xa[ks][1] = xbase + (unsigned)((vp[ks].y - vb - (W2 + 1)) * 64) + lane_chunk;
+        }
+        constexpr int NQ = WG_KS * 10, RING = WG_DEPTH + 1;
+        wtr_frag fr[RING];
+        bf16x8 a;
+        unsigned cr0 = 0, cr1 = 0;
+        const unsigned rowb = (unsigned)(W2 * 64);
+        auto issue = [&fr, &xa, &cr0, &cr1, d_lane, rowb](auto q1c) { // (see the kernel above)
+            constexpr int q1 = decltype(q1c)::value, ks1 = q1 / 10, j1 = q1 % 10;
+            if constexpr (j1 == 0) {
+                WTR_ISSUE_OFF(fr[q1 % RING], d_lane, d_lane, ks1 * 16 * 64, ks1 * 16 * 64 + 4 * 64);
+            } else {
+                constexpr int t = j1 - 1, dh = t / 3, dwc = t % 3;
+                if constexpr (W2C > 0) {
+                    WTR_ISSUE_OFF(fr[q1 % RING], xa[ks1][0], xa[ks1][1], (dh * W2C + dwc) * 64, (dh * W2C + dwc) * 64);
+                } else {
+                    if constexpr (dwc == 0) {
+                        cr0 = xa[ks1][0] + (unsigned)dh * rowb;
+                        cr1 = xa[ks1][1] + (unsigned)dh * rowb;
+                    }
+                    WTR_ISSUE_OFF(fr[q1 % RING], cr0, cr1, dwc * 64, dwc * 64);
+                }
+            }
+        };
+        wg_static_for([&issue](auto qc) { issue(qc); }, std::make_integer_sequence<int, WG_DEPTH>{});
+        wg_static_for([&issue, &fr, &a, &acc](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q + WG_DEPTH < NQ) issue(std::integral_constant<int, q + WG_DEPTH>{});
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                constexpr int younger = 2 * (NQ - 1 - q < WG_DEPTH ? NQ - 1 - q : WG_DEPTH);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fr[q % RING].lo), "+v"(fr[q % RING].hi) : "n"(younger));
+            }
+            constexpr int j = q % 10;
+            if constexpr (j == 0) a = wtr_value(fr[q % RING]);
+            else acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wtr_value(fr[q % RING]), acc[j - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, NQ>{});
+    };
+
+    // prologue: the tables of tiles 0..2, then tiles 0 and 1, then the tables of tile 3 (whose ring entry is tile 0's)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (i < n_mine) lookup(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (0 < n_mine) stage(0, 0);
+    int prev = 0; // loads this wave issued after the ones iteration i needs
+    if (1 < n_mine) { stage(1, 1); prev = nx + 4; }
+    __builtin_amdgcn_s_barrier(); // (every wave has read tile 0's table)
+    if (3 < n_mine) { lookup(3); prev += 1; }
+    int b = 0;
+    for (int i = 0; i < n_mine; i++) {
+        // tile i and the tables of tile i + 2 have landed when only the previous iteration's loads are in flight
+        switch (prev) {
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef WRW_NO_BARRIER // (probe)
+        __builtin_amdgcn_s_barrier(); // ... for every wave; and buffer (i + 2) % 3 = (i - 1) % 3 is free
+#endif
+        // The loads of this iteration are a chain of scalar and LDS round trips (tile bounds, table values, addresses) before the
+        // first of them issues: ~25 % of an iteration during which this wave feeds no MFMA.  The two waves of a SIMD (k-halves
+        // kq = 0 / 1) therefore take turns: one issues its loads before its multiply, the other after it.
+        prev = 0;
+        auto loads = [&]() {
+#ifndef WRW_NO_STAGE
+            if (i + 2 < n_mine) { stage(i + 2, b == 0 ? 2 : b - 1); prev = nx + 4; }
+#endif
+#ifndef WRW_NO_LOOKUP // (probe)
+            if (i + 4 < n_mine) { lookup(i + 4); prev += 1; }
+#endif
+        };
+#ifndef WRW_NO_STAGGER
+        if (kq == 0) loads();
+#else
+        loads();
+#endif
+#ifndef WRW_NO_MULT
+        multiply(i, b);
+#endif
+#ifndef WRW_NO_STAGGER
+        if (kq == 1) loads();
+#endif
+        b = b == 2 ? 0 : b + 1;
+    }
+    __syncthreads(); // (drains everything; the tile buffers are free for the pair reduction)
+    wide_wrw_finish(acc, wlds, dw, part, CIN, COUT, co0, ci0, wv, kq, lane, kh);
 }
 
 } // namespace
@@ -713,14 +991,33 @@ extern "C" int salsa_nn_conv3x3_wide_wrw(const void *x, const void *dy, float *d
     long shares = (256 + pairs - 1) / pairs; // one workgroup per CU (its 120 KiB of LDS fill it)
     if (shares > tiles) shares = tiles;
     if (shares < 1) shares = 1;
-    if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return -6; // 120 KiB of dynamic LDS (per device: set on every launch)
     int rc = 0;
     float *part = salsa_nn_det_begin((int)shares, (long)Cout * 9 * Cin, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv3x3_wide_wrw_kernel, dim3((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32)), dim3(WG_NT),
-                       WG_LDS, (hipStream_t)hip_stream, (const unsigned short *)x, (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout,
-                       (int)shares, part);
+    const dim3 grid((unsigned)shares, (unsigned)(Cout / 128), (unsigned)(Cin / 32));
+    const bool three = wrw3_supported(H, W); // three tile buffers when the map's x tiles are small enough for that (see the kernel)
+    auto launch = [&](auto w2c) -> int {
+        constexpr int W2C = decltype(w2c)::value;
+        // 120 - 159 KiB of dynamic LDS needs the attribute (per device: set on every launch)
+        if (three) {
+            if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw3_kernel<W2C>, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_MAX) != hipSuccess)
+                return -6;
+            const int lds = wrw3_lds_bytes(H, W) > WG_LDS ? wrw3_lds_bytes(H, W) : WG_LDS; // (>= the pair reduction's 144 KiB)
+            hipLaunchKernelGGL(conv3x3_wide_wrw3_kernel<W2C>, grid, dim3(WG_NT), lds, (hipStream_t)hip_stream, (const unsigned short *)x,
+                               (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout, (int)shares, part,
+                               wrw3_slots(H, W));
+            return 0;
+        }
+        if (hipFuncSetAttribute((const void *)conv3x3_wide_wrw_kernel<W2C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return -6;
+        hipLaunchKernelGGL(conv3x3_wide_wrw_kernel<W2C>, grid, dim3(WG_NT), WG_LDS, (hipStream_t)hip_stream, (const unsigned short *)x,
+                           (const unsigned short *)dy, dw, d_vpos, d_inv, (const int2 *)d_tbounds, P, W, Cin, Cout, (int)shares, part);
+        return 0;
+    };
+    // the CRNN's three wide map widths get instantiations with every tap offset an immediate; any other width the generic one
+    rc = W == 50 ? launch(std::integral_constant<int, 52>{}) : W == 25 ? launch(std::integral_constant<int, 27>{})
+       : W == 12 ? launch(std::integral_constant<int, 14>{}) : launch(std::integral_constant<int, 0>{});
+    if (rc) return rc;
     if (part) return salsa_nn_det_finish(part, (int)shares, (long)Cout * 9 * Cin, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
