@@ -1311,16 +1311,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 #endif
     }
     // D[m = co][n = ci]: column = lane&31 = ci, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = co within the block
+#ifndef WRW64_NO_ATOMIC // (probe)
+    if (part) {
+        // deterministic mode: the workgroup's 64 x 9 x 64 block goes to its slab.  Written as the accumulators lie that is 144
+        // scattered 4-byte stores per lane (the wide kernel's probe builds: a quarter of the launch); instead each tap's 64 x 64
+        // plane is turned through LDS (the x tile's buffer is free) into its memory layout and written as 16-byte stores,
+        // whole 256-byte rows (round 4)
+        float *blk = (float *)xl; // [64 co][64 ci]
+        static_assert(sizeof(xl) >= 64 * 64 * 4, "one tap's plane");
+        float *out = part + (long)blockIdx.x * (64L * 9 * 64);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            __syncthreads();
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                blk[(32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + 32 * nb + (lane & 31)] = acc[tap][reg];
+            __syncthreads();
+            const int ft = geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap; // (transposed geometry: tap (ky, kx) is the filter's (kx, ky))
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = 16 * r + (tid >> 4), seg = tid & 15;
+                *(float4 *)(out + ((long)(co * 9 + ft)) * CH + seg * 4) = *(const float4 *)(blk + co * 64 + seg * 4);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), ci = 32 * nb + (lane & 31);
-#ifdef WRW64_NO_ATOMIC // (probe)
-            if (acc[tap][reg] == 123.456f)
+            atomicAdd(dw + ((long)(co * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + ci), acc[tap][reg]);
+        }
 #endif
-            salsa_nn_accumulate(dw, part, 64L * 9 * 64, (int)blockIdx.x, ((long)(co * 9 + (geo.tap_t ? (tap % 3) * 3 + tap / 3 : tap)) * CH + ci), acc[tap][reg]); // (transposed
-        }                                                                                  // geometry: tap (ky, kx) is the filter's (kx, ky))
 }
 
 } // namespace

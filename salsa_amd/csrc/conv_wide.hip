@@ -736,6 +736,9 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
 //    and every wave issues a launch-constant number of loads per iteration (x: nx = 1..3 by wave, dy: 4, tables: 1);
 //  * the x buffers are sized for the map (W = 50: 304 slots instead of 448): 3 x (19 + 32) KiB + rings = 159 KiB of LDS.
 // Maps too wide for that keep the kernel above.
+#ifndef WRW_AUX
+#define WRW_AUX 0 // cache-policy bits of the tile loads (probe: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 constexpr int W3_VP_RING = 5, W3_INV_RING = 3;
 constexpr int W3_LDS_MAX = 160 * 1024;
 
@@ -821,16 +824,22 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw3_kernel(const unsig
             if (j < nx) { // wave-uniform
                 const int q = wave + 8 * j, sl = q * 16 + (lane >> 2), piece = lane & 3;
                 const unsigned short *src = (sl < ns && pix[j] >= 0) ? x + ((long)pix[j] * CIN + ci0 + piece * 8) : zero16;
+#if defined(WRW_STAGE_NOLOAD) || defined(WRW_STAGE_NOX) // (probe: the staging code with its scalar / LDS round trips, but zeros instead of the tensor)
+                src = zero16;
+#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(wlds + b * XB + q * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(wlds + b * XB + q * 1024), 16, 0, WRW_AUX);
             }
         }
 #pragma unroll
         for (int k = 0; k < WG_DL / 16 / WG_NT; k++) {
             const int idx = k * WG_NT + tid, piece = idx & 3, j = (idx >> 2) & (WG_TM - 1), cg = idx >> 9;
             const unsigned short *src = p0 + j < P ? dy + ((p0 + j) * COUT + co0 + cg * 32 + piece * 8) : zero16;
+#if defined(WRW_STAGE_NOLOAD) || defined(WRW_STAGE_NODY)
+            src = zero16;
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(wlds + o_dl + b * WG_DL + (k * WG_NT + wave * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(wlds + o_dl + b * WG_DL + (k * WG_NT + wave * 64) * 16), 16, 0, WRW_AUX);
         }
     };
     auto multiply = [&](int i, int b) {

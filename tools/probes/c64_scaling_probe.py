@@ -10,6 +10,8 @@ from salsa_amd import _lib
 from salsa_amd.crnn import nn_ops
 
 dev = torch.device('cuda:0')
+nn_ops.set_deterministic(os.environ.get('SALSA_DETERMINISTIC', '1') != '0', dev)
+print('deterministic slabs' if nn_ops.is_deterministic() else 'float atomics')
 L = _lib.load()
 g = torch.Generator(device='cpu').manual_seed(0)
 

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from salsa_amd.crnn import nn_ops
 dev = 'cuda:0'
+nn_ops.set_deterministic(os.environ.get('SALSA_DETERMINISTIC', '1') != '0', dev)
+print('deterministic slabs' if nn_ops.is_deterministic() else 'float atomics')
 g = torch.Generator(device=dev).manual_seed(0)
 for cin, cout, H, W in ((128, 128, 160, 50), (256, 256, 80, 25), (512, 512, 40, 12)):
     xs = [torch.randn((32, cin, H, W), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(3)]
