@@ -865,6 +865,7 @@ def _bank_filters(conv):
 
 USE_FUSED_SKIP = os.environ.get('SALSA_FUSED_SKIP', '1') != '0'
 USE_CONV_STATS = os.environ.get('SALSA_CONV_STATS', '1') != '0'   # BatchNorm statistics from the 64 -> 64 convolution's epilogue
+C64_STATS_MIN_PIX = int(os.environ.get('SALSA_C64_STATS_MIN_PIX', '0'))   # ... only for maps of at least this many pixels (N H W)
 USE_WIDE_CONV_STATS = os.environ.get('SALSA_WIDE_CONV_STATS', '1') != '0'   # the same in the wide kernels' epilogue
 
 
@@ -904,6 +905,8 @@ class Conv3x3(torch.nn.Conv2d):
             return torch.empty(nb * 2 * self.out_channels, dtype=torch.float64, device=x.device) if nb > 0 else None
         if not (USE_CONV_STATS and torch.is_grad_enabled() and self._hip_eligible(x)):
             return None
+        if x.shape[0] * x.shape[2] * x.shape[3] < C64_STATS_MIN_PIX:
+            return None                                   # (the BatchNorm takes its own statistics pass)
         nb = _lib.load().salsa_nn_conv3x3_c64_stats_blocks(x.shape[0], x.shape[2], x.shape[3])
         return torch.empty(nb * 128, dtype=torch.float64, device=x.device) if nb > 0 else None
 

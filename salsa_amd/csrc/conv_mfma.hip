@@ -575,6 +575,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         for (int j = 0; j < AFETCH; j++) {
             const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
             const unsigned short *src = inside ? origin + (hh * geo.sh + ww * geo.sw + blk8) : zero16;
+#ifdef CONV_ZERO_SRC // (probe: every halo load answered from one cached line)
+            src = zero16;
+#endif
+#ifdef CONV_FETCH_COLMAJOR // (TIMING probe, wrong results: neighbouring lanes fetch along the tile's SHORT axis -- contiguous 768-byte
+            {              // runs in the transposed geometry -- instead of along the long one, 34 lines a map row apart)
+                const int q = (tid >> 3) + 32 * j, h2 = q % HALO_H - 1, w2 = q / HALO_H - 1;
+                const bool in2 = q < HALO_H * HALO_W && h2 >= h_lo && h2 < h_hi && w2 >= w_lo && w2 < w_hi;
+                src = in2 ? origin + (h2 * geo.sh + w2 * geo.sw + blk8) : zero16;
+            }
+#endif
             unsigned short *dst = xl + buf * ABUF + (j * 256 + wv * 64) * 8; // the wave's 64 slots (lane l -> + 16 l bytes)
 #ifndef CONV_NO_FETCH
             if (tid + j * 256 < HALO_PIECES)

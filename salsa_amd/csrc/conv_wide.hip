@@ -125,6 +125,9 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
         for (int j = 0; j < X_INSTR; j++) {
             if ((j * NT + wv * 64) * 16 < xl_bytes && (j * NT + wv * 64) < n_pieces) { // wave-uniform: this wave-load lies inside the chunk
                 const unsigned short *src = src_off[j] >= 0 ? x + (long)src_off[j] + cc : zero16;
+#ifdef WIDE_X_ZERO // (probe)
+                src = zero16;
+#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(xl0 + buf * xl_bytes + (j * NT + wv * 64) * 16), 16, 0, 0);
             }
@@ -135,6 +138,9 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
         for (int j = 0; j < W_INSTR; j++) {
             if ((j * NT + wv * 64) * 16 < WL_BYTES) { // wave-uniform
                 const unsigned short *src = w + (long)wsrc[j] + r * 3 * CIN + cc;
+#ifdef WIDE_W_ZERO // (probe: the filter loads answered from one cached line)
+                src = zero16;
+#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(wl0 + buf * WL_BYTES + (j * NT + wv * 64) * 16), 16, 0, 0);
             }
@@ -226,6 +232,10 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
 #pragma unroll
         for (int r = 0; r < 3; r++, step++) {
             __syncthreads(); // (waits for this thread's loads, then the barrier) the step's data is complete; the other buffers are free
+            // (Round 4: a counted wait at the second filter row that leaves the next chunk's input loads in flight for one more
+            // step measured no gain, 87 - 90 us either way at 128 -> 128: what the staging costs -- 60 us with every tile load
+            // answered from one cached line, WIDE_X_ZERO / WIDE_W_ZERO -- is the rate at which 64-byte pieces arrive from L2,
+            // not the deadline they are given.)
             const int wb = step & 1;
             {   // the next step's loads, in flight during this step's MFMAs
                 const int nr = r == 2 ? 0 : r + 1, ncc = r == 2 ? cc + KC : cc;

@@ -22,4 +22,15 @@ for cin, cout, H, W in ((128, 128, 160, 50), (256, 256, 80, 25), (512, 512, 40, 
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 30
+    ws = [(torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(3)]
+    for _ in range(3):
+        nn_ops._conv_wide(xs[0], ws[0])
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(30):
+        nn_ops._conv_wide(xs[i % 3], ws[i % 3])
+    e1.record()
+    torch.cuda.synchronize()
+    tf = e0.elapsed_time(e1) / 30
+    print('%s %d->%d %dx%d: forward %.1f us  %.0f TF/s' % (os.path.basename(os.environ.get('SALSA_HIP_LIB', 'default')), cin, cout, H, W, tf * 1e3, 2.0 * 32 * H * W * cin * cout * 9 / tf / 1e9), flush=True)
     print('%s %d->%d %dx%d: %.1f us  %.0f TF/s' % (os.path.basename(os.environ.get('SALSA_HIP_LIB', 'default')), cin, cout, H, W, t * 1e3, 2.0 * 32 * H * W * cin * cout * 9 / t / 1e9), flush=True)
