@@ -1358,6 +1358,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_wrw_kernel(const unsigned 
 
 } // namespace
 
+#ifndef C64_WRW_MID
+#define C64_WRW_MID 256 // persistent workgroups of the weight gradient at 4096 .. 16383 tiles, and (C64_WRW_BIG) beyond; with slabs (round 4) at
+                        // 32 x 320 x 100: 256: 99 us, 384: 105, 512: 101 (the launch + its slab reduction); with atomics 384 was best
+#endif
+#ifndef C64_WRW_BIG
+#define C64_WRW_BIG 512
+#endif
 // dw: float32 [64 co][3][3][64 ci], ADDED to (zero it first); x, dy: [N][H][W][64] bf16
 extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream)
 {
@@ -1366,7 +1373,7 @@ extern "C" int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw
     const long tiles = pl.tiles;
     // persistent workgroups, two per CU; fewer when there are few tiles (every workgroup ends with 36 864 float atomics)
     // (mid sizes, 32 x 320 x 100: 256 workgroups 0.158 ms, 384: 0.141, 512: 0.149)
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? C64_WRW_BIG : tiles >= 4096 ? C64_WRW_MID : tiles >= 128 ? 128 : tiles);
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * 9 * 64, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
@@ -1387,7 +1394,7 @@ extern "C" int salsa_nn_conv3x3_c64_wrw_xform(const void *x1, const void *dy, fl
         return -1;
     const C64Plan pl = c64_plan(N, H, W, WT_H, WT_W);
     const long tiles = pl.tiles;
-    const unsigned nb = (unsigned)(tiles >= 16384 ? 512 : tiles >= 4096 ? 384 : tiles >= 128 ? 128 : tiles);
+    const unsigned nb = (unsigned)(tiles >= 16384 ? C64_WRW_BIG : tiles >= 4096 ? C64_WRW_MID : tiles >= 128 ? 128 : tiles);
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * 9 * 64, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
