@@ -810,7 +810,7 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw3_kernel(const unsig
             src = vpos + p;
             dst = o_vp + (i % W3_VP_RING) * 512 + h * 256;
         } else {                        // (a wave without a share: the same number of loads in flight as everyone else)
-            src = vpos + lane;
+            src = vpos; // (every lane the same valid word)
             dst = o_dump;
         }
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,

@@ -497,7 +497,8 @@ def test_wide_conv_kernel_matches_torch_forward_and_gradients():
     for n, cin, cout, h, w in ((3, 64, 128, 40, 50), (2, 128, 128, 37, 50), (5, 128, 256, 20, 25), (3, 256, 256, 23, 25),
                                (7, 256, 512, 40, 12), (5, 512, 512, 9, 12), (2, 128, 64, 16, 50), (1, 96, 192, 5, 7),
                                (3, 64, 128, 30, 33),    # weight gradient: the three-buffer kernel at a width without an instantiation
-                               (5, 128, 128, 3, 40)):   # ... and the two-buffer kernel (tiles spanning three images need more slots)
+                               (5, 128, 128, 3, 40),    # ... and the two-buffer kernel (tiles spanning three images need more slots)
+                               (1, 128, 128, 5, 7), (2, 128, 256, 9, 7)):   # fewer pixels than one 128-pixel tile / than two
         assert nn_ops._lib.load().salsa_nn_conv3x3_wide_supported(n, h, w, cin, cout)
         x = torch.randn((n, cin, h, w), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         wt = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5)
