@@ -208,6 +208,22 @@ int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b,
 int salsa_nn_set_deterministic(void *ws, size_t bytes);
 int salsa_nn_get_deterministic(void);
 
+/* One Adam step over MANY parameter tensors in one launch (round 4) -- torch.optim.Adam's update rule (its fused CUDA kernel,
+ * ADAM_MODE ORIGINAL, amsgrad off; the reference's optimiser, experiments/configs/seld.yml:37-52 through Lightning):
+ *     g += weight_decay p;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;
+ *     p -= (lr / (1 - beta1^step)) m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * all float32.  torch's own fused path takes three multi_tensor_apply launches for this network's 143 tensors, two of them ~40
+ * workgroups of tiny tensors (0.165 ms per step for 0.39 GB of traffic).
+ *   table  device array [n_tensors] of {float *p, *m, *v; int64 n} (salsa_nn_adam_entry): stable from step to step;
+ *   grads  HOST array [n_tensors] of device pointers to the gradients (they move from step to step: passed in the kernel arguments);
+ *   chunks device array [n_chunks] of {int tensor, int first element / SALSA_NN_ADAM_CHUNK}: one workgroup each;
+ * at most SALSA_NN_ADAM_MAX_TENSORS tensors per call.  Returns 0, -1 on bad arguments. */
+#define SALSA_NN_ADAM_MAX_TENSORS 192
+#define SALSA_NN_ADAM_CHUNK 8192
+typedef struct { float *p, *m, *v; int64_t n; } salsa_nn_adam_entry;
+int salsa_nn_adam_step(const salsa_nn_adam_entry *table, const float *const *grads, int n_tensors, const int *chunks, int n_chunks,
+                       double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

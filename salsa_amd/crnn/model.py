@@ -230,6 +230,21 @@ class SeldCRNN(nn.Module):
         out = self.decoder(self.encoder(x))
         return {k: interpolate_tensor(v, self.ratio) for k, v in out.items()}
 
+    def pack_parameters(self):
+        """Lay the parameters the decoder stacks every step (the two directions of each GRU parameter, the four heads' weights) out
+        stacked in memory, so that the stack is a view instead of a copy (nn_ops.pack_stacked_parameters).  Values, Parameter
+        objects and state-dict keys are unchanged.  Call it after the last ``.to(device)`` (the Trainer does); returns self."""
+        from .nn_ops import pack_stacked_parameters
+        gru, dec = self.decoder.gru, self.decoder
+        groups = [[getattr(gru, '%s_l%d%s' % (kind, layer, rev)) for rev in ('', '_reverse')]
+                  for layer in range(gru.num_layers) for kind in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        heads = (dec.event, dec.x, dec.y, dec.z)
+        groups += [[h.fc1.weight for h in heads], [h.fc1.bias for h in heads], [h.fc2.weight for h in heads], [h.fc2.bias for h in heads]]
+        pack_stacked_parameters(groups)
+        if hasattr(gru, '_flat_weights'):      # nn.GRU caches references to its weights for the (unused here) MIOpen path
+            gru._flat_weights = [getattr(gru, n) if hasattr(gru, n) else None for n in gru._flat_weights_names]
+        return self
+
     def load_reference_state_dict(self, sd, strict: bool = True):
         """Load weights trained with the reference (``torch.load(ckpt)`` or its ``['state_dict']``, experiments/inference.py:
         115-116): see salsa_amd/crnn/checkpoint.py."""

@@ -264,10 +264,52 @@ class _StackGroups(torch.autograd.Function):
         return (None,) + tuple(None if g is None else g[j] for g in gouts for j in range(n))
 
 
+class _StackViews(torch.autograd.Function):
+    """``torch.stack(g)`` for a group whose tensors already LIE stacked (pack_stacked_parameters): the result is a view of their
+    common storage -- no kernel at all; the backward hands out views of the incoming gradient like _StackGroups."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        t0 = tensors[0].detach()
+        return t0.as_strided((len(tensors),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()), t0.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[j] for j in range(g.shape[0]))
+
+
+def _lie_stacked(group):
+    """the group's tensors are contiguous, equally shaped slices of ONE storage, one after the other"""
+    t0 = group[0]
+    if not t0.is_contiguous():
+        return False
+    n, base, sp = t0.numel(), t0.storage_offset(), t0.untyped_storage().data_ptr()
+    return all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and t.untyped_storage().data_ptr() == sp
+               and t.storage_offset() == base + j * n for j, t in enumerate(group))
+
+
+def pack_stacked_parameters(groups):
+    """Re-home every group of same-shaped parameters in ONE buffer, one after the other (their ``.data`` become slices of it; the
+    Parameter objects, their values and everything that refers to them -- optimizer, state dict, hooks -- are untouched), so
+    that ``stack_groups`` finds them already stacked and returns a view: the two directions of every GRU parameter and the four
+    heads' weights used to be copied into a stack every step (three multi-tensor copies, ~0.06 ms).  Moving the module to another
+    device or dtype afterwards un-packs them again (``stack_groups`` then copies, as before): call this last."""
+    with torch.no_grad():
+        for g in groups:
+            if _lie_stacked(g):
+                continue
+            buf = torch.stack([t.detach() for t in g]).contiguous()
+            for j, t in enumerate(g):
+                t.data = buf[j]
+
+
 def stack_groups(groups):
-    """groups: lists of equally many same-shaped tensors -> the stacked tensor of every group (see _StackGroups)."""
+    """groups: lists of equally many same-shaped tensors -> the stacked tensor of every group: a view where the group already lies
+    stacked in memory (pack_stacked_parameters), one multi-tensor copy for the rest (see _StackGroups)."""
     n = len(groups[0])
     assert all(len(g) == n for g in groups)
+    if USE_STACK_GROUPS and USE_STACK_VIEWS and all(_lie_stacked(g) for g in groups):
+        return [_StackViews.apply(*g) for g in groups]
     flat = [t for g in groups for t in g]
     if not (USE_STACK_GROUPS and flat[0].is_cuda and hasattr(torch, '_foreach_copy_')):
         return [torch.stack(list(g)) for g in groups]
@@ -275,6 +317,7 @@ def stack_groups(groups):
 
 
 USE_STACK_GROUPS = os.environ.get('SALSA_STACK_GROUPS', '1') != '0'
+USE_STACK_VIEWS = os.environ.get('SALSA_STACK_VIEWS', '1') != '0'   # stacked parameters as views of packed storage (pack_stacked_parameters)
 USE_HIP_FREQ_MEAN = os.environ.get('SALSA_HIP_FREQ_MEAN', '1') != '0'
 
 

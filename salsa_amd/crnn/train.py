@@ -53,6 +53,8 @@ class Trainer:
         self.channels_last = self.device.type == 'cuda' and os.environ.get('SALSA_CHANNELS_LAST', '1') == '1'
         if self.channels_last:
             model = model.to(memory_format=torch.channels_last)
+        if self.device.type == 'cuda':
+            model.pack_parameters()                          # (stacked GRU / head parameters as views: no per-step copies)
         self.raw_model = model
         use_ddp = ddp if ddp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.grad_sync = None
@@ -73,7 +75,11 @@ class Trainer:
         self.model = model
         # one fused kernel per parameter group on the GPU (same update rule; SALSA_FUSED_ADAM=0 -> torch's foreach path)
         fused = self.device.type == 'cuda' and os.environ.get('SALSA_FUSED_ADAM', '1') == '1'
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=LRS[0], fused=fused)
+        if self.device.type == 'cuda' and os.environ.get('SALSA_HIP_ADAM', '1') == '1':
+            from .optim import HipAdam                        # the same rule in ONE launch (torch's fused path: three, 0.17 ms)
+            self.opt = HipAdam(self.model.parameters(), lr=LRS[0])
+        else:
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=LRS[0], fused=fused)
 
     def _input_layout(self, x):
         """channels-last for MIOpen -- unless the first layer runs the stem kernel, which reads the extractor's planar

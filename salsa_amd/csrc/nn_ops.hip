@@ -1135,3 +1135,56 @@ int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b,
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------ Adam, one launch
+namespace {
+struct AdamGrads {
+    const float *g[SALSA_NN_ADAM_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void adam_step_kernel(const salsa_nn_adam_entry *__restrict__ table, const AdamGrads grads,
+                                                        const int2 *__restrict__ chunks, float w1 /* 1 - beta1 */, float beta2,
+                                                        float w2 /* 1 - beta2 */, float step_size, float bc2_sqrt, float eps, float wd)
+{
+    const int2 ch = chunks[blockIdx.x];
+    const salsa_nn_adam_entry e = table[ch.x];
+    const float *__restrict__ g = grads.g[ch.x];
+    const long first = (long)ch.y * SALSA_NN_ADAM_CHUNK;
+    const long last = first + SALSA_NN_ADAM_CHUNK < e.n ? first + SALSA_NN_ADAM_CHUNK : e.n;
+    auto update = [&](float &p, float &m, float &v, float gr) {
+        if (wd != 0.f) gr += p * wd;
+        m = m + w1 * (gr - m);                       // lerp(m, g, 1 - beta1), weight < 0.5
+        v = beta2 * v + w2 * gr * gr;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        p -= step_size * m / denom;
+    };
+    const bool vec = ((((uintptr_t)e.p | (uintptr_t)e.m | (uintptr_t)e.v | (uintptr_t)g) & 15) == 0) && (e.n & 3) == 0;
+    if (vec) {
+        for (long i = first + 4 * threadIdx.x; i < last; i += 4 * 256) {
+            float4 p = *(float4 *)(e.p + i), m = *(float4 *)(e.m + i), v = *(float4 *)(e.v + i);
+            const float4 gr = *(const float4 *)(g + i);
+            update(p.x, m.x, v.x, gr.x); update(p.y, m.y, v.y, gr.y); update(p.z, m.z, v.z, gr.z); update(p.w, m.w, v.w, gr.w);
+            *(float4 *)(e.p + i) = p; *(float4 *)(e.m + i) = m; *(float4 *)(e.v + i) = v;
+        }
+    } else {
+        for (long i = first + threadIdx.x; i < last; i += 256) update(e.p[i], e.m[i], e.v[i], g[i]);
+    }
+}
+} // namespace
+
+extern "C" int salsa_nn_adam_step(const salsa_nn_adam_entry *table, const float *const *grads, int n_tensors, const int *chunks, int n_chunks,
+                                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, void *hip_stream)
+{
+    if (!table || !grads || !chunks || n_tensors <= 0 || n_tensors > SALSA_NN_ADAM_MAX_TENSORS || n_chunks <= 0 || step < 1) return -1;
+    AdamGrads ga;
+    for (int i = 0; i < n_tensors; i++) {
+        if (!grads[i]) return -1;
+        ga.g[i] = grads[i];
+    }
+    for (int i = n_tensors; i < SALSA_NN_ADAM_MAX_TENSORS; i++) ga.g[i] = nullptr;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)hip_stream, table, ga, (const int2 *)chunks,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps,
+                       (float)weight_decay); // (the hyper-parameters combine in double, as torch's kernel does per element)
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+

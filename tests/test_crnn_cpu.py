@@ -521,3 +521,49 @@ def test_bucketed_grad_sync_contract_accumulation_order_and_buffers():
     raises; buckets launch in bucket order on every rank even when gradients arrive in opposite orders (round-3 advice)."""
     port = _free_port()
     mp.spawn(_sync_contract_worker, args=(2, port, ''), nprocs=2, join=True)
+
+
+def test_packed_parameters_stack_as_views_with_the_same_values_and_gradients():
+    """SeldCRNN.pack_parameters (nn_ops.pack_stacked_parameters): the GRU directions' and the four heads' parameters re-homed in
+    stacked buffers -- state dict unchanged, ``stack_groups`` returns a VIEW of the storage (no copy), gradients reach the same
+    Parameter objects with the same values as through the copying path, and moving the module un-packs without breaking anything."""
+    import torch
+    from salsa_amd.crnn import nn_ops
+    from salsa_amd.crnn.model import SeldCRNN
+    torch.manual_seed(3)
+    m = SeldCRNN()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    params = dict(m.named_parameters())
+    assert m.pack_parameters() is m
+    after = m.state_dict()
+    assert before.keys() == after.keys() and all(torch.equal(before[k], after[k]) for k in before)
+    assert all(p is dict(m.named_parameters())[k] for k, p in params.items())           # the same Parameter objects
+    gru = m.decoder.gru
+    heads = (m.decoder.event, m.decoder.x, m.decoder.y, m.decoder.z)
+    groups = [[gru.weight_hh_l1, gru.weight_hh_l1_reverse], [h.fc2.bias for h in heads]]
+    assert all(nn_ops._lie_stacked(g) for g in groups)
+    stack = lambda: [nn_ops.stack_groups([g])[0] for g in groups]                        # (a call takes groups of ONE size)
+    outs = stack()
+    assert outs[0].data_ptr() == gru.weight_hh_l1.data_ptr() and outs[1].shape == (4, 12)
+    w = [torch.randn_like(o) for o in outs]
+    sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+    got = [p.grad.clone() for g in groups for p in g]
+    for g in groups:
+        for p in g:
+            p.grad = None
+    try:
+        nn_ops.USE_STACK_VIEWS = False                                                    # the copying path
+        outs2 = stack()
+        assert outs2[0].data_ptr() != gru.weight_hh_l1.data_ptr() and all(torch.equal(a, b) for a, b in zip(outs, outs2))
+        sum((o * wi).sum() for o, wi in zip(outs2, w)).backward()
+    finally:
+        nn_ops.USE_STACK_VIEWS = True
+    assert all(torch.equal(a, p.grad) for a, p in zip(got, [p for g in groups for p in g]))
+    with torch.no_grad():                                                                 # an optimizer's in-place update is seen
+        gru.weight_hh_l1.add_(1.0)
+    assert torch.equal(nn_ops.stack_groups([groups[0]])[0][0], gru.weight_hh_l1)
+    x = torch.randn(2, 7, 32, 200)
+    y1 = m.eval()(x)['event_frame_logit']
+    m64 = m.double()                                                                       # un-packs: stack_groups copies again
+    assert not nn_ops._lie_stacked([m64.decoder.gru.weight_hh_l1, m64.decoder.gru.weight_hh_l1_reverse])
+    torch.testing.assert_close(m64(x.double())['event_frame_logit'].float(), y1, rtol=1e-4, atol=1e-4)

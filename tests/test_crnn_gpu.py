@@ -1099,3 +1099,46 @@ def test_deterministic_mode_gives_bit_equal_weight_gradients():
     finally:
         nn_ops.set_deterministic(False)
         nn_ops._DET_USER[0] = None               # back to the default: the next differentiable forward selects its device's workspace
+
+
+def test_one_launch_adam_matches_torch_adam():
+    """optim.HipAdam (salsa_nn_adam_step: every tensor of a parameter group in one launch) against torch.optim.Adam on the same
+    gradients: contiguous and channels-last tensors, sizes that are not multiples of 4, tensors that are 4-byte-aligned views, more
+    than one 8192-element chunk, with and without weight decay, a changing learning rate; and the state dict loads into torch's."""
+    from salsa_amd.crnn.optim import HipAdam
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(7)
+    for wd in (0.0, 0.01):
+        base = torch.randn(100003, generator=g)
+        shapes = [(64, 64, 3, 3), (512,), (7,), (3, 5), (20011,), (12, 256)]
+        ref_p, our_p = [], []
+        for sh in shapes:
+            t = torch.randn(sh, generator=g)
+            a, b = t.clone().to(dev), t.clone().to(dev)
+            if len(sh) == 4:
+                a, b = a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)
+            ref_p.append(torch.nn.Parameter(a)); our_p.append(torch.nn.Parameter(b))
+        va, vb = base.clone().to(dev), base.clone().to(dev)                      # an odd-offset view: not 16-byte aligned
+        ref_p.append(torch.nn.Parameter(va[1:50002])); our_p.append(torch.nn.Parameter(vb[1:50002]))
+        ref = torch.optim.Adam(ref_p, lr=3e-4, weight_decay=wd)
+        our = HipAdam(our_p, lr=3e-4, weight_decay=wd)
+        for it in range(6):
+            lr = 3e-4 * (1.0 - 0.1 * it)
+            for opt in (ref, our):
+                opt.param_groups[0]['lr'] = lr
+            for a, b in zip(ref_p, our_p):
+                gr = torch.randn(a.shape, generator=g).to(dev) * (10.0 ** (it - 3))
+                if a.dim() == 4:
+                    gr = gr.contiguous(memory_format=torch.channels_last)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            ref.step(); our.step()
+            for a, b in zip(ref_p, our_p):
+                torch.testing.assert_close(b.detach(), a.detach(), rtol=2e-6, atol=1e-8)
+        for a, b in zip(ref_p, our_p):
+            for key in ('exp_avg', 'exp_avg_sq'):          # (the first moment cancels: tolerance relative to the tensor's scale)
+                want = ref.state[a][key]
+                torch.testing.assert_close(our.state[b][key], want, rtol=2e-6, atol=1e-6 * float(want.abs().max()))
+            assert float(our.state[b]['step']) == float(ref.state[a]['step']) == 6.0
+        again = torch.optim.Adam(our_p, lr=3e-4, weight_decay=wd)
+        again.load_state_dict(our.state_dict())                                   # the same state layout and keys
+        assert float(again.state[our_p[0]]['step']) == 6.0
