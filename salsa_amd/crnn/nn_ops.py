@@ -118,17 +118,25 @@ class _BnAct(torch.autograd.Function):
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
         # the mask seed comes from torch's CPU generator (torch.manual_seed makes it reproducible; no device sync)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_p > 0 else 0
+        # Where something is added before the ReLU the backward cannot recompute the mask from x: it used to read the stored y in
+        # both of its passes just to test `> 0`; the forward now leaves the tests as a bit plane (one byte per 16-byte vector)
+        bits = None
+        if relu and residual is not None and USE_BN_RELU_BITS:
+            bits = torch.empty(x.numel() // _DT[x.dtype][1], dtype=torch.uint8, device=x.device)
+        args = (_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight), _ptr(bias), float(eps), float(momentum),
+                _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu), float(drop_p), seed,
+                _ptr(batches_tracked), _ptr(stats_part), 0 if stats_part is None else stats_part.numel() // (2 * Cn))
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_bn_train_fwd(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], M, Cn, _ptr(weight),
-                                                   _ptr(bias), float(eps), float(momentum), _ptr(running_mean),
-                                                   _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), int(relu),
-                                                   float(drop_p), seed, _ptr(batches_tracked), _ptr(stats_part),
-                                                   0 if stats_part is None else stats_part.numel() // (2 * Cn), _stream(x))
+            if bits is not None:
+                rc = _lib.load().salsa_nn_bn_train_fwd_bits(*args, _ptr(bits), _stream(x))
+            else:
+                rc = _lib.load().salsa_nn_bn_train_fwd(*args, _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd failed (%d)' % rc)
-        # the ReLU mask comes from y only when something was added before the ReLU; otherwise the backward recomputes it from x
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, save)
-        ctx.has_residual, ctx.relu, ctx.drop = residual is not None, bool(relu), (float(drop_p), seed)
+        # the ReLU mask comes from the bit plane (or, with SALSA_BN_RELU_BITS=0, from y) only when something was added before the
+        # ReLU; otherwise the backward recomputes it from x
+        ctx.save_for_backward(x, bits if bits is not None else (y if (relu and residual is not None) else None), weight, bias, save)
+        ctx.has_residual, ctx.relu, ctx.drop = residual is not None, (2 if bits is not None else int(bool(relu))), (float(drop_p), seed)
         return y
 
     @staticmethod
@@ -160,14 +168,21 @@ class _BnReluPool(torch.autograd.Function):
         y = torch.empty((N, Cn, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         save = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
+        bits = None                                  # (with a residual the backward recomputed the mask from x AND the residual)
+        if residual is not None and USE_BN_RELU_BITS:
+            bits = torch.empty(x.numel() // _DT[x.dtype][1], dtype=torch.uint8, device=x.device)
+        args = (_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias), float(eps), float(momentum),
+                _ptr(running_mean), _ptr(running_var), _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _ptr(stats_part),
+                0 if stats_part is None else stats_part.numel() // (2 * Cn))
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_bn_train_fwd_pool(_ptr(x), _ptr(y), _ptr(residual), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
-                                                        float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
-                                                        _ptr(save[0]), _ptr(save[1]), _ptr(ws), _ptr(batches_tracked), _ptr(stats_part),
-                                                        0 if stats_part is None else stats_part.numel() // (2 * Cn), _stream(x))
+            if bits is not None:
+                rc = _lib.load().salsa_nn_bn_train_fwd_pool_bits(*args, _ptr(bits), _stream(x))
+            else:
+                rc = _lib.load().salsa_nn_bn_train_fwd_pool(*args, _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_train_fwd_pool failed (%d)' % rc)
-        ctx.save_for_backward(x, weight, bias, save, residual)
+        ctx.save_for_backward(x, weight, bias, save, bits if bits is not None else residual)
+        ctx.bits, ctx.has_residual = bits is not None, residual is not None
         return y
 
     @staticmethod
@@ -176,21 +191,21 @@ class _BnReluPool(torch.autograd.Function):
         N, Cn, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x, memory_format=torch.channels_last)
-        dres = torch.empty_like(x, memory_format=torch.channels_last) if residual is not None else None
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_residual else None
         dwb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.load().salsa_nn_bn_workspace_bytes(_DT[x.dtype][0], N * H * W, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
         coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
+        fn = _lib.load().salsa_nn_bn_bwd_pool_bits if ctx.bits else _lib.load().salsa_nn_bn_bwd_pool   # (residual = the bit plane)
         with torch.cuda.device(x.device):
-            rc = _lib.load().salsa_nn_bn_bwd_pool(_ptr(gy), _ptr(x), _ptr(residual), _ptr(dx), _ptr(dres), _DT[x.dtype][0], N, H, W, Cn,
-                                                  _ptr(weight), _ptr(bias),
-                                                  _ptr(save[0]), _ptr(save[1]), _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef),
-                                                  _stream(x))
+            rc = fn(_ptr(gy), _ptr(x), _ptr(residual), _ptr(dx), _ptr(dres), _DT[x.dtype][0], N, H, W, Cn, _ptr(weight), _ptr(bias),
+                    _ptr(save[0]), _ptr(save[1]), _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef), _stream(x))
         if rc:
             raise RuntimeError('salsa_nn_bn_bwd_pool failed (%d)' % rc)
         return dx, dwb[0].to(weight.dtype), dwb[1].to(weight.dtype), None, None, None, None, None, None, dres
 
 
 USE_HIP_BN_POOL = os.environ.get('SALSA_HIP_BN_POOL', '1') != '0'
+USE_BN_RELU_BITS = os.environ.get('SALSA_BN_RELU_BITS', '1') != '0'   # ReLU masks of the residual BatchNorms as bit planes (round 4)
 USE_HIP_BN_RES_POOL = os.environ.get('SALSA_HIP_BN_RES_POOL', '1') != '0'   # ... with a residual: the blocks before a stride-2 block
 
 

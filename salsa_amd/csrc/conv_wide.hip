@@ -744,6 +744,9 @@ __global__ __launch_bounds__(WG_NT, 1) void conv3x3_wide_wrw_kernel(const unsign
 //    entries; vpos[] of its 128 pixels, 5 entries), so no load returns into a register and the compiler inserts no vmcnt wait of
 //    its own; the kernel waits by COUNT at the top of an iteration -- everything but the loads of the previous iteration --
 //    and every wave issues a launch-constant number of loads per iteration (x: nx = 1..3 by wave, dy: 4, tables: 1);
+//    The count errs on the safe side only: where the compiler turns a `cond ? tensor : zeros` source into two exec-masked loads
+//    a wave has MORE loads in flight than counted and the wait is stricter than needed, never laxer; nothing in the loop lets it
+//    issue fewer (the LDS-direct builtins have side effects: they are neither merged nor dropped).
 //  * the x buffers are sized for the map (W = 50: 304 slots instead of 448): 3 x (19 + 32) KiB + rings = 159 KiB of LDS.
 // Maps too wide for that keep the kernel above.
 #ifndef WRW_AUX

@@ -27,6 +27,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 
 template <typename V, int L> struct vec_io;
 template <> struct vec_io<f32x4, 4> {
+    typedef float4 raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const void *p) { return *(const float4 *)p; }
+    static __device__ __forceinline__ void convert(const raw_t &t, float *f) { f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w; }
     static __device__ __forceinline__ void load(const void *p, float *f)
     {
         const float4 t = *(const float4 *)p;
@@ -35,9 +38,10 @@ template <> struct vec_io<f32x4, 4> {
     static __device__ __forceinline__ void store(void *p, const float *f) { *(float4 *)p = make_float4(f[0], f[1], f[2], f[3]); }
 };
 template <> struct vec_io<bf16x8, 8> {
-    static __device__ __forceinline__ void load(const void *p, float *f)
+    typedef uint4 raw_t;
+    static __device__ __forceinline__ raw_t load_raw(const void *p) { return *(const uint4 *)p; }
+    static __device__ __forceinline__ void convert(const raw_t &t, float *f)
     {
-        const uint4 t = *(const uint4 *)p;
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -45,6 +49,7 @@ template <> struct vec_io<bf16x8, 8> {
             f[2 * i + 1] = bf2f((unsigned short)(w[i] >> 16));
         }
     }
+    static __device__ __forceinline__ void load(const void *p, float *f) { convert(load_raw(p), f); }
     static __device__ __forceinline__ void store(void *p, const float *f)
     {
         unsigned w[4];
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
                                                        const char *__restrict__ residual, long M, int C,
                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                                       DropArgs drop)
+                                                       DropArgs drop, unsigned char *__restrict__ live_bits = nullptr)
 {
     const int cv = C / L, rpi = 256 / cv;
     const int cx = threadIdx.x % cv, ry = threadIdx.x / cv;
@@ -325,6 +330,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
             for (int k = 0; k < L; k++) v[k] = keep[k] ? v[k] * drop.scale : 0.f;
         }
         vec_io<V, L>::store(y + off, v);
+        if (live_bits) { // training: one byte per vector, bit k = "output k is positive" -- what the backward passes otherwise read y for
+            unsigned b = 0;
+#pragma unroll
+            for (int k = 0; k < L; k++) b |= (v[k] > 0.f ? 1u : 0u) << k;
+            live_bits[r * cv + cx] = (unsigned char)b;
+        }
     }
 }
 
@@ -335,7 +346,8 @@ template <typename V, int L>
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const char *__restrict__ x, char *__restrict__ y, long n_vec, int H, int W,
                                                             int C, const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            const char *__restrict__ res /* like x, added before the ReLU; or NULL */)
+                                                            const char *__restrict__ res /* like x, added before the ReLU; or NULL */,
+                                                            unsigned char *__restrict__ live_bits = nullptr /* full resolution */)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_vec) return;
@@ -360,15 +372,27 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const char *__restri
         vec_io<V, L>::load(q + (long)W * cv * 16, rv[2]);
         vec_io<V, L>::load(q + ((long)W * cv + cv) * 16, rv[3]);
     }
+    unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < L; k++) {
         const float mu = mean[c * L + k], is = invstd[c * L + k], ga = gamma[c * L + k], be = beta[c * L + k];
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc += fmaxf(((v[q][k] - mu) * is) * ga + be + (res ? rv[q][k] : 0.f), 0.f); // (same order as the backward's mask)
+        for (int q = 0; q < 4; q++) {
+            const float pre = ((v[q][k] - mu) * is) * ga + be + (res ? rv[q][k] : 0.f); // (same order as the backward's mask)
+            bits[q] |= (pre > 0.f ? 1u : 0u) << k;
+            acc += fmaxf(pre, 0.f);
+        }
         o[k] = acc * 0.25f;
     }
     vec_io<V, L>::store(y + i * 16, o);
+    if (live_bits) { // one byte per full-resolution vector (see bn_apply_kernel)
+        const long v0 = (p - x) / 16;
+        live_bits[v0] = (unsigned char)bits[0];
+        live_bits[v0 + cv] = (unsigned char)bits[1];
+        live_bits[v0 + (long)W * cv] = (unsigned char)bits[2];
+        live_bits[v0 + (long)W * cv + cv] = (unsigned char)bits[3];
+    }
 }
 
 // gradient vector of input row r when dy is the POOLED gradient [N][H/2][W/2][C]: dy[pooled row] / 4, zero in a dropped odd
@@ -389,7 +413,8 @@ __device__ __forceinline__ void pooled_grad(const char *__restrict__ gp, long r,
 
 // g = dy * (y > 0) ; sums[0][C] += sum g (= dbeta) ; sums[1][C] += sum g * xhat (= dgamma)
 // MASK: 0 no ReLU, 1 ReLU mask from the stored output y, 2 recomputed from x, 3 recomputed from x and the residual that was
-// added (passed in y's place: the fused-pool layers store no full-resolution output); DROP: fused dropout (compile-time, so
+// added (passed in y's place: the fused-pool layers store no full-resolution output), 4 (round 4) from the bit plane the forward
+// left (passed in y's place: one byte per vector instead of a 16-byte read of y / the residual); DROP: fused dropout (compile-time, so
 // the element loop has no branches)
 template <typename V, int L, int MASK, bool DROP, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restrict__ dy, const char *__restrict__ y,
@@ -418,20 +443,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
             float g[BN_BATCH][L], xv[BN_BATCH][L], yv[BN_BATCH][L];
             long vec[BN_BATCH];
             bool ok[BN_BATCH];
+            unsigned mb[BN_BATCH];
+            typename vec_io<V, L>::raw_t rg[BN_BATCH], rx[BN_BATCH], ry_[BN_BATCH];
 #pragma unroll
             for (int u = 0; u < BN_BATCH; u++) { // all of the batch's loads first (see bn_stats_kernel)
                 const long r = row0 + (long)(it0 + u) * rpi + ry;
                 ok[u] = r < M;
                 vec[u] = (ok[u] ? r : M - 1) * cv + cx;
+                // (raw loads here, conversions in a second loop: written as load + convert per vector, the MASK 4 instantiation
+                // came out as load / wait / convert / load / wait ... -- four serialised round trips per batch)
                 if (POOL) pooled_grad<V, L>(dy, ok[u] ? r : M - 1, cv, cx, PH, PW, g[u]); // dy = the pooled gradient
-                else vec_io<V, L>::load(dy + vec[u] * 16, g[u]);
-                vec_io<V, L>::load(x + vec[u] * 16, xv[u]);
-                if (MASK == 1 || MASK == 3) vec_io<V, L>::load(y + vec[u] * 16, yv[u]); // (MASK 3: y is the RESIDUAL that was added)
+                else rg[u] = vec_io<V, L>::load_raw(dy + vec[u] * 16);
+                rx[u] = vec_io<V, L>::load_raw(x + vec[u] * 16);
+#ifndef BN_PROBE_NO_Y // (timing probe: what the backward passes would cost if the ReLU mask came from a bit plane instead of y)
+                if (MASK == 1 || MASK == 3) ry_[u] = vec_io<V, L>::load_raw(y + vec[u] * 16); // (MASK 3: y is the RESIDUAL that was added)
+#endif
+                if (MASK == 4) mb[u] = ((const unsigned char *)y)[vec[u]]; // the forward's bit plane: 1 byte instead of 16
+            }
+#pragma unroll
+            for (int u = 0; u < BN_BATCH; u++) {
+                if (!POOL) vec_io<V, L>::convert(rg[u], g[u]);
+                vec_io<V, L>::convert(rx[u], xv[u]);
+#ifndef BN_PROBE_NO_Y
+                if (MASK == 1 || MASK == 3) vec_io<V, L>::convert(ry_[u], yv[u]);
+#else
+                if (MASK == 1 || MASK == 3) for (int k = 0; k < L; k++) yv[u][k] = 1.f;
+#endif
             }
 #pragma unroll
             for (int u = 0; u < BN_BATCH; u++) {
                 bool keep[L];
-                if (DROP && MASK != 1) drop_keep<L>(vec[u] * L, drop, keep); // a stored y already holds the dropped zeros
+                if (DROP && MASK != 1 && MASK != 4) drop_keep<L>(vec[u] * L, drop, keep); // a stored y (or its bit plane) already holds the dropped zeros
 #pragma unroll
                 for (int k = 0; k < L; k++) {
                     const float xh = (xv[u][k] - mu[k]) * is[k];
@@ -441,10 +483,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char *__restri
                     if (MASK == 1) live = live && yv[u][k] > 0.f;
                     if (MASK == 2) live = live && xh * ga[k] + be[k] > 0.f;
                     if (MASK == 3) live = live && xh * ga[k] + be[k] + yv[u][k] > 0.f;
-                    if (DROP && MASK != 1) live = live && keep[k];
+                    if (MASK == 4) live = live && ((mb[u] >> k) & 1u);
+                    if (DROP && MASK != 1 && MASK != 4) live = live && keep[k];
                     const float gk = live ? (DROP ? g[u][k] * drop.scale : g[u][k]) : 0.f;
                     db[k] += gk;
-                    dg[k] += gk * xh;
+                    dg[k] = fmaf(gk, xh, dg[k]); // (explicit: every MASK instantiation must round alike -- bit planes on == off)
                 }
             }
         }
@@ -509,7 +552,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         if (POOL) pooled_grad<V, L>(dy, r, cv, cx, PH, PW, g);
         else vec_io<V, L>::load(dy + off, g);
         vec_io<V, L>::load(x + off, xv);
-        if (y) vec_io<V, L>::load(y + off, yv);
+        unsigned mbits = 0;
+        if (mask_from_x == 3) mbits = ((const unsigned char *)y)[r * cv + cx]; // y = the forward's bit plane
+        else {
+#ifndef BN_PROBE_NO_Y
+            if (y) vec_io<V, L>::load(y + off, yv);
+#else
+            if (y) for (int k = 0; k < L; k++) yv[k] = 1.f;
+#endif
+        }
         if (drop.thresh) {
             bool keep[L];
             if (!y || mask_from_x == 2) drop_keep<L>((r * cv + cx) * L, drop, keep);
@@ -519,7 +570,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
 #pragma unroll
         for (int k = 0; k < L; k++) {
             const float xc = xv[k] - mu[k];
-            const bool zero = mask_from_x == 2 ? !((xc * is[k]) * ga[k] + be[k] + yv[k] > 0.f) // y = the residual that was added
+            const bool zero = mask_from_x == 3 ? !((mbits >> k) & 1u)
+                            : mask_from_x == 2 ? !((xc * is[k]) * ga[k] + be[k] + yv[k] > 0.f) // y = the residual that was added
                                                : y ? !(yv[k] > 0.f) : (mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f));
             if (zero) g[k] = 0.f;
             xv[k] = a[k] * (g[k] - b[k] - xc * kk[k]);
@@ -900,10 +952,10 @@ size_t salsa_nn_bn_workspace_bytes(int dtype, int64_t M, int C)
     return sizeof(double) * 2 * C + sizeof(double) * 2 * (size_t)C * bn_reduce_blocks(dtype, M, C);
 }
 
-int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
-                          const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                          float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
-                          int64_t *batches_tracked, const double *stats_part, int stats_blocks, void *hip_stream)
+static int bn_train_fwd_impl(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                             const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                             float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                             int64_t *batches_tracked, const double *stats_part, int stats_blocks, void *live_bits, void *hip_stream)
 {
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || !bn_geometry_ok(dtype, M, C) || drop_p < 0.f ||
         drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32))
@@ -921,8 +973,30 @@ int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtyp
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nparts, (long)M, C, eps, momentum, save_mean,
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     NN_LAUNCH(bn_apply_kernel, dim3(bn_apply_blocks(dtype, M, C)), dim3(256), (const char *)x, (char *)y,
-              (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed));
+              (const char *)residual, (long)M, C, save_mean, save_invstd, gamma, beta, relu, drop_args(drop_p, drop_seed),
+              (unsigned char *)live_bits);
     return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_bn_train_fwd(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                          float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                          int64_t *batches_tracked, const double *stats_part, int stats_blocks, void *hip_stream)
+{
+    return bn_train_fwd_impl(x, y, residual, dtype, M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                             sums_ws, relu, drop_p, drop_seed, batches_tracked, stats_part, stats_blocks, nullptr, hip_stream);
+}
+
+/* The same, also leaving live_bits[M * C / L] (L = 8 bf16 | 4 float32 elements per byte: bit k of byte i = "output element L i + k is
+ * positive"): the ReLU mask for salsa_nn_bn_bwd(relu = 2), which then reads one byte where it read 16 of y (round 4). */
+int salsa_nn_bn_train_fwd_bits(const void *x, void *y, const void *residual, int dtype, int64_t M, int C, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                               float *save_mean, float *save_invstd, double *sums_ws, int relu, float drop_p, uint32_t drop_seed,
+                               int64_t *batches_tracked, const double *stats_part, int stats_blocks, void *live_bits, void *hip_stream)
+{
+    if (!live_bits || !relu) return -1;
+    return bn_train_fwd_impl(x, y, residual, dtype, M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                             sums_ws, relu, drop_p, drop_seed, batches_tracked, stats_part, stats_blocks, live_bits, hip_stream);
 }
 
 /* Training statistics ONLY (round 4): mean / invstd, running statistics and the batch count from the per-workgroup partial rows
@@ -952,7 +1026,9 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
                     int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd, int relu,
                     float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, float drop_p, uint32_t drop_seed, void *hip_stream)
 {
-    const int mask_from_x = relu && !y_or_null;
+    const bool bits = relu == 2; // y_or_null is the forward's bit plane (salsa_nn_bn_train_fwd_bits)
+    if (bits && !y_or_null) return -1;
+    const int mask_from_x = bits ? 3 : (relu && !y_or_null);
     const DropArgs drop = drop_args(drop_p, drop_seed);
     if (drop_p < 0.f || drop_p >= 1.f || (int64_t)M * C >= ((int64_t)1 << 32)) return -1;
     // dx == NULL: only dgamma, dbeta and the coefficient table coef_ws[7][C] are produced, for a consumer that forms dx on the fly
@@ -974,14 +1050,16 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
                                (const char *)y_or_null, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, \
                                part);                                                                                           \
     } while (0)
-    const int mask_mode = !relu ? 0 : (y_or_null ? 1 : 2);
+    const int mask_mode = !relu ? 0 : bits ? 4 : (y_or_null ? 1 : 2);
     if (drop.thresh) {
         if (mask_mode == 0) BN_REDUCE(0, true);
         else if (mask_mode == 1) BN_REDUCE(1, true);
+        else if (mask_mode == 4) BN_REDUCE(4, true);
         else BN_REDUCE(2, true);
     } else {
         if (mask_mode == 0) BN_REDUCE(0, false);
         else if (mask_mode == 1) BN_REDUCE(1, false);
+        else if (mask_mode == 4) BN_REDUCE(4, false);
         else BN_REDUCE(2, false);
     }
 #undef BN_REDUCE
@@ -995,10 +1073,10 @@ int salsa_nn_bn_bwd(const void *dy, const void *y_or_null, const void *x, void *
 
 /* BatchNorm (training) + ReLU + 2x2 average pool in one pass over x (the stem's tail, models/model_utils.py:187-228):
  * x [N][H][W][C] -> y [N][H/2][W/2][C]; statistics over all N*H*W rows like salsa_nn_bn_train_fwd. */
-int salsa_nn_bn_train_fwd_pool(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
-                               const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
-                               float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
-                               const double *stats_part, int stats_blocks, void *hip_stream)
+static int bn_train_fwd_pool_impl(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
+                                  const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                  float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+                                  const double *stats_part, int stats_blocks, void *live_bits, void *hip_stream)
 {
     const int64_t M = N * H * W;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !sums_ws || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
@@ -1017,19 +1095,41 @@ int salsa_nn_bn_train_fwd_pool(const void *x, void *y, const void *residual, int
                        save_invstd, running_mean, running_var, (long long *)batches_tracked);
     const long n_vec = (long)N * (H / 2) * (W / 2) * (C / (dtype == 1 ? 8 : 4));
     NN_LAUNCH(bn_apply_pool_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), (const char *)x, (char *)y, n_vec, H, W, C,
-              save_mean, save_invstd, gamma, beta, (const char *)residual);
+              save_mean, save_invstd, gamma, beta, (const char *)residual, (unsigned char *)live_bits);
     return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_bn_train_fwd_pool(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
+                               const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+                               const double *stats_part, int stats_blocks, void *hip_stream)
+{
+    return bn_train_fwd_pool_impl(x, y, residual, dtype, N, H, W, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                                  save_invstd, sums_ws, batches_tracked, stats_part, stats_blocks, nullptr, hip_stream);
+}
+
+/* ... also leaving the full-resolution ReLU bit plane live_bits[N * H * W * C / L] (bytes of pixels the pool drops -- an odd last
+ * row / column -- are not written and not used) for salsa_nn_bn_bwd_pool_bits */
+int salsa_nn_bn_train_fwd_pool_bits(const void *x, void *y, const void *residual, int dtype, int64_t N, int H, int W, int C,
+                                    const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                    float *running_var, float *save_mean, float *save_invstd, double *sums_ws, int64_t *batches_tracked,
+                                    const double *stats_part, int stats_blocks, void *live_bits, void *hip_stream)
+{
+    if (!live_bits) return -1;
+    return bn_train_fwd_pool_impl(x, y, residual, dtype, N, H, W, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                                  save_invstd, sums_ws, batches_tracked, stats_part, stats_blocks, live_bits, hip_stream);
 }
 
 /* its backward: dy_pooled [N][H/2][W/2][C] -> dx [N][H][W][C] (+ dres, the residual's gradient, when one was added; + dgamma,
  * dbeta); the ReLU mask is recomputed from x (and the residual) */
-int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, const void *residual, void *dx, void *dres, int dtype, int64_t N, int H,
-                         int W, int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
-                         float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
+static int bn_bwd_pool_impl(const void *dy_pooled, const void *x, const void *residual /* or the bit plane */, bool bits, void *dx,
+                            void *dres, int dtype, int64_t N, int H, int W, int C, const float *gamma, const float *beta,
+                            const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta, double *sums_ws,
+                            float *coef_ws, void *hip_stream)
 {
     const int64_t M = N * H * W;
     if (!dy_pooled || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !sums_ws || !coef_ws ||
-        (residual && !dres) || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
+        (residual && !bits && !dres) || (bits && !residual) || N <= 0 || H < 2 || W < 2 || !bn_geometry_ok(dtype, M, C))
         return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const unsigned nblk = bn_reduce_blocks(dtype, M, C);
@@ -1039,24 +1139,45 @@ int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, const void *resid
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, L, MASK, false, true>), dim3(nblk), dim3(256), 0, st, (const char *)dy_pooled, \
                        (const char *)residual, (const char *)x, (long)M, C, save_mean, save_invstd, gamma, beta, drop, part, H, W)
     if (dtype == 1) {
-        if (residual) BN_POOL_REDUCE(bf16x8, 8, 3);
+        if (bits) BN_POOL_REDUCE(bf16x8, 8, 4);
+        else if (residual) BN_POOL_REDUCE(bf16x8, 8, 3);
         else BN_POOL_REDUCE(bf16x8, 8, 2);
     } else {
-        if (residual) BN_POOL_REDUCE(f32x4, 4, 3);
+        if (bits) BN_POOL_REDUCE(f32x4, 4, 4);
+        else if (residual) BN_POOL_REDUCE(f32x4, 4, 3);
         else BN_POOL_REDUCE(f32x4, 4, 2);
     }
 #undef BN_POOL_REDUCE
+    const int apply_mode = bits ? 3 : residual ? 2 : 1;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, (int)nblk, (long)M, C, gamma, save_mean,
                        save_invstd, beta, coef_ws, dgamma, dbeta);
     if (dtype == 1)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16x8, 8, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
                            (const char *)dy_pooled, (const char *)residual, (const char *)x, (char *)dx, (char *)dres, (long)M, C,
-                           coef_ws, residual ? 2 : 1, drop, H, W);
+                           coef_ws, apply_mode, drop, H, W);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<f32x4, 4, true>), dim3(bn_apply_blocks(dtype, M, C)), dim3(256), 0, st,
                            (const char *)dy_pooled, (const char *)residual, (const char *)x, (char *)dx, (char *)dres, (long)M, C,
-                           coef_ws, residual ? 2 : 1, drop, H, W);
+                           coef_ws, apply_mode, drop, H, W);
     return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
+int salsa_nn_bn_bwd_pool(const void *dy_pooled, const void *x, const void *residual, void *dx, void *dres, int dtype, int64_t N, int H,
+                         int W, int C, const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                         float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
+{
+    return bn_bwd_pool_impl(dy_pooled, x, residual, false, dx, dres, dtype, N, H, W, C, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                            sums_ws, coef_ws, hip_stream);
+}
+
+/* ... with the ReLU mask from the forward's bit plane (salsa_nn_bn_train_fwd_pool_bits) instead of recomputing it from x and the
+ * residual: dres (or NULL) = the gradient of the residual that was added */
+int salsa_nn_bn_bwd_pool_bits(const void *dy_pooled, const void *x, const void *live_bits, void *dx, void *dres, int dtype, int64_t N,
+                              int H, int W, int C, const float *gamma, const float *beta, const float *save_mean,
+                              const float *save_invstd, float *dgamma, float *dbeta, double *sums_ws, float *coef_ws, void *hip_stream)
+{
+    return bn_bwd_pool_impl(dy_pooled, x, live_bits, true, dx, dres, dtype, N, H, W, C, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                            sums_ws, coef_ws, hip_stream);
 }
 
 /* bf16 copies of all hand-written convolution layers' float32 filters in ONE launch: the forward layout [Cout][3][3][Cin] and

@@ -1142,3 +1142,60 @@ def test_one_launch_adam_matches_torch_adam():
         again = torch.optim.Adam(our_p, lr=3e-4, weight_decay=wd)
         again.load_state_dict(our.state_dict())                                   # the same state layout and keys
         assert float(again.state[our_p[0]]['step']) == 6.0
+
+
+def test_relu_bit_planes_leave_every_gradient_bit_equal():
+    """The residual blocks' second BatchNorm: the backward's ReLU mask from the bit plane the forward leaves
+    (salsa_nn_bn_train_fwd_bits / _pool_bits, salsa_nn_bn_bwd relu = 2 / salsa_nn_bn_bwd_pool_bits) instead of from the stored
+    output / the residual -- the bits ARE the tests the backward made, so with the deterministic reductions every gradient of the
+    network and the input gradient are bit-equal with the planes on and off; also at a map with an odd height and width (the pool
+    drops the last row / column: their bytes are never written and must not matter) and in float32."""
+    from salsa_amd.crnn import nn_ops
+    from salsa_amd.crnn.loss import seld_loss
+    from salsa_amd.crnn.train import Trainer, synthetic_batch
+    tr = Trainer('cuda:0', total_steps=10)
+    with torch.no_grad():
+        for m in tr.raw_model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+    x, sed, doa = synthetic_batch(4, 'cuda:0', seed=11)
+    params = [p for p in tr.raw_model.parameters()]
+
+    def grads(on):
+        nn_ops.USE_BN_RELU_BITS = on
+        torch.manual_seed(9)
+        tr.raw_model.zero_grad(set_to_none=True)
+        tr.model.train()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            pred = tr.model(tr._input_layout(x))
+        seld_loss(pred, sed, doa)[0].backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in params]
+
+    try:
+        a, b = grads(True), grads(False)
+        names = [n for n, _ in tr.raw_model.named_parameters()]
+        assert nn_ops.is_deterministic()
+        for n, ga, gb in zip(names, a, b):
+            assert torch.equal(ga, gb), n
+        # the layers alone, ragged pooled map, both dtypes, gradient of the input and of the residual too
+        g = torch.Generator(device='cuda').manual_seed(1)
+        for dtype in (torch.bfloat16, torch.float32):
+            for pool in (False, True):
+                outs = []
+                for on in (True, False):
+                    nn_ops.USE_BN_RELU_BITS = on
+                    bn = nn_ops.BatchNormAct2d(64).cuda().train()
+                    with torch.no_grad():
+                        bn.weight.copy_(torch.linspace(0.5, 1.5, 64)); bn.bias.copy_(torch.linspace(-0.3, 0.3, 64))
+                    gg = torch.Generator(device='cuda').manual_seed(5)
+                    xx = torch.randn((3, 64, 9, 7), device='cuda', generator=gg).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                    rr = torch.randn((3, 64, 9, 7), device='cuda', generator=gg).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                    y = bn.relu_pool(xx, residual=rr) if pool else bn(xx, residual=rr, relu=True)
+                    gy = torch.randn(y.shape, device='cuda', generator=gg).to(dtype)
+                    y.backward(gy)
+                    outs.append((y.detach().clone(), xx.grad.clone(), rr.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+                for u, v in zip(*outs):
+                    assert torch.equal(u, v), (dtype, pool)
+    finally:
+        nn_ops.USE_BN_RELU_BITS = True
