@@ -309,32 +309,50 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char *__restrict__ 
     }
     const int nrows = bn_apply_rows(M, rpi);
     const long row0 = (long)blockIdx.x * rpi * nrows;
-#pragma unroll 4
-    for (int it = 0; it < nrows; it++) {
-        const long r = row0 + (long)it * rpi + ry;
-        if (r >= M) break;
-        const long off = (r * cv + cx) * 16;
-        float v[L], rs[L];
-        vec_io<V, L>::load(x + off, v);
-        if (residual) vec_io<V, L>::load(residual + off, rs);
+    // Rows in batches of four with ALL of a batch's loads issued before anything is converted (a row past the end re-reads the last
+    // row and is not stored).  Written as load / compute / store per row with a `break` at the end of the map, every row was its own
+    // memory round trip (tools/asm_serial_loads.py: four serialised loads in the loop): invisible on the large maps, where enough
+    // waves are resident to hide it, and most of the time of the small ones (round 4).
+    static_assert(BN_APPLY_ROWS_MAX % 4 == 0, "row batches");
+    for (int it0 = 0; it0 < nrows; it0 += 4) {
+        if (row0 + (long)it0 * rpi >= M) break; // (uniform per workgroup: the whole batch is past the end)
+        typename vec_io<V, L>::raw_t rx[4], rr[4];
+        long vecs[4];
+        bool ok[4];
 #pragma unroll
-        for (int k = 0; k < L; k++) {
-            float o = ((v[k] - mu[k]) * is[k]) * ga[k] + be[k];
-            if (residual) o += rs[k];
-            v[k] = relu ? fmaxf(o, 0.f) : o;
+        for (int u = 0; u < 4; u++) {
+            const long r = row0 + (long)(it0 + u) * rpi + ry;
+            ok[u] = r < M;
+            vecs[u] = (ok[u] ? r : M - 1) * cv + cx;
+            rx[u] = vec_io<V, L>::load_raw(x + vecs[u] * 16);
+            if (residual) rr[u] = vec_io<V, L>::load_raw(residual + vecs[u] * 16);
         }
-        if (drop.thresh) {
-            bool keep[L];
-            drop_keep<L>((r * cv + cx) * L, drop, keep);
 #pragma unroll
-            for (int k = 0; k < L; k++) v[k] = keep[k] ? v[k] * drop.scale : 0.f;
-        }
-        vec_io<V, L>::store(y + off, v);
-        if (live_bits) { // training: one byte per vector, bit k = "output k is positive" -- what the backward passes otherwise read y for
-            unsigned b = 0;
+        for (int u = 0; u < 4; u++) {
+            float v[L], rs[L];
+            vec_io<V, L>::convert(rx[u], v);
+            if (residual) vec_io<V, L>::convert(rr[u], rs);
 #pragma unroll
-            for (int k = 0; k < L; k++) b |= (v[k] > 0.f ? 1u : 0u) << k;
-            live_bits[r * cv + cx] = (unsigned char)b;
+            for (int k = 0; k < L; k++) {
+                float o = ((v[k] - mu[k]) * is[k]) * ga[k] + be[k];
+                if (residual) o += rs[k];
+                v[k] = relu ? fmaxf(o, 0.f) : o;
+            }
+            if (drop.thresh) {
+                bool keep[L];
+                drop_keep<L>(vecs[u] * L, drop, keep);
+#pragma unroll
+                for (int k = 0; k < L; k++) v[k] = keep[k] ? v[k] * drop.scale : 0.f;
+            }
+            if (ok[u]) {
+                vec_io<V, L>::store(y + vecs[u] * 16, v);
+                if (live_bits) { // training: one byte per vector, bit k = "output k is positive" -- what the backward passes otherwise read y for
+                    unsigned bb = 0;
+#pragma unroll
+                    for (int k = 0; k < L; k++) bb |= (v[k] > 0.f ? 1u : 0u) << k;
+                    live_bits[vecs[u]] = (unsigned char)bb;
+                }
+            }
         }
     }
 }
@@ -520,6 +538,78 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     coef[6 * C + c] = gamma[c];
 }
 
+// One workgroup's rows of the backward element-wise pass.  YM (compile-time, so that nothing but loads sits between the loads of a
+// batch): 0 = no second operand (mask from x, or none), 1 = y is a tensor like x (the stored output, or -- mask_from_x 2 -- the
+// residual that was added), 3 = y is the forward's bit plane.
+template <typename V, int L, bool POOL, int YM>
+__device__ __forceinline__ void bn_bwd_apply_rows(const char *__restrict__ dy, const char *__restrict__ y, const char *__restrict__ x,
+                                                  char *__restrict__ dx, char *__restrict__ dres, long M, int cv, int rpi, int cx, int ry,
+                                                  const float (&a)[L], const float (&b)[L], const float (&mu)[L], const float (&kk)[L],
+                                                  const float (&is)[L], const float (&be)[L], const float (&ga)[L], int mask_from_x,
+                                                  const DropArgs &drop, int PH, int PW)
+{
+    const int nrows = bn_apply_rows(M, rpi);
+    const long row0 = (long)blockIdx.x * rpi * nrows;
+    // (rows in batches of four, loads first: see bn_apply_kernel)
+    for (int it0 = 0; it0 < nrows; it0 += 4) {
+        if (row0 + (long)it0 * rpi >= M) break;
+        typename vec_io<V, L>::raw_t rg[4], rx[4], ryv[4];
+        float gp[4][L];
+        unsigned mbv[4] = {0u, 0u, 0u, 0u};
+        long vecs[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long r = row0 + (long)(it0 + u) * rpi + ry;
+            ok[u] = r < M;
+            const long rc = ok[u] ? r : M - 1;
+            vecs[u] = rc * cv + cx;
+            if (POOL) pooled_grad<V, L>(dy, rc, cv, cx, PH, PW, gp[u]);
+            else rg[u] = vec_io<V, L>::load_raw(dy + vecs[u] * 16);
+            rx[u] = vec_io<V, L>::load_raw(x + vecs[u] * 16);
+            if (YM == 3) mbv[u] = ((const unsigned char *)y)[vecs[u]];
+#ifndef BN_PROBE_NO_Y
+            if (YM == 1) ryv[u] = vec_io<V, L>::load_raw(y + vecs[u] * 16);
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float g[L], xv[L], yv[L];
+            if (POOL) {
+#pragma unroll
+                for (int k = 0; k < L; k++) g[k] = gp[u][k];
+            } else vec_io<V, L>::convert(rg[u], g);
+            vec_io<V, L>::convert(rx[u], xv);
+#ifndef BN_PROBE_NO_Y
+            if (YM == 1) vec_io<V, L>::convert(ryv[u], yv);
+#else
+            if (YM == 1) for (int k = 0; k < L; k++) yv[k] = 1.f;
+#endif
+            if (drop.thresh) {
+                bool keep[L];
+                if (YM == 0 || mask_from_x == 2) drop_keep<L>(vecs[u] * L, drop, keep);
+#pragma unroll
+                for (int k = 0; k < L; k++) g[k] = ((YM != 0 && mask_from_x != 2) || keep[k]) ? g[k] * drop.scale : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < L; k++) {
+                const float xc = xv[k] - mu[k];
+                bool zero;
+                if (YM == 3) zero = !((mbv[u] >> k) & 1u);
+                else if (YM == 1) zero = mask_from_x == 2 ? !((xc * is[k]) * ga[k] + be[k] + yv[k] > 0.f) // y = the residual that was added
+                                                          : !(yv[k] > 0.f);
+                else zero = mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f);
+                if (zero) g[k] = 0.f;
+                xv[k] = a[k] * (g[k] - b[k] - xc * kk[k]);
+            }
+            if (ok[u]) {
+                vec_io<V, L>::store(dx + vecs[u] * 16, xv);
+                if (dres) vec_io<V, L>::store(dres + vecs[u] * 16, g);
+            }
+        }
+    }
+}
+
 template <typename V, int L, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restrict__ dy, const char *__restrict__ y,
                                                            const char *__restrict__ x, char *__restrict__ dx,
@@ -541,44 +631,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char *__restric
         be[k] = coef[5 * C + c];
         ga[k] = coef[6 * C + c];
     }
-    const int nrows = bn_apply_rows(M, rpi);
-    const long row0 = (long)blockIdx.x * rpi * nrows;
-#pragma unroll 2
-    for (int it = 0; it < nrows; it++) {
-        const long r = row0 + (long)it * rpi + ry;
-        if (r >= M) break;
-        const long off = (r * cv + cx) * 16;
-        float g[L], xv[L], yv[L];
-        if (POOL) pooled_grad<V, L>(dy, r, cv, cx, PH, PW, g);
-        else vec_io<V, L>::load(dy + off, g);
-        vec_io<V, L>::load(x + off, xv);
-        unsigned mbits = 0;
-        if (mask_from_x == 3) mbits = ((const unsigned char *)y)[r * cv + cx]; // y = the forward's bit plane
-        else {
-#ifndef BN_PROBE_NO_Y
-            if (y) vec_io<V, L>::load(y + off, yv);
-#else
-            if (y) for (int k = 0; k < L; k++) yv[k] = 1.f;
-#endif
-        }
-        if (drop.thresh) {
-            bool keep[L];
-            if (!y || mask_from_x == 2) drop_keep<L>((r * cv + cx) * L, drop, keep);
-#pragma unroll
-            for (int k = 0; k < L; k++) g[k] = ((y && mask_from_x != 2) || keep[k]) ? g[k] * drop.scale : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < L; k++) {
-            const float xc = xv[k] - mu[k];
-            const bool zero = mask_from_x == 3 ? !((mbits >> k) & 1u)
-                            : mask_from_x == 2 ? !((xc * is[k]) * ga[k] + be[k] + yv[k] > 0.f) // y = the residual that was added
-                                               : y ? !(yv[k] > 0.f) : (mask_from_x && !((xc * is[k]) * ga[k] + be[k] > 0.f));
-            if (zero) g[k] = 0.f;
-            xv[k] = a[k] * (g[k] - b[k] - xc * kk[k]);
-        }
-        vec_io<V, L>::store(dx + off, xv);
-        if (dres) vec_io<V, L>::store(dres + off, g);
-    }
+    if (mask_from_x == 3) bn_bwd_apply_rows<V, L, POOL, 3>(dy, y, x, dx, dres, M, cv, rpi, cx, ry, a, b, mu, kk, is, be, ga, mask_from_x, drop, PH, PW);
+    else if (y) bn_bwd_apply_rows<V, L, POOL, 1>(dy, y, x, dx, dres, M, cv, rpi, cx, ry, a, b, mu, kk, is, be, ga, mask_from_x, drop, PH, PW);
+    else bn_bwd_apply_rows<V, L, POOL, 0>(dy, y, x, dx, dres, M, cv, rpi, cx, ry, a, b, mu, kk, is, be, ga, mask_from_x, drop, PH, PW);
 }
 
 // ------------------------------------------------------------------------------------------------ convolution filter bank
