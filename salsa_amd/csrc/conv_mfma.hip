@@ -12,6 +12,7 @@
 // the 64 -> 64 weight gradient (transposing LDS reads; "weight gradient" below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "nn_det.h"
 #include "nn_common.h"
 
@@ -461,10 +462,24 @@ __device__ __forceinline__ void conv64_lds_read(bf16x8 &dst, const unsigned (&rb
 #else
 #define CONV_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
-template <int S, int AD>
-__device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&bb)[AD + 1], f32x16 (&acc)[RPW], const unsigned (&rb)[8])
+// HOOK: called with std::integral_constant<int, j> before step CONV_HOOK_FIRST + CONV_HOOK_EVERY * j, j = 0 .. AFETCH - 1: the
+// kernel issues one wave-load of the tile-after-next there (see "spread fetch" in the kernel)
+#ifndef CONV_HOOK_FIRST
+#define CONV_HOOK_FIRST 2
+#endif
+#ifndef CONV_HOOK_EVERY
+#define CONV_HOOK_EVERY 6
+#endif
+struct conv64_no_hook {
+    template <class J> __device__ __forceinline__ void operator()(J) const {}
+};
+template <int S, int AD, class HOOK = conv64_no_hook>
+__device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&bb)[AD + 1], f32x16 (&acc)[RPW], const unsigned (&rb)[8],
+                                             const HOOK &hook = HOOK())
 {
     constexpr int RING = AD + 1;
+    if constexpr (S >= CONV_HOOK_FIRST && (S - CONV_HOOK_FIRST) % CONV_HOOK_EVERY == 0 && (S - CONV_HOOK_FIRST) / CONV_HOOK_EVERY < 8 && S < 48)
+        hook(std::integral_constant<int, (S - CONV_HOOK_FIRST) / CONV_HOOK_EVERY>{});
     if constexpr (S == 0) {
 #pragma unroll
         for (int s = 0; s < AD; s++) { // (AD is 1 or 2: spelled out so that the fragment numbers stay template constants)
@@ -488,7 +503,7 @@ __device__ __forceinline__ void conv64_steps(const bf16x8 (&af)[9][4], bf16x8 (&
         if constexpr (ir <= 2) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ir * 3 + sx][kc], bb[S % RING], first0 ? f32x16{} : acc[0], 0, 0, 0);
         if constexpr (ir >= 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(ir - 1) * 3 + sx][kc], bb[S % RING], first1 ? f32x16{} : acc[1], 0, 0, 0);
         CONV_SCHED_BARRIER();
-        conv64_steps<S + 1, AD>(af, bb, acc, rb);
+        conv64_steps<S + 1, AD, HOOK>(af, bb, acc, rb, hook);
     }
 }
 
@@ -599,6 +614,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
             hh += wrap;
         }
     };
+    // Spread fetch (round 4 experiment, OFF).  Counters of this kernel at 32 x 640 x 200 (tools/probes/pmc_mem.sh): the CU's L1 is
+    // stalled on pending requests 73 % of the launch and on its translation queue 30 %, while an L2 read is answered in ~800 cycles
+    // on average; it sees 9.5e7 accesses per launch -- one per LANE of every 16-byte load and store, halo re-reads included -- i.e.
+    // 373 k accesses per CU in a 551 k-cycle launch, and with every load answered from one cached line (CONV_ZERO_SRC) the same
+    // accesses pass at 0.96 per cycle in 388 k cycles.  So the L1 path (about one 16-byte lane access per cycle and CU = 8 TB/s over
+    // the chip) is this kernel's second roofline, next to the matrix pipe, and misses make each access dearer.  Hypothesis tested
+    // here: the seven wave-loads of a tile, issued in one burst, block their waves in the ISSUE of the loads; so piece j of the
+    // tile-after-next is issued from inside the multiply (conv64_steps' hook, address formed from the compile-time piece number).
+    // Measured: plain forward 341 -> 349 us, with statistics 411 -> 399, 320 x 100 the same: it is the L1's RATE, not the burst.
+#ifndef CONV_SPREAD_FETCH
+#define CONV_SPREAD_FETCH 0
+#endif
+    struct FetchCtx { const unsigned short *origin; int h_lo, h_hi, w_lo, w_hi, buf; bool on; };
+    auto fetch_ctx = [&](const Cursor &c, int buf, bool on) {
+        FetchCtx f;
+        f.origin = x + geo_off(geo, c.n, c.th * TH, c.tw * TW);
+        f.h_lo = -c.th * TH; f.h_hi = H - c.th * TH; f.w_lo = -c.tw * TW; f.w_hi = W - c.tw * TW;
+        f.buf = buf; f.on = on;
+        return f;
+    };
+    auto fetch_piece = [&](auto jc, const FetchCtx &f) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j < AFETCH) {
+            if (f.on && (j * 256 + wv * 64 < HALO_PIECES)) { // (wave-uniform)
+                const int q = p0 + 32 * j;                                    // this thread's halo pixel of piece j, row-major in 6 x 34
+                const int hq = (q * 241) >> 13, wq = q - hq * HALO_W;         // q / 34 for q < 236
+                const int hh = hq - 1, ww = wq - 1;
+                const bool inside = hh >= f.h_lo && hh < f.h_hi && ww >= f.w_lo && ww < f.w_hi && tid + j * 256 < HALO_PIECES;
+                const unsigned short *src = inside ? f.origin + (hh * geo.sh + ww * geo.sw + blk8) : zero16;
+                unsigned short *dst = xl + f.buf * ABUF + (j * 256 + wv * 64) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
+        }
+    };
+    static_assert(HALO_H * HALO_W + 31 < 236 && AFETCH <= 8, "q / 34 == (q * 241) >> 13; eight hook slots");
     // XF: rewrite this thread's own (landed) pieces of a tile in place
     auto transform = [&](const Cursor &c, int buf) {
         const int h_lo = -c.th * TH, h_hi = H - c.th * TH, w_lo = -c.tw * TW, w_hi = W - c.tw * TW;
@@ -668,7 +719,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #ifndef CONV_NO_BARRIER // (probe)
         __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
 #endif
+#if CONV_SPREAD_FETCH
+        const FetchCtx fctx = fetch_ctx(cursor_of(pahead), (it + 2) % NBUF, tile + 2 * stride < n_tiles); // issued inside the multiply
+#else
         if (tile + 2 * stride < n_tiles) fetch(cursor_of(pahead), (it + 2) % NBUF); // into the buffer of the tile before
+#endif
         const int tw = cur.tw, th = cur.th;
         const long n = cur.n;
         f32x16 acc[RPW];
@@ -699,7 +754,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         // v_mfma_f32_32x32x16_bf16 cannot start until its predecessor's 8 passes have drained (with the ds_read / s_waitcnt /
         // s_nop issue slots between them the gap is the microarchitecture guide's "+43 cycles" case): a third of the MFMAs
         // ran at half rate.  Interleaving row 0 with row 3 alternates the two accumulators on EVERY step.
+#if CONV_SPREAD_FETCH
+        conv64_steps<0, AD>(af, bb, acc, rb, [&](auto jc) { fetch_piece(jc, fctx); });
+#else
         conv64_steps<0, AD>(af, bb, acc, rb);
+#endif
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
