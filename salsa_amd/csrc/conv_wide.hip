@@ -417,7 +417,11 @@ static int wide_tile(int64_t N, int H, int W, int Cout, int *tn)
     const long P = (long)N * H * W;
     const bool big_ok = wide_xl_bytes(512, H, W) <= MAX_XL_BYTES;
     if (Cout % 128 == 0 && big_ok && (P + 511) / 512 * (Cout / 128) >= 192) { *tn = 128; return 512; }
-    if (Cout % 128 == 0 && (P + 255) / 256 * (Cout / 128) >= 192) { *tn = 128; return 256; }
+#ifndef WIDE_SMALL_TN64
+#define WIDE_SMALL_TN64 0 // (round-4 experiment) small maps as 256-pixel x 64-channel tiles, two workgroups per CU, instead of 256 x 128, one per CU:
+                           // 512 -> 512 at 40 x 12: 68.0 -> 66.0 us (+3 %, for twice the input re-reads): not adopted
+#endif
+    if (Cout % 128 == 0 && (P + 255) / 256 * (Cout / 128) >= 192 && !(WIDE_SMALL_TN64 && 2 * wide_xl_bytes(256, H, W) + 2 * 3 * 64 * 64 <= 80 * 1024)) { *tn = 128; return 256; }
     *tn = 64;
     return (big_ok && (P + 511) / 512 * (Cout / 64) >= 192) ? 512 : 256;
 }
