@@ -593,6 +593,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #ifdef CONV_ZERO_SRC // (probe: every halo load answered from one cached line)
             src = zero16;
 #endif
+#ifdef CONV_PROBE_ROLL // (TIMING probe, wrong results: two of the six halo rows answered from one cached line -- the traffic of a tile
+            if (hh < 1) src = zero16; // walk that keeps the rows consecutive tiles share in LDS)
+#endif
 #ifdef CONV_FETCH_COLMAJOR // (TIMING probe, wrong results: neighbouring lanes fetch along the tile's SHORT axis -- contiguous 768-byte
             {              // runs in the transposed geometry -- instead of along the long one, 34 lines a map row apart)
                 const int q = (tid >> 3) + 32 * j, h2 = q % HALO_H - 1, w2 = q / HALO_H - 1;
