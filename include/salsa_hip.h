@@ -50,7 +50,11 @@ enum { SALSA_LAYOUT_PLANAR = 0, SALSA_LAYOUT_INTERLEAVED = 1 };           /* [B]
  * (clip_spatial_alias, :262-263); fmax_doa is not clamped to fs/2.  cond_num = ew_thresh, n_hopframes =
  * covmat_avg_neighbours.  Fewer than 4 microphones: pad the audio with silent channels (the covariance gains zero
  * eigenvalues, the gate and the principal eigenvector are unchanged) and drop the padded output channels. */
-enum { SALSA_FLAG_FLEX = 1, SALSA_FLAG_NO_CLIP_FREQS = 2, SALSA_FLAG_CLIP_SPATIAL_ALIAS = 4 };
+enum { SALSA_FLAG_FLEX = 1, SALSA_FLAG_NO_CLIP_FREQS = 2, SALSA_FLAG_CLIP_SPATIAL_ALIAS = 4,
+       /* verification switch: salsa_extract_batch / salsa_eigvec_feature_batch launch the all-float64 instantiation of the
+        * covariance + eigen kernel instead of the production packed-float32 pair solve with its float64 cold list (same
+        * spill, same masks), so a test can hold the two against each other on the GPU. */
+       SALSA_FLAG_FORCE_F64 = 8 };
 
 enum {
     SALSA_OK = 0,
@@ -118,6 +122,19 @@ size_t salsa_eigvec_workspace_bytes(const salsa_plan *plan, int batch, int n_bin
 int salsa_eigvec_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
                        double *d_out, unsigned char *d_gate, void *d_workspace, size_t workspace_bytes,
                        void *hip_stream);
+
+/* The same stage through the PRODUCTION feature kernel (the instantiation salsa_extract_batch launches: packed-float32 pair solve
+ * + float64 cold list, float32 output, or the float64 one under SALSA_FLAG_FORCE_F64): d_X as above, d_feat float32
+ * [B][7][n_frames][n_bins] of which planes 4-6 are written (time-major, like salsa_extract_batch's output with F = n_bins; planes
+ * 0-3 are not touched).  Exists so that the reference's extract_normalized_eigenvector goldens -- rank-1 windows, eigenvalue
+ * ratios straddling cond_num, u[0] ~ 0, silence -- reach the solver that ships, not only salsa_eigvec_batch's float64 one. */
+int salsa_eigvec_feature_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
+                               float *d_feat, void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
+/* Optional solver statistics (verification / study): d_counters = 4 device uint64, ADDED to by every covariance / eigen launch of
+ * the plan: [0] work-list items (frame pairs), [1] gated frames in them, [2] frames handed to the float64 cold list (the packed
+ * solve's `unsure` + small-pivot fallbacks), [3] tiles.  NULL (the default) detaches; the kernels then touch nothing. */
+int salsa_plan_set_stats(salsa_plan *plan, unsigned long long *d_counters);
 
 /* compute_scaler (salsa_feature_extraction.py:204-262) on device: accumulate float64 sum / sum-of-squares over time of
  * the first n_scaler_channels channels per frequency into d_sums [2][n_scaler_channels][n_freq] (zeroed by the caller

@@ -220,9 +220,12 @@ int salsa_nn_colsum2(const float *a, const float *b, float *out_a, float *out_b,
  * training steps differ in the last bits.  salsa_nn_set_deterministic(ws, bytes) with a device workspace switches all of them to
  * partial SLABS (every workgroup stores its partial sums into its own slab of `ws`) followed by one reduction launch that adds the
  * slabs in slab order -- bit-identical results run to run, at the price of the slab traffic (<= 76 MB per call) and one more
- * launch per call.  ws = NULL switches back to atomics.  The calls then return -5 when `bytes` is too small for a shape
- * (SALSA_NN_DET_WS_BYTES covers every layer of the SELD CRNN at the bench's sizes).  The workspace is shared by all calls: use
- * one stream at a time, as the trainer does.  salsa_nn_get_deterministic: 1 when on. */
+ * launch per call.  The workspace is registered FOR THE DEVICE THAT IS CURRENT at the call (one per device; memory of another
+ * device is refused with -1) and every launcher uses the workspace of the device current at ITS call -- a device without one keeps
+ * the atomics.  ws = NULL switches every device back to atomics.  The calls return -5 when `bytes` is too small for a shape
+ * (SALSA_NN_DET_WS_BYTES covers every layer of the SELD CRNN at the bench's sizes).  On one device the workspace is shared by all
+ * calls: use one stream at a time, as the trainer does (two backward passes racing on two streams of one device need the atomics).
+ * salsa_nn_get_deterministic: 1 when the current device has a workspace. */
 #define SALSA_NN_DET_WS_BYTES ((size_t)160 << 20)
 int salsa_nn_set_deterministic(void *ws, size_t bytes);
 int salsa_nn_get_deterministic(void);

@@ -16,8 +16,7 @@ USE_HIP_CONV = os.environ.get('SALSA_HIP_CONV', '1') != '0'
 USE_HIP_CONV_WIDE = os.environ.get('SALSA_HIP_CONV_WIDE', '1') != '0'   # the 128 / 256 / 512-channel 3x3 layers (conv_wide.hip)
 
 
-_DET_WS = {}                    # device -> workspace tensor
-_DET_ON = [None]                # the device the library's workspace pointer currently names (None: atomics)
+_DET_WS = {}                    # device -> workspace tensor (registered with the library for THAT device)
 DET_WS_BYTES = 160 << 20        # include/salsa_nn.h: SALSA_NN_DET_WS_BYTES
 # Deterministic weight gradients are the DEFAULT (SALSA_DETERMINISTIC=0 opts out): measured at +0.04 - 0.09 ms of a 10.8-ms
 # training step (profiles/r4_ab_notes.txt) for bit-reproducible gradients.
@@ -26,21 +25,28 @@ _DET_ENV = os.environ.get('SALSA_DETERMINISTIC', '1') != '0'
 
 def set_deterministic(on: bool, device=None) -> None:
     """Bit-reproducible weight gradients (include/salsa_nn.h: salsa_nn_set_deterministic): every weight-gradient kernel and the GRU
-    bias column sums write per-workgroup partial slabs into one device workspace and a reduction launch adds them in slab order,
+    bias column sums write per-workgroup partial slabs into a device workspace and a reduction launch adds them in slab order,
     instead of float atomics in arrival order.  On by default: the first differentiable forward of a model on a CUDA device
     switches it on for that device (``SALSA_DETERMINISTIC=0``, or ``set_deterministic(False)`` after it, selects the atomics).
-    One 160-MB workspace per device, shared by all calls: one stream at a time, as the trainer uses it."""
+    One 160-MB workspace PER DEVICE, looked up by the library from the device that is current at each launch (so a backward on
+    cuda:0 never writes through cuda:1's workspace); on one device it is shared by all calls: one stream at a time, as the trainer
+    uses it -- two concurrent backward passes on different streams of one device need ``set_deterministic(False)``."""
     L = _lib.load()
     if not on:
         L.salsa_nn_set_deterministic(None, 0)
-        _DET_ON[0] = None
+        _DET_WS.clear()
         _DET_USER[0] = False
         return
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
     if dev not in _DET_WS:
-        _DET_WS[dev] = torch.empty(DET_WS_BYTES, dtype=torch.uint8, device=dev)
-    L.salsa_nn_set_deterministic(C.c_void_p(_DET_WS[dev].data_ptr()), DET_WS_BYTES)
-    _DET_ON[0] = dev
+        ws = torch.empty(DET_WS_BYTES, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.salsa_nn_set_deterministic(C.c_void_p(ws.data_ptr()), DET_WS_BYTES)
+        if rc:
+            raise RuntimeError('salsa_nn_set_deterministic failed (%d) on %s' % (rc, dev))
+        _DET_WS[dev] = ws
     _DET_USER[0] = True
 
 
@@ -445,7 +451,7 @@ def new_backward_generation(device=None):
     on a CUDA device this is also where the deterministic-gradient workspace of THAT device is (created and) selected."""
     _GRAD_ZEROS.new_generation()
     if device is not None and device.type == 'cuda' and (_DET_USER[0] is True or (_DET_USER[0] is None and _DET_ENV)) \
-            and _DET_ON[0] != device:
+            and device not in _DET_WS:
         user = _DET_USER[0]
         set_deterministic(True, device)
         _DET_USER[0] = user

@@ -65,9 +65,11 @@ class HipAdam(torch.optim.Optimizer):
                     raise RuntimeError('HipAdam: parameters must be dense in memory')
                 st = self.state[p]
                 if not st:
-                    if 'step_tensor' not in group:               # one host counter shared by the group's parameters
-                        group['step_tensor'] = torch.zeros((), dtype=torch.float32)
-                    st['step'] = group['step_tensor']
+                    # torch.optim.Adam's layout: every parameter owns its `step` (a host float32 scalar).  (Round-4 advice: one
+                    # tensor OBJECT shared by the group survived load_state_dict into torch's single-tensor / foreach paths, which
+                    # then advanced it once per parameter; and a parameter whose first gradient came late inherited the group's
+                    # count.)  143 host scalar increments per step cost nothing.
+                    st['step'] = torch.zeros((), dtype=torch.float32)
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             # the update is element-wise: any dense layout is fine as long as p, its gradient and its moments agree on it
@@ -76,25 +78,29 @@ class HipAdam(torch.optim.Optimizer):
             for p, g in zip(ps, grads):
                 if g.stride() != p.stride() or self.state[p]['exp_avg'].stride() != p.stride():
                     raise RuntimeError('HipAdam: gradient / moment layout differs from the parameter layout')
-            ms = [self.state[p]['exp_avg'] for p in ps]
-            vs = [self.state[p]['exp_avg_sq'] for p in ps]
-            counters = {id(self.state[p]['step']): self.state[p]['step'] for p in ps}      # (normally ONE shared tensor per group)
-            steps = {float(t) for t in counters.values()}
-            if len(steps) != 1:
-                raise RuntimeError('HipAdam: the parameters of a group must share their step count')
-            step = int(steps.pop()) + 1
             beta1, beta2 = group['betas']
             stream = C.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
-            b0 = 0
-            with torch.cuda.device(ps[0].device):
-                for table, cht, n_chunks, nt in self._plan(gi, ps, ms, vs):
-                    gp = (C.c_void_p * nt)(*[g.data_ptr() for g in grads[b0:b0 + nt]])
-                    rc = L.salsa_nn_adam_step(C.c_void_p(table.data_ptr()), gp, nt, C.c_void_p(cht.data_ptr()), n_chunks,
-                                              float(group['lr']), float(beta1), float(beta2), float(group['eps']),
-                                              float(group['weight_decay']), step, stream)
-                    if rc:
-                        raise RuntimeError('salsa_nn_adam_step failed (%d)' % rc)
-                    b0 += nt
-            for t in counters.values():
-                t += 1                              # (host scalars: no kernel)
+            # one launch per DISTINCT step count (the bias correction depends on it): one in any normal run, more only when
+            # parameters started receiving gradients at different times or a torch state dict with uneven counts was loaded
+            by_step = {}
+            for p, g in zip(ps, grads):
+                by_step.setdefault(int(float(self.state[p]['step'])), []).append((p, g))
+            for k, count in enumerate(sorted(by_step)):
+                sub = by_step[count]
+                sp = [p for p, _ in sub]
+                sg = [g for _, g in sub]
+                ms = [self.state[p]['exp_avg'] for p in sp]
+                vs = [self.state[p]['exp_avg_sq'] for p in sp]
+                b0 = 0
+                with torch.cuda.device(sp[0].device):
+                    for table, cht, n_chunks, nt in self._plan((gi, k), sp, ms, vs):
+                        gp = (C.c_void_p * nt)(*[g.data_ptr() for g in sg[b0:b0 + nt]])
+                        rc = L.salsa_nn_adam_step(C.c_void_p(table.data_ptr()), gp, nt, C.c_void_p(cht.data_ptr()), n_chunks,
+                                                  float(group['lr']), float(beta1), float(beta2), float(group['eps']),
+                                                  float(group['weight_decay']), count + 1, stream)
+                        if rc:
+                            raise RuntimeError('salsa_nn_adam_step failed (%d)' % rc)
+                        b0 += nt
+                for p in sp:
+                    self.state[p]['step'] += 1      # (host scalars: no kernel)
         return loss

@@ -910,28 +910,51 @@ __global__ __launch_bounds__(256) void seld_loss_scale_kernel(const float *__res
 
 } // namespace
 
-static float *g_det_ws = nullptr;
-static size_t g_det_bytes = 0;
+// One workspace PER DEVICE (round-4 advice: a single process-global pointer, re-pointed by whichever device ran a forward last,
+// made the backward kernels of device A write their slabs through device B's pointer in any single-process multi-device pattern).
+// salsa_nn_set_deterministic registers the workspace for the device that is current at the call; the kernels' launchers look up
+// the device current at THEIR call, so a device without a workspace keeps the atomics instead of borrowing a neighbour's.
+constexpr int DET_MAX_DEV = 64;
+static float *g_det_ws[DET_MAX_DEV] = {};
+static size_t g_det_bytes[DET_MAX_DEV] = {};
+static int det_device()
+{
+    int d = -1;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < DET_MAX_DEV) ? d : -1;
+}
 extern "C" int salsa_nn_set_deterministic(void *ws, size_t bytes)
 {
-    g_det_ws = (float *)ws;
-    g_det_bytes = ws ? bytes : 0;
+    if (!ws) { // off, everywhere
+        for (int i = 0; i < DET_MAX_DEV; i++) g_det_ws[i] = nullptr, g_det_bytes[i] = 0;
+        return 0;
+    }
+    const int d = det_device();
+    if (d < 0) return -6;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ws) == hipSuccess && at.type == hipMemoryTypeDevice && at.device != d) return -1; // not this device's memory
+    g_det_ws[d] = (float *)ws;
+    g_det_bytes[d] = bytes;
     return 0;
 }
-extern "C" int salsa_nn_get_deterministic(void) { return g_det_ws != nullptr; }
+extern "C" int salsa_nn_get_deterministic(void)
+{
+    const int d = det_device();
+    return d >= 0 && g_det_ws[d] != nullptr;
+}
 float *salsa_nn_det_begin(int slabs, long n, hipStream_t st, int *rc)
 {
     *rc = 0;
-    if (!g_det_ws) return nullptr;
+    const int d = det_device();
+    if (d < 0 || !g_det_ws[d]) return nullptr;
     const size_t need = (size_t)slabs * (size_t)n * sizeof(float);
-    if (need > g_det_bytes) {
+    if (need > g_det_bytes[d]) {
         *rc = -5;
         return nullptr;
     }
     // (no clearing pass: every kernel's workgroups cover every element of their slabs -- grids are sized so that no workgroup is
     // idle -- and the GPU test runs on a NaN-poisoned workspace; a 75-MB memset per call was most of this mode's cost)
     (void)st;
-    return g_det_ws;
+    return g_det_ws[d];
 }
 int salsa_nn_det_finish(const float *ws, int slabs, long n, float *dw, hipStream_t st)
 {

@@ -75,6 +75,8 @@ struct KParams {
     double snr_ratio;     // indicator_sig = mag > snr_ratio * floor (1.5, :36; contrib: floor_mask_ratio)
     const float *sc_mean; // optional fused normalise-on-load of the spectrogram channels: [4][F] mean / std, or NULL
     const float *sc_std;
+    unsigned long long *stats; // optional solver counters (salsa_plan_set_stats), or NULL
+    int force_f64;             // SALSA_FLAG_FORCE_F64: the float64 instantiation of the covariance / eigen kernel
 };
 
 constexpr int FEATURE_LOGSPEC_ONLY = 3;
@@ -973,6 +975,14 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
     if (FAST) { // cold loop: the few gated bins the hot loop could not finish, general path, one frame per item
         __syncthreads();
         const int ns = nslow;
+        if (kp.stats && tid == 0) { // (verification counters; NULL in production)
+            int live = 0;
+            for (int s = 0; s < n; s++) live += __popc((list[s] >> 12) & 15);
+            atomicAdd(&kp.stats[0], (unsigned long long)n);
+            atomicAdd(&kp.stats[1], (unsigned long long)live);
+            atomicAdd(&kp.stats[2], (unsigned long long)ns);
+            atomicAdd(&kp.stats[3], 1ull);
+        }
         for (int s = tid; s < ns; s += K3_NT) {
             const int i = slow[s];
             const int t = t0 + (i >> 8), bin = bin0 + (i & 255);
@@ -1014,7 +1024,7 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
 {
     const bool gated = kp.tracking || kp.flex; // (!ungated: the coherence test decides, so passing bins have a spectral gap)
     // (the packed pair solve: feature output only -- salsa_eigvec_batch keeps float64 results -- and never for contrib's variant)
-    if (FEAT && SALSA_PK && K3_GROUP == 2 && kp.n_hop == 3 && gated && SALSA_COL0 && !kp.flex && kp.cond > 1.0 && kp.cond < 1e6)
+    if (FEAT && SALSA_PK && K3_GROUP == 2 && kp.n_hop == 3 && gated && SALSA_COL0 && !kp.flex && kp.cond > 1.0 && kp.cond < 1e6 && !kp.force_f64)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true, FEAT && K3_GROUP == 2>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else if (kp.n_hop == 3 && gated && SALSA_COL0)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
@@ -1347,6 +1357,7 @@ struct salsa_plan {
     double *d_window;
     cplx<double> *d_tw;
     const float *sc_mean, *sc_std; // caller-owned device arrays set by salsa_plan_set_scaler (or NULL)
+    unsigned long long *stats;     // caller-owned device counters set by salsa_plan_set_stats (or NULL)
     int timing;
     int stop_after; // measurement only: 1 = issue the STFT launch alone, 2 = STFT + tracker, 0 = the whole path (salsa_plan_set_timing(plan, -1 | -2))
     int n_kernels;
@@ -1619,6 +1630,8 @@ static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
     kp.delta = pl->delta;
     kp.sc_mean = pl->sc_mean;
     kp.sc_std = pl->sc_std;
+    kp.stats = pl->stats;
+    kp.force_f64 = (pl->p.flags & SALSA_FLAG_FORCE_F64) != 0;
     return kp;
 }
 
@@ -1646,7 +1659,10 @@ static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, 
     const int fpb = 4 * (lite ? NF_LITE : single ? NF_PAIR : NF_FULL); // frames per workgroup
     const unsigned nblk = (unsigned)((kp.T + fpb - 1) / fpb);
     dim3 grid(nblk, (unsigned)kp.B);
-    if (pl->p.n_fft == 512 && kp.sc_mean && !single) { // a scaler is attached: the instantiation with the tables in LDS
+    // a scaler is attached: the instantiation with the tables in LDS -- which hold [2][4 * 256] floats, so only while F <= 256 (the
+    // contrib plan with SALSA_FLAG_NO_CLIP_FREQS and a lite band from bin 0 have F = 257: they take the plain kernel, whose
+    // store path reads the tables from global memory at any F)
+    if (pl->p.n_fft == 512 && kp.sc_mean && !single && kp.F <= 256) {
         constexpr size_t SCT_BYTES = 2 * 4 * 256 * sizeof(float);
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
@@ -1929,6 +1945,48 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + K3_NT - 1) / K3_NT));
     launch_cov_eig<false>(kp, grid, s, Xs, valid, (float *)nullptr, d_out, d_gate);
     HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_eigvec_feature_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
+                               float *d_feat, void *d_workspace, size_t workspace_bytes, void *hip_stream)
+{
+    if (!pl || !d_X || !d_feat || batch <= 0 || n_bins <= 0 || n_frames <= 0)
+        return fail(SALSA_EINVAL, "salsa_eigvec_feature_batch: bad argument%s");
+    if ((int64_t)n_frames * 2 * n_bins >= INT32_MAX / 8 || (int64_t)n_frames * 7 * n_bins >= INT32_MAX / 2)
+        return fail(SALSA_EINVAL, "block too large for 32-bit per-clip indexing%s");
+    if ((n_frames + K3_FT - 1) / K3_FT > 65535) return fail(SALSA_EINVAL, "block too long for one launch%s");
+    const size_t need = salsa_eigvec_workspace_bytes(pl, batch, n_bins, n_frames);
+    if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
+    hipStream_t s = (hipStream_t)hip_stream;
+    KParams kp = make_kparams(pl, batch, 0);
+    kp.T = (int)n_frames;
+    kp.nd = n_bins;
+    kp.lower = lower_bin;
+    kp.upper = lower_bin + n_bins;
+    kp.F = n_bins;
+    kp.OC = 7;
+    kp.feature = SALSA_FEATURE_SALSA;
+    float4 *Xs = (float4 *)d_workspace;
+    unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
+    const long total = (long)batch * n_bins * n_frames * 2;
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
+    HIP_TRY(hipGetLastError());
+    if (kp.tracking) {
+        hipLaunchKernelGGL(tracker_kernel, dim3(tracker_grid(kp)), dim3(64 * TR_WAVES), 0, s, kp, Xs, valid);
+        HIP_TRY(hipGetLastError());
+    }
+    const unsigned ntile = (unsigned)((kp.T + K3_FT - 1) / K3_FT);
+    dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + K3_NT - 1) / K3_NT));
+    launch_cov_eig<true>(kp, grid, s, Xs, valid, d_feat, (double *)nullptr, (unsigned char *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_plan_set_stats(salsa_plan *pl, unsigned long long *d_counters)
+{
+    if (!pl) return fail(SALSA_EINVAL, "salsa_plan_set_stats: NULL plan%s");
+    pl->stats = d_counters;
     return SALSA_OK;
 }
 

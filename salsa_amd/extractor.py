@@ -78,6 +78,18 @@ class SalsaExtractor:
             _raise(rc)
         self._ws = None
         self._prefix_mode = False
+        self._scaler = None
+        self._pipe = None                            # (n_groups, split_pairs, graph) once set_pipeline / set_groups was called
+
+    def copy_plan_state_to(self, other: 'SalsaExtractor'):
+        """Re-apply to ``other`` (built from kwargs()) the plan state attached AFTER construction: the fused scaler and the
+        pipelined schedule.  (Timing / prefix-issue modes are measurement state and are not carried over.)"""
+        if self._scaler is not None:
+            other.set_scaler(*self._scaler)
+        else:
+            other.set_scaler(None)
+        if self._pipe is not None:
+            other.set_pipeline(*self._pipe)
 
     def kwargs(self):
         """the constructor arguments of this extractor (to build further plans with the same parameters: one per pipeline slot)"""
@@ -193,6 +205,35 @@ class SalsaExtractor:
             _raise(rc)
         return (out, gate) if return_gate else out
 
+    def eigvec_features(self, X: torch.Tensor, lower_bin: int) -> torch.Tensor:
+        """extract_normalized_eigenvector through the PRODUCTION feature kernel (salsa_eigvec_feature_batch: the packed-float32
+        pair solve with its float64 cold list, or the float64 instantiation under FLAG_FORCE_F64): X complex64
+        [B,n_bins,n_frames,4] -> float32 [B,3,n_frames,n_bins] (time-major, as extract() writes channels 4-6)."""
+        assert X.is_cuda and X.dtype == torch.complex64 and X.dim() == 4 and X.shape[3] == 4 and X.is_contiguous()
+        B, nb, nt, _ = X.shape
+        feat = torch.zeros((B, 7, nt, nb), dtype=torch.float32, device=X.device)
+        ws = self._workspace(int(self.L.salsa_eigvec_workspace_bytes(self._plan, B, nb, nt)))
+        with torch.cuda.device(self.device):
+            rc = self.L.salsa_eigvec_feature_batch(self._plan, C.c_void_p(X.data_ptr()), B, nb, nt, int(lower_bin),
+                                                   C.c_void_p(feat.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                   self._stream())
+        if rc:
+            _raise(rc)
+        return feat[:, 4:]
+
+    def set_stats(self, on: bool = True):
+        """Attach (or detach) the solver counters (salsa_plan_set_stats); read_stats() returns and clears them."""
+        self._stats = torch.zeros(4, dtype=torch.int64, device=self.device) if on else None
+        rc = self.L.salsa_plan_set_stats(self._plan, C.c_void_p(self._stats.data_ptr()) if on else None)
+        if rc:
+            _raise(rc)
+
+    def read_stats(self):
+        """{'items', 'gated_frames', 'cold_frames', 'tiles'} accumulated by the covariance / eigen launches since the last read"""
+        v = self._stats.cpu().tolist()
+        self._stats.zero_()
+        return dict(items=v[0], gated_frames=v[1], cold_frames=v[2], tiles=v[3])
+
     # ------------------------------------------------------------------------------------------------ timing
     def set_timing(self, enable):
         """False / 0: off.  True / 1: an event pair around every launch.  K > 1: every kernel of a call is launched K times back
@@ -237,6 +278,7 @@ class SalsaExtractor:
             rc = self.L.salsa_plan_set_groups(self._plan, int(n_groups))
         if rc:
             _raise(rc)
+        self._pipe = (int(n_groups),) + (self._pipe[1:] if self._pipe else (False, False))
 
     def set_pipeline(self, n_groups: int = 1, split_pairs: bool = False, graph: bool = False):
         """Pipelined schedule of extract() (include/salsa_hip.h salsa_plan_set_pipeline): clip groups on plan-owned streams,
@@ -246,6 +288,7 @@ class SalsaExtractor:
             rc = self.L.salsa_plan_set_pipeline(self._plan, int(n_groups), flags)
         if rc:
             _raise(rc)
+        self._pipe = (int(n_groups), bool(split_pairs), bool(graph))
 
     def read_timing(self):
         """[(kernel name, milliseconds)] of the last extract() call (HIP events on its stream)."""

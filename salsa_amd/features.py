@@ -141,7 +141,6 @@ class _FilePipeline:
     An exception in any thread stops the run and is re-raised by ``run``."""
 
     def __init__(self, ex, depth=3, writers=8):
-        import queue
         torch = _torch()
         from .extractor import SalsaExtractor
         self.torch, self.depth, self.writers = torch, depth, writers
@@ -149,7 +148,6 @@ class _FilePipeline:
         dev = ex.device
         self.slots = [dict(idx=i, ex=self.exs[i], n=None, s_in=torch.cuda.Stream(device=dev), s_run=torch.cuda.Stream(device=dev),
                            s_out=torch.cuda.Stream(device=dev)) for i in range(depth)]
-        self.free, self.filled, self.inflight = queue.Queue(), queue.Queue(), queue.Queue()
         self.error = None
 
     def _buffers(self, sl, batch, n_samples):
@@ -164,12 +162,35 @@ class _FilePipeline:
         sl['h_out'] = torch.empty(oshape, dtype=torch.float32, pin_memory=True)
         sl['n'] = (batch, n_samples)
 
+    def _fail(self, e):
+        """Record the first failure of any thread and tell every other thread to stop."""
+        self.error = self.error or e
+        self.stop.set()
+
+    def _take(self, q):
+        """q.get() that gives up (returns _STOP) once any thread has failed: no stage may block forever on a queue whose
+        producer is gone (round-4 advice: a failed extract() or writer left the reader in free.get() and run() in join())."""
+        import queue
+        while True:
+            try:
+                return q.get(timeout=0.05)
+            except queue.Empty:
+                if self.stop.is_set():
+                    return _STOP
+
     def run(self, todo, audio_dir, feature_dir, fs, batch_size, stats=None):
         """todo: [(count, file name)] in order.  Writes <feature_dir>/<feature_name(fn)> for every clip."""
+        import queue
         import threading
         import time
         from concurrent.futures import ThreadPoolExecutor
         torch = self.torch
+        self.free, self.filled, self.inflight = queue.Queue(), queue.Queue(), queue.Queue()
+        self.stop, self.error = threading.Event(), None
+        # the clones were built from the constructor arguments only: carry over the plan state attached since (round-4
+        # advice: with a scaler on the caller's extractor, two of every three batches came out un-normalised)
+        for other in self.exs[1:]:
+            self.exs[0].copy_plan_state_to(other)
         for sl in self.slots:
             self.free.put(sl)
         t_read, t_write = [0.0], [0.0]
@@ -185,7 +206,7 @@ class _FilePipeline:
                     sl['items'] = items
                     self.filled.put(sl)
                 for count, fn in todo:
-                    if self.error:
+                    if self.stop.is_set():
                         return
                     t0 = time.perf_counter()
                     a = sio.load_audio(os.path.join(audio_dir, fn), sr=fs)
@@ -194,7 +215,9 @@ class _FilePipeline:
                     if n not in open_:
                         if len(open_) >= self.depth - 1:    # never hold every slot half-filled: flush the fullest bucket
                             close(max(open_, key=lambda k: len(open_[k][1])))
-                        sl = self.free.get()
+                        sl = self._take(self.free)
+                        if sl is _STOP:
+                            return
                         self._buffers(sl, cap, n)
                         open_[n] = (sl, [])
                     sl, items = open_[n]
@@ -210,7 +233,7 @@ class _FilePipeline:
                 for n in sorted(open_, key=lambda k: open_[k][1][0][0]):
                     close(n)
             except BaseException as e:                      # noqa: BLE001 - re-raised by run()
-                self.error = self.error or e
+                self._fail(e)
             finally:
                 self.filled.put(None)
 
@@ -219,8 +242,8 @@ class _FilePipeline:
             try:
                 torch.cuda.set_device(self.exs[0].device)
                 while True:
-                    sl = self.inflight.get()
-                    if sl is None:
+                    sl = self._take(self.inflight)
+                    if sl is None or sl is _STOP:
                         return
                     sl['done'].synchronize()
                     t0 = time.perf_counter()
@@ -233,9 +256,7 @@ class _FilePipeline:
                     t_write[0] += time.perf_counter() - t0
                     self.free.put(sl)
             except BaseException as e:                      # noqa: BLE001
-                self.error = self.error or e
-                while self.inflight.get() is not None:      # keep draining so that nobody blocks on us
-                    pass
+                self._fail(e)
             finally:
                 pool.shutdown(wait=True)
 
@@ -244,8 +265,8 @@ class _FilePipeline:
         n_batches = 0
         try:
             while True:
-                sl = self.filled.get()
-                if sl is None or self.error:
+                sl = self._take(self.filled)
+                if sl is None or sl is _STOP:
                     break
                 b = len(sl['items'])
                 with torch.cuda.stream(sl['s_in']):
@@ -260,22 +281,22 @@ class _FilePipeline:
                     sl['done'].record(sl['s_out'])
                 self.inflight.put(sl)
                 n_batches += 1
+        except BaseException as e:                          # noqa: BLE001 - a failed copy / extract in THIS thread stops the others too
+            self._fail(e)
         finally:
-            self.inflight.put(None)
+            self.inflight.put(None)                         # (the writer finishes what is in flight, or leaves at once after a failure)
             tw.join()
-            if self.error:                                  # unblock a reader waiting for a slot, then let it end
-                for sl in self.slots:
-                    self.free.put(sl)
             tr.join()
-            while not self.free.empty():
-                self.free.get_nowait()
-            while not self.filled.empty():
-                self.filled.get_nowait()
+            if self.error:                                  # in-flight device work may still touch the pinned slots
+                torch.cuda.synchronize(self.exs[0].device)
         if self.error:
             e, self.error = self.error, None
             raise e
         if stats is not None:
             stats.update(batches=n_batches, read_s=t_read[0], write_s=t_write[0])
+
+
+_STOP = object()
 
 
 USE_FILE_PIPELINE = os.environ.get('SALSA_FILE_PIPELINE', '1') != '0'

@@ -54,6 +54,39 @@ def test_config2_batch32_full_size_properties(dev, oracle):
         _check(out2[i].cpu().numpy(), ref, aux['margin'])
 
 
+def _both_instantiations(dev, ys, **kw):
+    """The production covariance / eigen instantiation (packed float32 + float64 cold list) and the all-float64 one
+    (FLAG_FORCE_F64) on ONE batch -- same STFT kernel, same tracker, so the same spill and masks: gate pattern bit-equal,
+    features inside the bar, spectrogram channels bit-equal; returns the production run's solver counters."""
+    from salsa_amd import _lib
+    a = torch.from_numpy(ys).to(dev)
+    ex = _extractor(**kw)
+    ex.set_stats(True)
+    out = ex.extract(a)
+    st = ex.read_stats()
+    ref = _extractor(flags=_lib.FLAG_FORCE_F64, **kw).extract(a)
+    assert torch.equal(out[:, :4], ref[:, :4])
+    g0, g1 = (out[:, 4:] != 0).any(dim=1), (ref[:, 4:] != 0).any(dim=1)
+    assert torch.equal(g0, g1), 'gate patterns differ in %d TF bins' % int((g0 != g1).sum())
+    err = (out[:, 4:] - ref[:, 4:]).abs() - (1e-6 + 1e-5 * ref[:, 4:].abs())
+    assert float(err.max()) <= 0.0, float(err.max())
+    st['emitted'] = int(g0.sum())
+    return st
+
+
+def test_config2_packed_solver_equals_float64_instantiation(dev):
+    """Round-4 review item 2(i): the 32 clips of config 2 through both instantiations on one spill; 32 MIC 8-s chunks likewise."""
+    from bench import make_batch
+    st = _both_instantiations(dev, make_batch(2021, 32, 60 * 24000))
+    assert 0 < st['cold_frames'] < 0.05 * st['gated_frames'], st
+    print('config 2, FOA 32 x 60 s: %(gated_frames)d gated frames in %(items)d items, %(cold_frames)d to the float64 cold list, '
+          '%(emitted)d emitted' % st)
+    ys = np.stack([synth_clip(4021 + i, 8 * 24000) for i in range(32)])
+    st = _both_instantiations(dev, ys, audio_format='mic', fmax_doa=4000)
+    assert st['cold_frames'] < 0.1 * st['gated_frames'], st
+    print('config 4 chunks, MIC 32 x 8 s: %(gated_frames)d gated frames, %(cold_frames)d to the float64 cold list, %(emitted)d emitted' % st)
+
+
 def test_full_size_lite_and_mic_clips_against_oracle(dev, oracle):
     """One 60-s clip through SALSA-Lite (config 1's shape) and one through full SALSA MIC (fmax_doa 4 kHz, config 4's
     extractor) against the oracle -- the goldens hold 3-s clips only."""

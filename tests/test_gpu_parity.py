@@ -114,6 +114,77 @@ def test_eigvec_adversarial_golden(dev, oracle):
         assert np.array_equal(gate[0].cpu().numpy() > 0, a[case + '_sig_mask']), case
 
 
+# ------------------------------------------------------------------ the PRODUCTION solver (packed float32 + float64 cold list)
+def _feat_vs_ref(out_f32, ref_f64, margin=None, tol_scale=1.0):
+    """out (3, T, nb) float32 from the feature kernel vs ref (3, nb, T) float64 of the reference: the feature bar
+    1e-6 + 1e-5 |ref|; where a margin array is given, a disagreement is admitted only inside round-off of the gate."""
+    out = np.transpose(out_f32, (0, 2, 1)).astype(np.float64)
+    fin = np.isfinite(ref_f64)
+    assert np.array_equal(np.isfinite(out), fin)
+    with np.errstate(invalid='ignore'):
+        bad = ((np.abs(out - ref_f64) > tol_scale * (ATOL_SP + RTOL * np.abs(ref_f64))) & fin).any(axis=0)
+    if bad.any():
+        assert margin is not None, '%d TF bins outside the bar' % bad.sum()
+        assert np.all(np.abs(margin[bad]) < 1e-9), np.abs(margin[bad])[:8]
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_production_solver_matches_reference_golden(dev, oracle, seed):
+    """Round-4 review, missing 1 / weak 1: goldens g1 reached the GPU only through salsa_eigvec_batch, which is hard-wired to the
+    float64 instantiation.  salsa_eigvec_feature_batch runs the instantiation salsa_extract_batch launches -- the packed-float32
+    pair solve with its float64 cold list -- on the same blocks; FLAG_FORCE_F64 runs the float64 one through the same entry."""
+    from salsa_amd import _lib
+    meta, a = load_golden('g1_eigvec_s%d' % seed)
+    X = synth_stft_block(seed, meta['n_bins'], meta['n_frames'], kind=meta['kind'])
+    Xd = torch.from_numpy(X[None]).to(dev)
+    cold = 0
+    for fmt, key, kw, lb in (('foa', 'foa_track', {}, 1), ('mic', 'mic_track', {}, 1), ('foa', 'foa_track_cond2', dict(cond_num=2.0), 1),
+                             ('mic', 'mic_track_lb7', {}, 7)):
+        cond = kw.get('cond_num', 5.0)
+        _, aux = oracle.extract_normalized_eigenvector(X, cond, 3, True, fmt, fs=24000, n_fft=512, lower_bin=lb, return_aux=True)
+        outs = []
+        for flags in (0, _lib.FLAG_FORCE_F64):
+            ex = _extractor(audio_format=fmt, fmax_doa=9000 if fmt == 'foa' else 4000, flags=flags, **kw)
+            ex.set_stats(True)
+            out = ex.eigvec_features(Xd, lb)[0].cpu().numpy()
+            st = ex.read_stats()
+            _feat_vs_ref(out, a[key], aux['margin'])
+            outs.append(out)
+            if flags == 0:
+                cold += st['cold_frames']
+                assert st['gated_frames'] == int(a['sig_mask'].sum()), (st, int(a['sig_mask'].sum()))   # the tracker's gate, bit for bit
+        # the two instantiations against each other: same gate pattern, features inside the bar
+        assert np.array_equal((outs[0] != 0).any(axis=0), (outs[1] != 0).any(axis=0))
+        np.testing.assert_allclose(outs[0], outs[1], rtol=RTOL, atol=ATOL_SP)
+    print('g1 seed %d: %d frames handed to the float64 cold list' % (seed, cold))
+
+
+def test_production_solver_adversarial_golden(dev, oracle):
+    """Goldens g2 (exact rank-1 windows, eigenvalue ratios 4.999 / 5.001 around cond_num, u[0] ~ 0, silence, constant magnitude,
+    level steps) through the packed-float32 instantiation and through the float64 one."""
+    from salsa_amd import _lib
+    meta, a = load_golden('g2_adversarial')
+    report = {}
+    for case in meta['cases']:
+        X = a['X_' + case]
+        Xd = torch.from_numpy(np.ascontiguousarray(X[None])).to(dev)
+        for fmt in ('foa', 'mic'):
+            ref = a['%s_%s_track' % (case, fmt)]
+            _, aux = oracle.extract_normalized_eigenvector(X, 5.0, 3, True, fmt, fs=24000, n_fft=512, lower_bin=1, return_aux=True)
+            for flags in (0, _lib.FLAG_FORCE_F64):
+                ex = _extractor(audio_format=fmt, fmax_doa=9000 if fmt == 'foa' else 4000, flags=flags)
+                ex.set_stats(True)
+                out = ex.eigvec_features(Xd, 1)[0].cpu().numpy()
+                st = ex.read_stats()
+                # u[0] ~ 0: Re(u/u[0]) is ill-conditioned in the reference itself; the float64 test above admits 1e-5 (0.1 + |ref|) there
+                nbad = _feat_vs_ref(out, ref, aux['margin'] if case == 'margin' else None, tol_scale=10.0 if case == 'w_tiny' else 1.0)
+                assert st['gated_frames'] == int(a[case + '_sig_mask'].sum())
+                if flags == 0:
+                    report[(case, fmt)] = (st['gated_frames'], st['cold_frames'], nbad)
+    print('g2 through the packed solve: (gated frames, float64 cold-list frames, margin-admitted) per case: %s' % report)
+
+
 # ----------------------------------------------------------------------------------------------- end-to-end goldens
 def _golden_items(meta, a):
     clips = {k: golden_clip(*v) for k, v in meta['clips'].items()}
