@@ -131,6 +131,15 @@ int salsa_eigvec_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins
 int salsa_eigvec_feature_batch(salsa_plan *plan, const float *d_X, int batch, int n_bins, int64_t n_frames, int lower_bin,
                                float *d_feat, void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* Schedule of salsa_extract_batch for the dataset scripts' main configuration (full SALSA, n_fft 512, n_hopframes 3, tracking on,
+ * cond_num > 1; every other plan ignores the switch).  0: STFT -> tracker -> covariance / eigen, connected by the spectra spilled
+ * to the workspace.  1 (round-5 stage a): STFT -> tracker as before, then ONE fused kernel that recomputes the STFT of a segment
+ * of frames into a ring in LDS, rewrites the log-spectrogram and solves straight from the ring -- the spill is still written (the
+ * tracker reads it) but no longer read back; it exists to measure the fused kernel against the two it replaces (measured:
+ * slower, DESIGN.md section 6 -- the default stays 0).  2 (verification): as 1 with the deferred float64 records switched off,
+ * i.e. every frame the packed solve hands back takes the fused kernel's in-step fallback.  Results are bit-identical in all three. */
+int salsa_plan_set_fused(salsa_plan *plan, int mode);
+
 /* Optional solver statistics (verification / study): d_counters = 4 device uint64, ADDED to by every covariance / eigen launch of
  * the plan: [0] work-list items (frame pairs), [1] gated frames in them, [2] frames handed to the float64 cold list (the packed
  * solve's `unsure` + small-pivot fallbacks), [3] tiles.  NULL (the default) detaches; the kernels then touch nothing. */

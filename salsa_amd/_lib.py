@@ -65,6 +65,7 @@ def load():
     L.salsa_eigvec_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.c_size_t, vp]
     L.salsa_eigvec_feature_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, C.c_size_t, vp]
     L.salsa_plan_set_stats.argtypes = [vp, vp]
+    L.salsa_plan_set_fused.argtypes = [vp, C.c_int]
     L.salsa_plan_set_timing.argtypes = [vp, C.c_int]
     L.salsa_plan_read_timing.argtypes = [vp, fp, C.POINTER(C.c_char_p), ip]
     L.salsa_plan_set_groups.argtypes = [vp, C.c_int]
@@ -149,7 +150,7 @@ def last_error() -> str:
 
 EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
-           'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_eigvec_feature_batch', 'salsa_plan_set_stats', 'salsa_plan_set_timing',
+           'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_eigvec_feature_batch', 'salsa_plan_set_stats', 'salsa_plan_set_fused', 'salsa_plan_set_timing',
            'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_plan_set_pipeline', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
            'salsa_to_freq_major', 'salsa_augment_batch', 'salsa_selftest_decibel', 'salsa_multichannel_workspace_bytes', 'salsa_extract_multichannel']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_fwd_regw', 'salsa_gru_scan_bwd', 'salsa_gru_scan_bwd_regw']

@@ -1034,6 +1034,422 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
 }
 
+// ------------------------------------------------------------------------------------------------------------ fused K1 + K3
+// Round 5: the STFT spill removed from the path.  One workgroup WALKS a segment of L consecutive frames of one clip in steps of
+// FZ_S = 8 frames: its eight waves FFT the step's eight frames (both channel pairs each, exactly stft_kernel's arithmetic), write the
+// log-spectrogram rows of the segment's own frames to the output as before -- and the DOA band of the spectra NOT to a 0.94-GB
+// spill in HBM but into a ring of FZ_RING = 14 frames in LDS ([frame][pair][bin] float4, the spill's own layout); then the same
+// eight waves compact the gated TF bins of the eight frames whose +-3-frame windows are now complete into a work list and run
+// cov_eig_kernel's packed-float32 pair solve with the sixteen 16-byte gathers of an item answered by LDS instead of L2 / HBM.
+// What is recomputed is the 3-frame halo at either end of a SEGMENT (6 / L of the FFT work: 4 % at L = 152), not of an 8-frame
+// tile.  The tracker's masks come from the separate launch before it.
+//  * A wave's audio for the NEXT step is loaded into registers before the solve phase of this one (the barriers between the
+//    phases order LDS traffic only), so the FFT phase starts on data that has arrived.
+//  * The frames the packed solve hands back to float64 (~0.3 % FOA, ~3 % MIC) are not solved inside the step -- one lane's float64
+//    solve would hold the whole workgroup at the step's barrier, 7 k cycles for 1.8 frames per step -- but written out as records
+//    (the 7-frame window, 240 bytes) into a per-workgroup slice of the workspace and solved together at the end of the segment;
+//    a slice that is full (FZ_COLD_CAP records: never on natural signals) falls back to the in-step cold loop.
+//
+// LDS (dynamic, <= 160 KB; one workgroup per CU): [0, 64 KB) the eight waves' FFT buffers -- reused by the solve phase for the
+// output tile of channels 4-6, the work list and the cold list; then the ring (14 x 2 x nd x 16 B: 85.6 KB at nd = 191), the
+// window, the row-offset table and counters, the optional scaler tables.
+constexpr int FZ_S = 8;
+constexpr int FZ_W = 8;
+constexpr int FZ_NT = 64 * FZ_W;
+constexpr int FZ_RING = FZ_S + 6;
+constexpr int FZ_COLD_CAP = 256;    // deferred float64 records per workgroup
+constexpr unsigned FZ_OFF_OTILE = 0, FZ_OFF_LIST = 24576, FZ_OFF_SLOW = FZ_OFF_LIST + 2048, FZ_OFF_RING = 65536;
+struct fz_cold_rec {
+    float4 x[14];                   // window frame k: x[2k] = channel pair 0, x[2k+1] = pair 1
+    int t, bl, pad0, pad1;
+};
+static size_t fused_lds_bytes(int nd, int F, bool scaler) { return FZ_OFF_RING + (size_t)FZ_RING * 32 * nd + 4096 + 128 + (scaler ? 2 * 4 * (size_t)F * 4 : 0); }
+
+template <bool MIC>
+__global__ __launch_bounds__(FZ_NT, 1) void fused_kernel(const KParams kp, const float *__restrict__ audio,
+                                                        const double *__restrict__ window, const cplx<double> *__restrict__ tw,
+                                                        float *__restrict__ out, const unsigned *__restrict__ valid32, const int L,
+                                                        fz_cold_rec *__restrict__ cold_all, const int cold_cap)
+{
+    constexpr int N = 512, R = 8, NP = 2;
+    using T = double;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fz_lds[];
+    const int nd = kp.nd, F = kp.F, Tn = kp.T, Ns = kp.N;
+    const int OWs = (F + 3) & ~3;                                    // columns of the output tile (the zero band above nd included)
+    const unsigned frame_bytes = 32u * (unsigned)nd, half = 16u * (unsigned)nd;
+    cplx<T> *zall = (cplx<T> *)fz_lds;
+    float *otile = (float *)(fz_lds + FZ_OFF_OTILE);
+    unsigned short *list = (unsigned short *)(fz_lds + FZ_OFF_LIST), *slow = (unsigned short *)(fz_lds + FZ_OFF_SLOW);
+    unsigned char *ringb = fz_lds + FZ_OFF_RING;
+    T *wins = (T *)(ringb + (size_t)FZ_RING * frame_bytes);
+    unsigned *rowoff = (unsigned *)(wins + N);                       // [14] + counters (never aliased by the FFT buffers)
+    int *count = (int *)(rowoff + 16), *nslow = count + 1, *ncold = count + 2;
+    float *sct0 = (float *)(rowoff + 32), *sct1 = sct0 + 4 * F;
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * L, f1 = f0 + L < Tn ? f0 + L : Tn;   // own frames [f0, f1)
+    fz_cold_rec *cold = cold_all + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * FZ_COLD_CAP;
+    for (int i = tid; i < N; i += FZ_NT) wins[i] = (T)(0.5 * window[i]);
+    if (kp.sc_mean)
+        for (int i = tid; i < 4 * F; i += FZ_NT) sct0[i] = kp.sc_mean[i], sct1[i] = kp.sc_std[i];
+    if (tid == 0) *count = 0, *nslow = 0, *ncold = 0;
+    cplx<T> w1[NP];
+    {
+        int p = R;
+#pragma unroll
+        for (int q = 0; q < NP; q++, p *= R) {
+            const cplx<double> wd = tw[salsa::stockham_tw(lane, 1, p, N, R)];
+            w1[q] = {(T)wd.re, (T)wd.im};
+        }
+    }
+    __syncthreads();
+    cplx<T> *z = zall + w * N;
+    float *pw = (float *)z;                                          // the compressed band's powers: in the wave's FFT buffer, free after the last pass
+    const float *clip = audio + (long)b * 4 * Ns;
+    const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
+    const int sstride = planar ? 1 : 4;
+    float *o = out + (long)b * kp.OC * Tn * F;
+    const int mlane = (64 - lane) & 63;
+    const unsigned plane = 4u * (unsigned)(Tn * F);
+    auto spec = [&](const float p, const int c, const int f) -> float {
+        const float v = db10(p);
+        const int i = c * F + f;
+        return kp.sc_mean ? (v - sct0[i]) / sct1[i] : v;
+    };
+    auto wrap_frame = [&](const int vf) { // np.pad(..., 'wrap') on the time axis (:43): the halo of the clip's first / last segment
+        int t = vf;
+        t = t < 0 ? t + Tn : t;
+        return t >= Tn ? t - Tn : t;
+    };
+    // the 2 x 2 x 8 samples a lane contributes to the two packed FFTs of one frame
+    auto load_frame = [&](const int vf, float (&y)[2][2][R]) {
+        const int t = wrap_frame(vf);
+        const int base = t * kp.hop - N / 2;
+        const unsigned step = 4u * (unsigned)sstride;
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const int c0 = 2 * pr;
+            const unsigned ch0 = 4u * (unsigned)(planar ? c0 * Ns : c0), ch1 = ch0 + 4u * (unsigned)(planar ? Ns : 1);
+#ifdef FZ_PROBE_NOLOAD
+            if (true) {
+#pragma unroll
+                for (int r = 0; r < R; r++) y[pr][0][r] = (float)(lane + r + t) * 1e-3f, y[pr][1][r] = (float)(lane - r + c0) * 1e-3f;
+            } else
+#endif
+            if (base >= 0 && base + N <= Ns) {
+                const unsigned q = (unsigned)(base + lane) * step;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    y[pr][0][r] = ld_off(clip, ch0 + q + (unsigned)(r * (N / R)) * step);
+                    y[pr][1][r] = ld_off(clip, ch1 + q + (unsigned)(r * (N / R)) * step);
+                }
+            } else { // a frame that overlaps a clip end: np.pad(mode='reflect')
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int sidx = base + salsa::stockham_in(lane, r, N, R);
+                    sidx = sidx < 0 ? -sidx : sidx;
+                    sidx = sidx >= Ns ? 2 * (Ns - 1) - sidx : sidx;
+                    y[pr][0][r] = ld_off(clip, ch0 + (unsigned)sidx * step);
+                    y[pr][1][r] = ld_off(clip, ch1 + (unsigned)sidx * step);
+                }
+            }
+        }
+    };
+    // one frame: both channel pairs (stft_kernel's item, twice)
+    auto fft_frame = [&](const int vf, const float (&y)[2][2][R]) {
+        const int t = wrap_frame(vf);
+        const bool own = vf >= f0 && vf < f1;
+        const int sl = (vf - (f0 - 3)) % FZ_RING;
+        float4 *slot = (float4 *)(ringb + (unsigned)sl * frame_bytes);
+#pragma unroll 1
+        for (int pr = 0; pr < 2; pr++) { // (rolled: unrolled, the two transforms' live ranges overlap and spill)
+            const int c0 = 2 * pr;
+            cplx<T> v[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const T wn = wins[salsa::stockham_in(lane, r, N, R)];
+                const float ya = pr ? y[1][0][r] : y[0][0][r], yb = pr ? y[1][1][r] : y[0][1][r]; // (wave-uniform selects)
+                v[r] = {wn * (T)ya, wn * (T)yb};
+            }
+            salsa::dftR<R>(v);
+#pragma unroll
+            for (int r = 0; r < R; r++) z[swz(salsa::stockham_out(lane, r, 1, R))] = v[r];
+            {
+                int p = R;
+#pragma unroll
+                for (int q = 0; q < NP; q++, p *= R) {
+                    wave_lds_fence();
+#pragma unroll
+                    for (int r = 0; r < R; r++) v[r] = z[swz(salsa::stockham_in(lane, r, N, R))];
+                    wave_lds_fence();
+                    {
+                        const cplx<T> a1 = w1[q], a2 = salsa::cmul(a1, a1), a3 = salsa::cmul(a2, a1), a4 = salsa::cmul(a2, a2);
+                        v[1] = salsa::cmul(v[1], a1);
+                        v[2] = salsa::cmul(v[2], a2);
+                        v[3] = salsa::cmul(v[3], a3);
+                        v[4] = salsa::cmul(v[4], a4);
+                        v[5] = salsa::cmul(v[5], salsa::cmul(a4, a1));
+                        v[6] = salsa::cmul(v[6], salsa::cmul(a3, a3));
+                        v[7] = salsa::cmul(v[7], salsa::cmul(a4, a3));
+                    }
+                    salsa::dftR<R>(v);
+                    if (q + 1 < NP) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) z[swz(salsa::stockham_out(lane, r, p, R))] = v[r];
+                    }
+                }
+            }
+            auto emit_bin = [&](const int k, const cplx<T> a, const cplx<T> bm) {
+                cplx<T> Xa, Xb;
+                salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
+                const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
+                const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
+                if (k >= kp.lower && k < kp.upper) slot[pr * nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
+                if (own) {
+                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                    if (k >= kp.spec_lo && k < kp.spec_hi) {
+                        const unsigned off = 4u * (unsigned)((c0 * Tn + t) * F + (k - kp.spec_lo));
+                        st_off(o, off, spec(pa, c0, k - kp.spec_lo));
+                        st_off(o, off + plane, spec(pb, c0 + 1, k - kp.spec_lo));
+                    } else if (kp.compress && k > kp.ident && k < N / 2) {
+                        pw[k - kp.ident - 1] = pa;
+                        pw[64 + k - kp.ident - 1] = pb;
+                    }
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < R / 2; r++) {
+                cplx<T> bm = {__shfl(v[R - 1 - r].re, mlane), __shfl(v[R - 1 - r].im, mlane)};
+                if (lane == 0) bm = v[(R - r) & (R - 1)];
+                emit_bin(lane + 64 * r, v[r], bm);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (the Nyquist bin belongs to no spectrogram row and no DOA band of the default configuration: a wave-uniform skip)
+            if ((kp.spec_hi > N / 2 || kp.upper > N / 2) && lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2]);
+            if (own && kp.compress) {
+                wave_lds_fence();
+                const int ng = F - kp.ident;
+                const int h = lane & 1, gi = lane >> 1;
+                if (gi < ng) {
+                    const int cnt = gi < ng - 1 ? 8 : 7;
+                    float acc = 0.f;
+                    for (int q = 0; q < cnt; q++) acc += 0.125f * pw[64 * h + 8 * gi + q];
+                    st_off(o, 4u * (unsigned)(((c0 + h) * Tn + t) * F + kp.ident + gi), spec(acc, c0 + h, kp.ident + gi));
+                }
+            }
+            wave_lds_fence();
+        }
+    };
+    auto lds_barrier = [&]() { // orders LDS traffic only: global loads / stores stay in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // float64 covariance of one 7-frame window + the general solve (cov_eig_kernel's cold path); e[] = the feature or zeros
+    auto cold_solve = [&](auto getx, const int bl, double *e) -> bool { // getx(k, a, c): the two float4 of window frame k
+        salsa::herm4<double> Rm = {};
+#pragma unroll 1
+        for (int k = 0; k < 7; k++) {
+            float4 a, c;
+            getx(k, a, c);
+            const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
+                                       {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
+            salsa::herm4_rank1_add(Rm, x);
+        }
+        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec<2>(Rm, kp.cond, kp.inv_cond, false, MIC);
+        if (!er.rank1) return false;
+        if (MIC) salsa::normalise_mic(er.u, kp.delta * (double)(bl + kp.lower), e);
+        else salsa::normalise_foa(er.u, e, false);
+        return true;
+    };
+
+    float y[2][2][R];
+    // prologue: the six frames around the segment's first step that no step produces (v = f0-3 .. f0+2)
+#ifndef FZ_PROBE_NOFFT
+    if (w < 6) {
+        load_frame(f0 - 3 + w, y);
+        fft_frame(f0 - 3 + w, y);
+    }
+    if (f0 + 3 + w < f1 + 3) load_frame(f0 + 3 + w, y);
+#endif
+    const int ng32 = (nd + TR_BINS - 1) / TR_BINS, ng64 = (nd + 63) >> 6;
+    float *of = out + ((long)b * kp.OC + 4) * Tn * F;                 // channels 4-6 of this clip, [3][T][F]
+    const float fcond = (float)kp.cond, finv = (float)kp.inv_cond;
+    for (int fs0 = f0; fs0 < f1; fs0 += FZ_S) {
+        const int nft = f1 - fs0 < FZ_S ? f1 - fs0 : FZ_S;
+        // the tracker's masks of this step's frames (two 32-bin groups x 8 frames per wave of the compaction): issued before the
+        // FFTs, first used after them
+        unsigned myw = 0u;
+        if (w < ng64 && lane < 2 * FZ_S) {
+            const int ft = lane % FZ_S, hf = lane / FZ_S;
+            if (ft < nft && 2 * w + hf < ng32) myw = valid32[((long)b * ng32 + 2 * w + hf) * Tn + fs0 + ft];
+        }
+        // ---- FFT phase: frames fs0+3 .. fs0+10 (as far as the segment's window reaches), then the next step's audio on its way
+#ifndef FZ_PROBE_NOFFT
+        {
+            const int vf = fs0 + 3 + w;
+            if (vf < f1 + 3) fft_frame(vf, y);
+            if (fs0 + FZ_S < f1 && vf + FZ_S < f1 + 3) load_frame(vf + FZ_S, y);
+        }
+#endif
+        lds_barrier(); // B1: the ring holds fs0-3 .. fs0+10; the FFT buffers are free
+#ifdef FZ_PROBE_NOSOLVE
+        if (myw == 0xdeadbeefu) otile[tid] = 1.f;
+        continue;
+#endif
+        // ---- output tile zeroed, row offsets, compaction of the gated TF bins (waves 0 .. ng64-1: one 64-bin group each)
+        for (int i = tid; i < 3 * FZ_S * OWs / 4; i += FZ_NT) ((float4 *)otile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < FZ_RING) rowoff[tid] = (unsigned)((fs0 - f0 + tid) % FZ_RING) * frame_bytes;
+        if (w < ng64) {
+            const int bl = tid;
+            const bool in = bl < nd;
+            const unsigned long long inmask = __ballot(in);
+            unsigned long long words[FZ_S];
+            int total = 0;
+#pragma unroll
+            for (int ft = 0; ft < FZ_S; ft++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)myw, ft), hi = (unsigned)__builtin_amdgcn_readlane((int)myw, FZ_S + ft);
+                words[ft] = (((unsigned long long)hi << 32) | lo) & inmask;
+            }
+#pragma unroll
+            for (int ft = 0; ft < FZ_S; ft += 2) total += __popcll(words[ft] | words[ft + 1]);
+            int base = 0;
+            if (lane == 0 && total) base = atomicAdd(count, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int ft = 0; ft < FZ_S; ft += 2) {
+                const unsigned long long wd = words[ft] | words[ft + 1];
+                if (in) {
+                    const unsigned v = ((unsigned)(words[ft] >> lane) & 1u) | (((unsigned)(words[ft + 1] >> lane) & 1u) << 1);
+                    if (v) list[base + __popcll(wd & ((1ull << lane) - 1))] = (unsigned short)((v << 12) | ((ft / 2) << 8) | bl);
+                }
+                base += __popcll(wd);
+            }
+        }
+        lds_barrier(); // B2
+        const int n = *count;
+        // ---- hot loop: the packed-float32 pair solve of cov_eig_kernel<true, 3, true, true>, windows read from the ring
+        for (int s = tid; s < n; s += FZ_NT) {
+            const int i = list[s];
+            const int ft = 2 * ((i >> 8) & 15), bl = i & 255;
+            constexpr int NW = 8;
+            const unsigned *ro = rowoff + ft;
+            const unsigned boff = 16u * (unsigned)bl;
+            float4 xa[NW], xc[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const unsigned r = ro[k];
+                xa[k] = *(const float4 *)(ringb + r + boff);
+                xc[k] = *(const float4 *)(ringb + r + boff + half);
+            }
+            auto chans = [&](int k, salsa::pk2f *v) {
+                v[0] = salsa::pk2f{xa[k].x, xa[k].y};
+                v[1] = salsa::pk2f{xa[k].z, xa[k].w};
+                v[2] = salsa::pk2f{xc[k].x, xc[k].y};
+                v[3] = salsa::pk2f{xc[k].z, xc[k].w};
+            };
+            salsa::cov4pk Cc = {}, C0, C1;
+            salsa::pk2f v[4];
+#pragma unroll
+            for (int k = 1; k <= 6; k++) {
+                chans(k, v);
+                salsa::cov4pk_rank1(Cc, Cc, v);
+            }
+            chans(0, v);
+            salsa::cov4pk_rank1(C0, Cc, v);
+            chans(7, v);
+            salsa::cov4pk_rank1(C1, Cc, v);
+            const int live = (i >> 12) & 3;
+            int odd;
+            const salsa::herm4<salsa::pk2f> A = salsa::herm4_pk_from_windows(C0, C1, odd);
+            salsa::pk2f e[3];
+            salsa::pk_eig r = salsa::herm4_gate_eigvec_pk<MIC>(A, fcond, finv, live & ~odd);
+            if (r.pass) {
+                if (MIC) salsa::normalise_mic_pk(r, (float)(kp.delta * (double)(bl + kp.lower)), e);
+                else salsa::normalise_foa_pk(r, e);
+            }
+            r.unsure |= odd & live;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if ((r.unsure >> j) & 1) { // float64 decides: a record for the end of the segment (or, slice full, the in-step cold list)
+                    const int ci = atomicAdd(ncold, 1);
+                    if (ci < cold_cap) {
+                        fz_cold_rec *rec = cold + ci;
+#pragma unroll
+                        for (int k = 0; k < 7; k++) {
+                            const unsigned rr = ro[j + k];
+                            rec->x[2 * k] = *(const float4 *)(ringb + rr + boff);
+                            rec->x[2 * k + 1] = *(const float4 *)(ringb + rr + boff + half);
+                        }
+                        rec->t = fs0 + ft + j;
+                        rec->bl = bl;
+                    } else slow[atomicAdd(nslow, 1)] = (unsigned short)(((ft + j) << 8) | bl);
+                } else if ((r.pass >> j) & 1) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) otile[(q * FZ_S + ft + j) * OWs + bl] = e[q][j];
+                }
+            }
+        }
+        lds_barrier(); // B3
+        const int ns = *nslow;
+        if (kp.stats && tid == 0) {
+            int lv = 0;
+            for (int s = 0; s < n; s++) lv += __popc((list[s] >> 12) & 3);
+            atomicAdd(&kp.stats[0], (unsigned long long)n);
+            atomicAdd(&kp.stats[1], (unsigned long long)lv);
+            atomicAdd(&kp.stats[3], 1ull);
+        }
+        if (ns) { // (wave-uniform; only when the record slice overflowed) the in-step cold loop
+            for (int s = tid; s < ns; s += FZ_NT) {
+                const int i = slow[s];
+                const int ft = i >> 8, bl = i & 255;
+                double e[3] = {0.0, 0.0, 0.0};
+                if (cold_solve([&](int k, float4 &a, float4 &c) {
+                        const unsigned rr = rowoff[ft + k] + 16u * (unsigned)bl;
+                        a = *(const float4 *)(ringb + rr);
+                        c = *(const float4 *)(ringb + rr + half);
+                    }, bl, e)) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) otile[(q * FZ_S + ft) * OWs + bl] = (float)e[q];
+                }
+            }
+            lds_barrier(); // B4
+        }
+        // ---- channels 4-6 of the step's frames: whole rows (the zeros above the DOA band included, :373-374)
+        if (tid == 0) *count = 0, *nslow = 0;
+        if (!(F & 3)) {
+            const int q = F >> 2;
+            for (int i = tid; i < 3 * nft * q; i += FZ_NT) {
+                const int row = i / q, col = i - row * q, c = row / nft, ft = row - c * nft;
+                *(float4 *)(of + ((long)(c * Tn + fs0 + ft) * F + 4 * col)) = *(const float4 *)(otile + (c * FZ_S + ft) * OWs + 4 * col);
+            }
+        } else {
+            for (int i = tid; i < 3 * nft * F; i += FZ_NT) {
+                const int row = i / F, col = i - row * F, c = row / nft, ft = row - c * nft;
+                of[(long)(c * Tn + fs0 + ft) * F + col] = otile[(c * FZ_S + ft) * OWs + col];
+            }
+        }
+        lds_barrier(); // B5: the tile has been read; the next step's FFTs may overwrite it (and the ring's oldest frames)
+    }
+    // ---- the segment's deferred float64 frames: their rows (zeros there) were stored above by this workgroup; __syncthreads()
+    // waits for those stores and for the records, then the passing frames' three values go straight to the output
+    __syncthreads();
+    const int nc = *ncold < cold_cap ? *ncold : cold_cap;
+    if (kp.stats && tid == 0) atomicAdd(&kp.stats[2], (unsigned long long)*ncold);
+#ifndef FZ_PROBE_NOCOLD
+    for (int s = tid; s < nc; s += FZ_NT) {
+        const fz_cold_rec *rec = cold + s;
+        const int t = rec->t, bl = rec->bl;
+        double e[3] = {0.0, 0.0, 0.0};
+        if (cold_solve([&](int k, float4 &a, float4 &c) { a = rec->x[2 * k]; c = rec->x[2 * k + 1]; }, bl, e)) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) of[(long)(q * Tn + t) * F + bl] = (float)e[q];
+        }
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------ K3, N channels
 // contrib/salsa_flexible.py takes ANY number of microphones (stacked_covmat_eigh :52-77: an N x N Hermitian eigenproblem per
 // gated TF bin).  The 4 x 4 closed form above does not generalise, so 5 - 8 microphones (padded to an even count NCH = 6 | 8
@@ -1358,6 +1774,7 @@ struct salsa_plan {
     cplx<double> *d_tw;
     const float *sc_mean, *sc_std; // caller-owned device arrays set by salsa_plan_set_scaler (or NULL)
     unsigned long long *stats;     // caller-owned device counters set by salsa_plan_set_stats (or NULL)
+    int fused;                     // salsa_plan_set_fused: 0 = three kernels; 1 = STFT -> tracker -> fused STFT + covariance / eigen (stage a)
     int timing;
     int stop_after; // measurement only: 1 = issue the STFT launch alone, 2 = STFT + tracker, 0 = the whole path (salsa_plan_set_timing(plan, -1 | -2))
     int n_kernels;
@@ -1383,6 +1800,46 @@ struct salsa_plan {
         int64_t n_samples;
     } gkey;
 };
+
+// the fused kernel serves the dataset scripts' main configuration (what cov_eig_kernel's packed instantiation serves) at sizes
+// whose ring fits the LDS; everything else keeps the three-kernel path
+static bool fused_eligible(const salsa_plan *pl, const KParams &kp)
+{
+    return SALSA_PK && pl->p.n_fft == 512 && kp.feature == SALSA_FEATURE_SALSA && kp.nch == 4 && kp.n_hop == 3 && kp.tracking &&
+           !kp.flex && kp.cond > 1.0 && kp.cond < 1e6 && !kp.force_f64 && kp.nd >= 1 && kp.T >= 4 * FZ_S && kp.F <= 256 &&
+           fused_lds_bytes(kp.nd, kp.F, kp.sc_mean != nullptr) <= 160 * 1024;
+}
+// frames per segment: enough workgroups for every CU, whole rounds of them when the batch allows, segments long enough that
+// the 6-frame halo stays a few percent
+static int fused_segment_frames(const KParams &kp)
+{
+    const long total = (long)kp.B * kp.T;
+    long rounds = (total + 256L * 160 - 1) / (256L * 160);
+    long nseg = (256 * rounds + kp.B - 1) / kp.B;
+    if (nseg < 1) nseg = 1;
+    long Lf = (kp.T + nseg - 1) / nseg;
+    Lf = (Lf + FZ_S - 1) / FZ_S * FZ_S;
+    if (Lf < 4 * FZ_S) Lf = 4 * FZ_S;
+    return (int)Lf;
+}
+static size_t fused_cold_bytes(const KParams &kp) { return (size_t)kp.B * ((kp.T + fused_segment_frames(kp) - 1) / fused_segment_frames(kp)) * FZ_COLD_CAP * sizeof(fz_cold_rec); }
+static int launch_fused(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, const unsigned *valid, void *cold, hipStream_t s)
+{
+    const size_t lds = fused_lds_bytes(kp.nd, kp.F, kp.sc_mean != nullptr);
+    static bool attr_set[64][2] = {};
+    const bool mic = kp.format == SALSA_FORMAT_MIC;
+    if (pl->device >= 0 && pl->device < 64 && !attr_set[pl->device][mic]) {
+        if (mic) HIP_TRY(hipFuncSetAttribute((const void *)fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        else HIP_TRY(hipFuncSetAttribute((const void *)fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[pl->device][mic] = true;
+    }
+    const int L = fused_segment_frames(kp);
+    dim3 grid((unsigned)((kp.T + L - 1) / L), (unsigned)kp.B);
+    if (mic) hipLaunchKernelGGL(fused_kernel<true>, grid, dim3(FZ_NT), lds, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, valid, L, (fz_cold_rec *)cold, pl->fused == 2 ? 0 : FZ_COLD_CAP);
+    else hipLaunchKernelGGL(fused_kernel<false>, grid, dim3(FZ_NT), lds, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, valid, L, (fz_cold_rec *)cold, pl->fused == 2 ? 0 : FZ_COLD_CAP);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
 
 template <int NPAIRS>
 static int launch_stft_multi(salsa_plan *pl, const KParams &kp, const float *d_audio, float *d_out, float4 *Xs, hipStream_t s)
@@ -1759,6 +2216,14 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         }
         if (pl->stop_after == 2) return SALSA_PARTIAL;
         if (two && s1 != s2) HIP_TRY(hipStreamWaitEvent(s2, after_second, 0));
+        // stage (a): the fused kernel on the masks of the launches above; its float64 records go where the spill was (dead
+        // once the tracker has read it: same stream)
+        if (pl->fused >= 1 && !two && fused_eligible(pl, gp) && fused_cold_bytes(gp) <= (size_t)gp.B * T * 4 * gp.nd * sizeof(float2)) {
+            m = mark_begin(pl, s2, "fused_stft_cov_eig");
+            for (int r = 0; r < reps && !rc; r++) rc = launch_fused(pl, gp, a, o, vm, (void *)xs, s2);
+            mark_end(pl, s2, m);
+            return rc;
+        }
         m = mark_begin(pl, s2, "cov_eig");
         const unsigned ntile = (unsigned)((gp.T + K3_FT - 1) / K3_FT);
         dim3 grid(ntile, (unsigned)gp.B, (unsigned)((gp.nd + K3_NT - 1) / K3_NT));
@@ -1980,6 +2445,13 @@ int salsa_eigvec_feature_batch(salsa_plan *pl, const float *d_X, int batch, int 
     dim3 grid(ntile, (unsigned)kp.B, (unsigned)((n_bins + K3_NT - 1) / K3_NT));
     launch_cov_eig<true>(kp, grid, s, Xs, valid, d_feat, (double *)nullptr, (unsigned char *)nullptr);
     HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_plan_set_fused(salsa_plan *pl, int mode)
+{
+    if (!pl || mode < 0 || mode > 2) return fail(SALSA_EINVAL, "salsa_plan_set_fused: bad argument%s");
+    pl->fused = mode;
     return SALSA_OK;
 }
 

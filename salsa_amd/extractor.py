@@ -221,8 +221,18 @@ class SalsaExtractor:
             _raise(rc)
         return feat[:, 4:]
 
+    def set_fused(self, mode: int):
+        """Schedule of extract() (include/salsa_hip.h salsa_plan_set_fused): 0 three kernels, 1 the fused STFT + covariance / eigen
+        kernel behind the tracker."""
+        rc = self.L.salsa_plan_set_fused(self._plan, int(mode))
+        if rc:
+            _raise(rc)
+        self._fused = int(mode)
+
     def set_stats(self, on: bool = True):
         """Attach (or detach) the solver counters (salsa_plan_set_stats); read_stats() returns and clears them."""
+        if not on:
+            torch.cuda.synchronize(self.device)          # launches in flight still add to the old counters
         self._stats = torch.zeros(4, dtype=torch.int64, device=self.device) if on else None
         rc = self.L.salsa_plan_set_stats(self._plan, C.c_void_p(self._stats.data_ptr()) if on else None)
         if rc:

@@ -87,6 +87,16 @@ def test_config2_packed_solver_equals_float64_instantiation(dev):
     print('config 4 chunks, MIC 32 x 8 s: %(gated_frames)d gated frames, %(cold_frames)d to the float64 cold list, %(emitted)d emitted' % st)
 
 
+def test_config2_fused_schedule_is_bit_identical(dev):
+    """config 2 at full size through the fused STFT + covariance / eigen kernel (1024 segments of 152 frames): bit-identical."""
+    from bench import make_batch
+    a = torch.from_numpy(make_batch(2021, 32, 60 * 24000)).to(dev)
+    ex = _extractor()
+    ref = ex.extract(a).clone()
+    ex.set_fused(1)
+    assert torch.equal(ex.extract(a), ref)
+
+
 def test_full_size_lite_and_mic_clips_against_oracle(dev, oracle):
     """One 60-s clip through SALSA-Lite (config 1's shape) and one through full SALSA MIC (fmax_doa 4 kHz, config 4's
     extractor) against the oracle -- the goldens hold 3-s clips only."""

@@ -185,6 +185,42 @@ def test_production_solver_adversarial_golden(dev, oracle):
     print('g2 through the packed solve: (gated frames, float64 cold-list frames, margin-admitted) per case: %s' % report)
 
 
+def test_fused_schedule_is_bit_identical(dev):
+    """Round 5, stage (a) of the spill removal: STFT -> tracker -> ONE fused kernel (STFT of a segment of frames into an LDS ring,
+    packed solve from the ring, float64 records solved at the end of the segment) does the three-kernel path's arithmetic in
+    the same order, so its features are bit-identical -- FOA / MIC, ragged lengths, interleaved audio, a fused scaler, and with
+    the record slice switched off (mode 2: the in-step fallback)."""
+    cases = [('foa 3 x 2 s', np.stack([synth_clip(7 + i, 48000) for i in range(3)]), {}),
+             ('foa ragged', np.stack([synth_clip(17 + i, 14700) for i in range(2)]), {}),
+             ('mic 4 x 8 s', np.stack([synth_clip(60 + i, 8 * 24000) for i in range(4)]), dict(audio_format='mic', fmax_doa=4000)),
+             ('interleaved', np.ascontiguousarray(np.stack([synth_clip(27 + i, 72000) for i in range(2)]).transpose(0, 2, 1)),
+              dict(audio_layout='interleaved')),
+             ('one 20-s clip', synth_clip(33, 20 * 24000)[None], {})]
+    for name, ys, kw in cases:
+        a = torch.from_numpy(ys).to(dev)
+        ex = _extractor(**kw)
+        ref = ex.extract(a).clone()
+        assert bool((ref[:, 4:] != 0).any()), name
+        for mode in (1, 2):
+            ex.set_fused(mode)
+            ex.set_stats(True)
+            out = ex.extract(a).clone()
+            st = ex.read_stats()
+            ex.set_stats(False)
+            assert torch.equal(out, ref), '%s, mode %d: %d elements differ' % (name, mode, int((out != ref).sum()))
+            assert st['tiles'] > 0 and st['gated_frames'] > 0, (name, st)      # (the fused kernel ran: its counters moved)
+        ex.set_fused(0)
+    # with the scaler fused into the stores (config 4's extractor)
+    ys = np.stack([synth_clip(90 + i, 8 * 24000) for i in range(3)])
+    a = torch.from_numpy(ys).to(dev)
+    ex = _extractor(audio_format='mic', fmax_doa=4000)
+    rng = np.random.default_rng(5)
+    ex.set_scaler(rng.normal(-60, 5, (4, 200)).astype(np.float32), rng.uniform(5, 15, (4, 200)).astype(np.float32))
+    ref = ex.extract(a).clone()
+    ex.set_fused(1)
+    assert torch.equal(ex.extract(a), ref)
+
+
 # ----------------------------------------------------------------------------------------------- end-to-end goldens
 def _golden_items(meta, a):
     clips = {k: golden_clip(*v) for k, v in meta['clips'].items()}
