@@ -950,8 +950,11 @@ constexpr int STH = 8, SHALO_H = STH + 2; // stem tile: 8 rows x TW pixels, wave
 // STATS (training): the launch is persistent (a workgroup walks tiles blockIdx.x, + gridDim.x, ...) and also leaves the
 // per-channel sum / sum of squares of its bf16-rounded outputs as one float64 row [2][64] per workgroup for the BatchNorm that
 // follows, accumulated like the 64 -> 64 kernel's (conv64_stats: DPP quad sums, lane q of a quad keeps channel group q).
+#ifndef STEM_FWD_WPS
+#define STEM_FWD_WPS 2 // round 5: with (256, 1) the compiler parked the accumulators in 64 AGPRs next to 160 - 208 VGPRs: one (training) / two (inference) waves per SIMD; held to 256 / 2 registers they stay in VGPRs: two / three waves, 277 -> 210 us (training, with the statistics epilogue), 0.361 -> 0.313 ms (inference sub-batch)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__restrict__ x, const unsigned short *__restrict__ wq,
+__global__ __launch_bounds__(256, STEM_FWD_WPS) void conv3x3_stem_fwd_kernel(const float *__restrict__ x, const unsigned short *__restrict__ wq,
                                                                unsigned short *__restrict__ y, int N, int Cin, int H, int W, long x_batch_stride,
                                                                long x_channel_stride, const float *__restrict__ shift, int relu,
                                                                double *__restrict__ stats_part)
@@ -1128,12 +1131,15 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_kernel(const float *__re
 #ifndef STEM_FWD_GRID
 #define STEM_FWD_GRID 1536
 #endif
+#ifndef STEM_STATS_GRID
+#define STEM_STATS_GRID 1024
+#endif
 /* number of partial rows salsa_nn_conv3x3_stem_stats writes (= its persistent workgroup count) */
 extern "C" int salsa_nn_conv3x3_stem_stats_blocks(int64_t N, int H, int W)
 {
     if (N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return 0;
     const long tiles = (long)N * ((H + STH - 1) / STH) * ((W + TW - 1) / TW);
-    return (int)(tiles >= 1024 ? 1024 : tiles);
+    return (int)(tiles >= STEM_STATS_GRID ? STEM_STATS_GRID : tiles);
 }
 
 // training: the plain first-layer convolution from a persistent launch that also leaves its output's per-channel partial sums
@@ -1502,7 +1508,10 @@ __device__ __forceinline__ void stem_wrw_steps(f32x16 &acc, const unsigned ga, c
 // as the separate pass would have stored it.  This layer's weight gradient is dx's ONLY reader (the network input needs no
 // gradient), so the 524-MB dx is never written or read: 4 tensor passes become 2.
 template <bool BN>
-__global__ __launch_bounds__(256) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
+#ifndef STEM_WRW_WPS
+#define STEM_WRW_WPS 1
+#endif
+__global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
                                                                const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                int N, int Cin, int H, int W,
                                                                const unsigned short *__restrict__ x1, const float *__restrict__ coef,

@@ -687,6 +687,9 @@ constexpr int K3_OW = K3_NT + 8; // columns of the LDS output tile: a block's bi
 #ifndef SALSA_PK
 #define SALSA_PK 1
 #endif
+#ifndef K3_STAGE_LDS
+#define K3_STAGE_LDS 0
+#endif
 #ifndef K3_PK_WAVES
 #define K3_PK_WAVES 4 // waves per SIMD the register allocation is held to (4: 128 VGPRs, 3: 168)
 #endif
@@ -710,6 +713,11 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
     // 16-byte stores at the end, instead of one 4-byte store per lane per (channel, frame) for the zeros plus three scattered
     // 4-byte stores per result
     __shared__ __attribute__((aligned(16))) float otile[FEAT ? 3 * K3_FT * K3_OW : 4];
+#if K3_STAGE_LDS
+    // Round-5 experiment (review item 6): the tile's 14 frames x 2 pairs x K3_NT bins copied into LDS with coalesced 16-byte loads
+    // once per workgroup, the work items' sixteen gathers answered from there.  Measured slower (profiles/r5_ab_notes.txt): off.
+    __shared__ __attribute__((aligned(16))) float4 stage[PK ? (K3_FT + 6) * 2 * K3_NT : 1];
+#endif
     const int tid = threadIdx.x;
     const int Tn = kp.T;
     int tile = blockIdx.x, b = blockIdx.y;
@@ -862,6 +870,15 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
         // SIMD -- or, held to 128 / 168, into scratch: 0.50 - 0.88 ms against 0.38, profiles/r4_k3_pk_ab.txt.)
         constexpr int NW = 2 * NHOP + 2;
         const unsigned half = 16u * (unsigned)kp.nd;
+#if K3_STAGE_LDS
+        if (n > 0) { // (a tile with nothing gated stages nothing)
+            for (int i = tid; i < (K3_FT + 6) * 2 * K3_NT; i += K3_NT) {
+                const int fr = i / (2 * K3_NT), rem = i - fr * 2 * K3_NT, pr = rem / K3_NT, bl = rem - pr * K3_NT;
+                if (bl < nbc) stage[i] = ld_off(xclip, rowoff[fr] + 16u * (unsigned)(bin0 + bl) + (pr ? half : 0u));
+            }
+        }
+        __syncthreads();
+#endif
         for (int s = tid; s < n; s += K3_NT) {
             const int i = list[s];
             const int ft = 2 * ((i >> 8) & 15), bl = i & 255; // entry = validity of the pair's frames << 12 | pair << 8 | bin
@@ -871,9 +888,15 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
                 const unsigned boff = 16u * (unsigned)(bin0 + bl);
 #pragma unroll
                 for (int k = 0; k < NW; k++) {
+#if K3_STAGE_LDS
+                    xa[k] = stage[((ft + k) * 2 + 0) * K3_NT + bl];
+                    xc[k] = stage[((ft + k) * 2 + 1) * K3_NT + bl];
+                    (void)ro; (void)boff;
+#else
                     const unsigned r = ro[k];
                     xa[k] = ld_off(xclip, r + boff);
                     xc[k] = ld_off(xclip, r + boff + half);
+#endif
                 }
             }
             auto chans = [&](int k, salsa::pk2f *v) {
