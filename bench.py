@@ -196,6 +196,8 @@ def main():
     ap.add_argument('--streams', type=int, default=1, help='extra leg: K steps round-robin over this many HIP streams / plans (reported as pipelined, never `value`)')
     ap.add_argument('--pcie', action='store_true', help='also time host->device->extract->device->host (reported, never `value`)')
     ap.add_argument('--groups', type=int, default=0, help='clip-group pipelining depth (0 = library default)')
+    ap.add_argument('--fused', type=int, default=0, help='measurement: salsa_plan_set_fused mode (1 = STFT -> tracker -> fused STFT + '
+                                                         'covariance / eigen kernel; bit-identical, measured slower: DESIGN section 6)')
     args = ap.parse_args()
 
     from bench_crnn import infer_bench, self_spawn, train_bench
@@ -231,6 +233,8 @@ def main():
         rccl_ranks = dist.get_world_size()          # read back from the process group, not from the command line
 
     ex = SalsaExtractor(audio_format=fmt, feature_type=args.feature, fmax_doa=fmax, device=dev)
+    if args.fused:
+        ex.set_fused(args.fused)
     if args.groups:
         ex.set_groups(args.groups)
     audio = torch.from_numpy(host).to(dev)
@@ -466,7 +470,11 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f64',
+            # what the path computes in (round-4 review): the STFT, the tracker and the cold list of the eigen-solve in float64; the
+            # covariance + eigen-solve of the other ~99.7 % of the gated frames as a packed-float32 pair solve whose every kept
+            # decision is certified against float64; SALSA-Lite: float64 STFT, float32 phases
+            'dtype': ('f64 (STFT, noise-floor tracker, eigen-solve cold list) + packed f32 (covariance and eigen-solve of the certified frames)'
+                      if args.feature == 'salsa' else 'f64 (STFT) + f32 (log-spectrogram, phase differences)'),
             'data': 'synthetic',
             'config': {'workload': 'Full SALSA %s (eigenvector path): batch %dx%.0f-s 4-ch 24 kHz clips per GPU, '
                                    'feature-extract only, n_fft 512 hop 300 fmax_doa %d cond 5 tracking on'

@@ -103,7 +103,7 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
         'metric': 'SALSA+CRNN inference clips/s', 'value': round(world * args.clips * args.steps / elapsed, 2),
         'unit': '60-s clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 (features)', 'data': 'synthetic (seeded synth_clip bursts + noise, the config-2 clips)',
+        'vs_baseline': None, 'dtype': 'bf16 (CRNN) / f64 + packed f32 (features: see the feature line)', 'data': 'synthetic (seeded synth_clip bursts + noise, the config-2 clips)',
         'p50_latency_ms_per_clip': round(p50, 2),
         'p90_latency_ms_per_clip': round(1e3 * lat[min(len(lat) - 1, (9 * len(lat)) // 10)], 2),
         'latency_samples': len(lat),
