@@ -456,6 +456,10 @@ constexpr int TR_BINS = 32;
 #ifndef TR_MASK_HISTORY
 #define TR_MASK_HISTORY 1 // the countdown as three scalar `above` masks (round 3); 0: the per-lane countdown of round 2
 #endif
+#ifndef TR_CHUNK_CLAMP_SKIP
+#define TR_CHUNK_CLAMP_SKIP 0 // round 5: chunks whose floors cannot reach the 1e-6 clamp run the step without it (see the consumer).
+                              // Masks bit-identical (20 GPU parity tests), tracker 0.175 - 0.183 (off) vs 0.180 - 0.188 ms (on): no gain, off
+#endif
 #ifndef TR_LAZY_CLAMP
 #define TR_LAZY_CLAMP 0 // measured: 0.35 ms with the lazy clamp against 0.22 ms without -- the chain is not what bounds the step
 #endif
@@ -525,19 +529,24 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
     // vector instruction of this mix: VOP3 compares writing SGPR pairs, selects reading them), not the dependent chain -- a
     // hand-pipelined order that puts the indicator of step t-1 into the stall slots of step t's chain ran no faster (0.179).
     unsigned long long h1 = 0ull, h2 = 0ull, h3 = 0ull; // `above` masks of the previous three steps (wave-uniform)
-    auto step = [&](const double m) -> unsigned long long {
+    // CLAMPED = false (round 5): the 1e-6 clamp (:85) left out.  The floor falls by at most 0.98 per step, so a chunk that STARTS
+    // with every lane's floor >= 1e-6 / 0.98^64 (3.65e-6; 4e-6 is tested) cannot bring any floor below 1e-6 within its 64 steps:
+    // max(x, 1e-6) == x bit for bit there, and the chunk runs 9 instead of 10 vector instructions per step with the float64 max
+    // off the dependent chain.  Near-silent bins (a floor at the clamp) take the clamped step; the test is one ballot per chunk.
+    auto step = [&](const double m, auto clamped) -> unsigned long long {
         const bool slow = __builtin_amdgcn_inverse_ballot_w64(h1 & h2 & h3);
         const double up = slow ? 1.0 + 0.1 * 0.02 : 1.0 + 0.02;
         const bool above = m > fl;
         const double f = above ? up : 1.0 - 0.02;
-        fl = fmax(f * fl, 1e-6); // (a product of finite numbers is canonical: one v_max_f64)
+        if (decltype(clamped)::value) fl = fmax(f * fl, 1e-6); // (a product of finite numbers is canonical: one v_max_f64)
+        else fl = f * fl;
         h3 = h2;
         h2 = h1;
         h1 = __ballot(above);
         return __ballot(m > snr * fl); // :87
     };
 #else
-    auto step = [&](const double m) -> unsigned long long { return __ballot(salsa::tracker_step(fl, cd, m, snr)); }; // :65-87
+    auto step = [&](const double m, auto) -> unsigned long long { return __ballot(salsa::tracker_step(fl, cd, m, snr)); }; // :65-87
 #endif
     auto consume = [&](const int c) {
         const double *cur = ring[c & 1] + col;
@@ -551,6 +560,11 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
         unsigned word = 0, word_hi = 0; // lane i: indicator_sig mask (bit j = bin 32 g + j) of frame 64 c + i (TR_WIDE: + bins 32-63)
         const int nfr = Tn - c * TR_CH < TR_CH ? Tn - c * TR_CH : TR_CH; // wave-uniform
         if (nfr == TR_CH) { // every chunk but the last: straight-line code, no per-frame conditionals
+#if TR_MASK_HISTORY
+            const bool noclamp = __ballot(!(fl >= 4e-6)) == 0ull; // wave-uniform: no lane's floor can reach the clamp in this chunk
+#else
+            const bool noclamp = false;
+#endif
 #pragma unroll
             for (int i0 = 0; i0 < TR_CH; i0 += 16) {
                 double m[16]; // one LDS round trip per 16 frames, not per frame
@@ -582,17 +596,26 @@ __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp
                     }
                 }
 #else
+                if (TR_CHUNK_CLAMP_SKIP && noclamp) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const unsigned long long bal = step(m[i]);
-                    word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
-                    if (TR_WIDE) word_hi = (unsigned)salsa_writelane_i32((int)(unsigned)(bal >> 32), i0 + i, (int)word_hi);
+                    for (int i = 0; i < 16; i++) {
+                        const unsigned long long bal = step(m[i], std::false_type{});
+                        word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
+                        if (TR_WIDE) word_hi = (unsigned)salsa_writelane_i32((int)(unsigned)(bal >> 32), i0 + i, (int)word_hi);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const unsigned long long bal = step(m[i], std::true_type{});
+                        word = (unsigned)salsa_writelane_i32((int)(unsigned)bal, i0 + i, (int)word);
+                        if (TR_WIDE) word_hi = (unsigned)salsa_writelane_i32((int)(unsigned)(bal >> 32), i0 + i, (int)word_hi);
+                    }
                 }
 #endif
             }
         } else {
             for (int i = 0; i < nfr; i++) {
-                const unsigned long long bal = step(cur[i * BINS]);
+                const unsigned long long bal = step(cur[i * BINS], std::true_type{});
                 word = lane == i ? (unsigned)bal : word; // (ragged last chunk only)
                 if (TR_WIDE) word_hi = lane == i ? (unsigned)(bal >> 32) : word_hi;
             }
