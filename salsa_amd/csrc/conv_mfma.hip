@@ -193,14 +193,50 @@ __device__ __forceinline__ float dpp_xor2(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
 }
+#ifndef CONV_STATS_DOT2
+#define CONV_STATS_DOT2 0 // round 5 experiment: the two rows of a channel as ONE bf16 pair, sum and sum of squares by v_dot2_f32_bf16: 144 instead of 240 vector
+                          // instructions per tile-wave and NO faster (with statistics 0.442 / 0.446 -> 0.459 / 0.460 ms at 32 x 640 x 200; 36 B of scratch); off
+#endif
 __device__ __forceinline__ void conv64_stats(const f32x16 (&acc)[RPW], float (&rs)[4], float (&rq)[4], int th, int tw, int H, int W,
                                              int px, int rg)
 {
     const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
+    const int quad = px & 3;
+#if CONV_STATS_DOT2 && CONV_RPW == 2
+    // Round 5.  The epilogue cost what a separate statistics pass would (tools/probes/conv64_stats_probe.py: +60 - 80 us on the 311-us
+    // kernel at 32 x 640 x 200): 9 vector instructions per bf16 PAIR of neighbouring channels (pack, two unpacks, two masks, two
+    // adds, two FMAs) + the quad sums.  A lane's two output ROWS of one channel make a pair as well: packed once (the same
+    // round-to-nearest-even as the store's), `v_dot2_f32_bf16 pair, (1, 1)` is the channel's sum over both rows and
+    // `v_dot2_f32_bf16 pair, pair` its sum of squares -- 3 instructions per channel where there were 9, and the row mask of an edge tile
+    // is one AND on the pair (skipped, wave-uniformly, on interior tiles).
+    const bool row1 = h0 + 1 < H;                                    // wave-uniform
+    const unsigned keep_rows = !(h0 < H) ? 0u : row1 ? 0xffffffffu : 0x0000ffffu;
+    const unsigned lane_mask = wcol < W ? keep_rows : 0u;            // per lane: the pixel column may lie outside the map
+    const bool edge = !row1 || tw * TW + TW > W;                     // wave-uniform: some lane or row of this wave's tile part is outside
+    const unsigned ones = 0x3f803f80u;                               // bf16 (1, 1)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        float t[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned pr = pack_bf16(acc[0][4 * g + j], acc[1][4 * g + j]);
+            if (edge) pr &= lane_mask;
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(t[j]) : "v"(pr), "v"(ones));
+            asm("v_dot2_f32_bf16 %0, %1, %1, 0" : "=v"(q[j]) : "v"(pr));
+        }
+        const float keep = quad == g ? 1.f : 0.f; // lane `quad` of each quad keeps channel group g = quad
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[j] += dpp_xor1(t[j]); q[j] += dpp_xor1(q[j]);
+            t[j] += dpp_xor2(t[j]); q[j] += dpp_xor2(q[j]);
+            rs[j] = fmaf(keep, t[j], rs[j]);
+            rq[j] = fmaf(keep, q[j], rq[j]);
+        }
+    }
+#else
     float m[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; rr++) m[rr] = (h0 + rr < H && wcol < W) ? 1.f : 0.f;
-    const int quad = px & 3;
 #pragma unroll
     for (int g = 0; g < 4; g++) { // accumulator elements 4 g .. 4 g + 3 = channels 8 g + j (+ the lane's base); 8 temporaries live
         float t[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -223,6 +259,7 @@ __device__ __forceinline__ void conv64_stats(const f32x16 (&acc)[RPW], float (&r
             rq[j] = fmaf(keep, q[j], rq[j]);
         }
     }
+#endif
 }
 
 // The WHOLE filter lives in registers (72 A fragments per lane: a wave per SIMD may use all 512 VGPR+AGPR), so LDS only
