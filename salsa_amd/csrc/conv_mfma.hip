@@ -476,6 +476,9 @@ constexpr int AFETCH = (HALO_PIECES + 255) / 256;    // load instructions per th
 // loop over a permuted step number the filter array was indexed "dynamically" and the compiler moved it to scratch memory).
 // Step S multiplies fragment FRAG(S) = (input row ir, tap column sx, channel block kc) while the next AD fragments are in
 // flight; rb[] are the lane's eight rotated base addresses (see the kernel).
+#ifndef CONV_FETCH_NO_HOIST
+#define CONV_FETCH_NO_HOIST 1
+#endif
 #ifndef CONV_ORDER
 #define CONV_ORDER 1 // 1: fragments ordered so that consecutive MFMAs never share an accumulator (0: row by row, round 1)
 #endif
@@ -623,6 +626,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         const unsigned short *origin = x + geo_off(geo, c.n, c.th * TH, c.tw * TW); // pixel (0, 0) of the tile
         const int h_lo = -c.th * TH, h_hi = H - c.th * TH, w_lo = -c.tw * TW, w_hi = W - c.tw * TW; // valid (row, col) - origin
         int hh = hh0 - 1, ww = ww0 - 1; // halo pixel relative to the tile origin
+#if CONV_FETCH_NO_HOIST
+        // Round 5.  hh0 / ww0 never change, so the compiler hoisted the seven pieces' sign-extended element offsets out of the tile
+        // loop as seven 64-bit register pairs -- and in the instantiations that need a few registers more (the statistics epilogue:
+        // 8 running sums) it SPILLED three of them: every tile then reloaded them from scratch with `s_waitcnt vmcnt(0)` in front of
+        // the LDS-direct load that uses them, i.e. three times per tile a wave sat out everything it had in flight, the next two
+        // tiles' loads included (+70 us on the 311-us kernel at 32 x 640 x 200; found in the ISA, the counters only showed
+        // "waiting").  Laundering the two start values makes the offsets loop-variant: ~5 integer instructions per piece per tile,
+        // recomputed, and nothing to spill.
+        // (Only where it spilled: the plain forward / data-gradient instantiation fits with the offsets hoisted and is 2 - 7 % faster so.)
+        if (STATS || POOL || XF) asm volatile("" : "+v"(hh), "+v"(ww));
+#endif
 #pragma unroll
         for (int j = 0; j < AFETCH; j++) {
             const bool inside = hh >= h_lo && hh < h_hi && ww >= w_lo && ww < w_hi;
@@ -1571,32 +1585,43 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
     const long n_tiles = (long)N * tiles_h * tiles_w;
     constexpr int GP = WT_H * WT_W * 8 / 256;
     const int n_x = Cin * WHALO_H * WHALO_W;
-    float px_[SW_XPF];
-    uint4 pg_[GP], pq_[BN ? GP : 1];
-    auto fetch = [&](long tile) {
+    // Round 5: TWO register sets of tile loads in flight (the tile after next is fetched while this one is converted and
+    // multiplied) and raw barriers.  Before: one set, fetched after the second __syncthreads() of a tile and needed right after the
+    // first one of the next -- a fence + barrier = s_waitcnt vmcnt(0), so every tile exposed a whole memory latency minus eight
+    // MFMAs, at two resident workgroups per CU (185 registers).  The second set costs 38 registers the kernel had spare at that
+    // occupancy.  Every load is unconditional (a clamped in-bounds address; validity bits applied at conversion), so that nothing
+    // but loads sits between the loads of a set.
+    struct TileRegs {
+        float px[SW_XPF];
+        uint4 pg[GP], pq[BN ? GP : 1];
+        unsigned okx, okg; // validity bits of the halo elements / the tile pieces
+        int th, tw;
+    };
+    auto fetch = [&](long tile, TileRegs &r) {
         const int tw = (int)(tile % tiles_w);
         const int th = (int)((tile / tiles_w) % tiles_h);
         const long n = tile / ((long)tiles_w * tiles_h);
         const int h0 = th * WT_H, w0 = tw * WT_W;
+        r.th = th; r.tw = tw; r.okx = 0u; r.okg = 0u;
 #pragma unroll
         for (int j = 0; j < SW_XPF; j++) {
-            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), r = i - cc * (WHALO_H * WHALO_W);
-            const int hh = r / WHALO_W, ww = r - hh * WHALO_W;
+            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), rr = i - cc * (WHALO_H * WHALO_W);
+            const int hh = rr / WHALO_W, ww = rr - hh * WHALO_W;
             const int h = h0 + hh - 1, wc = w0 + ww - 1;
-            px_[j] = 0.f;
-            if (i < n_x && h >= 0 && h < H && wc >= 0 && wc < W) px_[j] = x[n * xbs + cc * xcs + (long)h * W + wc];
+            const bool ok = i < n_x && h >= 0 && h < H && wc >= 0 && wc < W;
+            r.okx |= ok ? 1u << j : 0u;
+            r.px[j] = x[n * xbs + (ok ? cc * xcs + (long)h * W + wc : 0)];
         }
 #pragma unroll
         for (int j = 0; j < GP; j++) {
             const int i = tid + j * 256, piece = i & 7, p = i >> 3;
             const int hh = p / WT_W, ww = p - hh * WT_W;
             const int h = h0 + hh, wc = w0 + ww;
-            pg_[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (BN) pq_[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (h < H && wc < W) {
-                pg_[j] = *(const uint4 *)(dy + (((n * H + h) * W + wc) * CH + piece * 8));
-                if (BN) pq_[j] = *(const uint4 *)(x1 + (((n * H + h) * W + wc) * CH + piece * 8));
-            }
+            const bool ok = h < H && wc < W;
+            r.okg |= ok ? 1u << j : 0u;
+            const long off = ((n * H + (ok ? h : 0)) * W + (ok ? wc : 0)) * CH + piece * 8;
+            r.pg[j] = *(const uint4 *)(dy + off);
+            if (BN) r.pq[j] = *(const uint4 *)(x1 + off);
         }
     };
     // one bf16 pair of the tile: BatchNorm-backward apply on (g, x1) -> dx, rounded to bf16 (a pixel outside the image has
@@ -1624,16 +1649,19 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
         }
         return pack_bf16(r[0], r[1]);
     };
-    long tile = blockIdx.x;
-    if (tile < n_tiles) fetch(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads(); // the previous tile's LDS reads (and, the first time, the zero fill and the coefficient table) are done
+    auto raw_barrier = [&]() { // LDS order only: the loads in flight stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // registers -> LDS: the halo as three column-shifted bf16 copies per (ci, row); the (g [, x1]) tile as dx rows
+    auto convert = [&](const TileRegs &r) {
 #pragma unroll
         for (int j = 0; j < SW_XPF; j++) {
-            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), r = i - cc * (WHALO_H * WHALO_W);
-            const int hh = r / WHALO_W, ww = r - hh * WHALO_W;
+            const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), rr = i - cc * (WHALO_H * WHALO_W);
+            const int hh = rr / WHALO_W, ww = rr - hh * WHALO_W;
             if (i < n_x) {
-                const unsigned short bits = (unsigned short)(pack_bf16(px_[j], 0.f) & 0xffffu); // round to nearest even
+                const unsigned short bits = (unsigned short)(pack_bf16(((r.okx >> j) & 1u) ? r.px[j] : 0.f, 0.f) & 0xffffu); // round to nearest even
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) { // copy kx holds halo columns kx .. kx + 31 at positions 0 .. 31
                     const int col = ww - kx;
@@ -1644,19 +1672,44 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
 #pragma unroll
         for (int j = 0; j < GP; j++) {
             const int i = tid + j * 256;
-            uint4 v = pg_[j];
+            const bool inside = (r.okg >> j) & 1u;
+            uint4 v = r.pg[j];
             if (BN) {
-                const int tw = (int)(tile % tiles_w), th = (int)((tile / tiles_w) % tiles_h), p = i >> 3;
-                const bool inside = th * WT_H + p / WT_W < H && tw * WT_W + p % WT_W < W;
-                v.x = inside ? bn_pair(pg_[j].x, pq_[j].x, 0) : 0u;
-                v.y = inside ? bn_pair(pg_[j].y, pq_[j].y, 2) : 0u;
-                v.z = inside ? bn_pair(pg_[j].z, pq_[j].z, 4) : 0u;
-                v.w = inside ? bn_pair(pg_[j].w, pq_[j].w, 6) : 0u;
+                v.x = bn_pair(r.pg[j].x, r.pq[j].x, 0);
+                v.y = bn_pair(r.pg[j].y, r.pq[j].y, 2);
+                v.z = bn_pair(r.pg[j].z, r.pq[j].z, 4);
+                v.w = bn_pair(r.pg[j].w, r.pq[j].w, 6);
             }
+            if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
             *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = v;
         }
-        __syncthreads();
-        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x); // in flight during the multiply below
+    };
+    TileRegs ra, rb;
+    long tile = blockIdx.x; // (< n_tiles: the launch has at most one workgroup per tile)
+    const long G = gridDim.x, t_last = n_tiles - 1;
+    // Every fetch is issued unconditionally (past the end: the last tile again, never converted): with a fetch or a tile behind a
+    // branch the compiler's wait insertion merges the paths and drains BOTH sets (vmcnt 13 .. 0) where the older set alone
+    // is needed (vmcnt 27 .. 14)
+    auto clampt = [&](long t) { return t < t_last ? t : t_last; };
+    fetch(tile, ra);
+    fetch(clampt(tile + G), rb);
+    __syncthreads(); // the zero fill of xs (and nothing else: the loads above land in registers)
+    for (; tile + G < n_tiles; tile += 2 * G) {
+        raw_barrier(); // the previous tile's LDS reads are done
+        convert(ra);
+        raw_barrier();
+        fetch(clampt(tile + 2 * G), ra); // in flight during this tile's multiply and the whole next tile
+        stem_wrw_steps<0>(acc, ga, xa);
+        raw_barrier();
+        convert(rb);
+        raw_barrier();
+        fetch(clampt(tile + 3 * G), rb);
+        stem_wrw_steps<0>(acc, ga, xa);
+    }
+    if (tile < n_tiles) {
+        raw_barrier();
+        convert(ra);
+        raw_barrier();
         stem_wrw_steps<0>(acc, ga, xa);
     }
     // D[m = co][n = column]: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -1691,6 +1744,9 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
 
+#ifndef STEM_WRW_BN_GRID
+#define STEM_WRW_BN_GRID 512
+#endif
 // The same with the BatchNorm (+ ReLU) that follows the first layer differentiated on the fly: g = gradient of the BatchNorm's
 // OUTPUT, x1 = its input (the first layer's output), both bf16 channels-last; coef = the [7][64] table salsa_nn_bn_bwd leaves in
 // coef_ws (call it with dx = NULL: it then skips its apply pass, whose only reader would have been this kernel).
@@ -1702,7 +1758,9 @@ extern "C" int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stri
         x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
-    const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles);
+    // persistent; this instantiation holds 246 registers (two sets of tile loads in flight): TWO workgroups per CU are resident, so
+    // the grid is a whole number of rounds of 512 (1280 left the last half round on half the CUs)
+    const unsigned nb = (unsigned)(tiles >= STEM_WRW_BN_GRID ? STEM_WRW_BN_GRID : tiles);
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * Cin * 9, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
