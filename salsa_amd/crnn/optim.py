@@ -47,6 +47,18 @@ class HipAdam(torch.optim.Optimizer):
         self._plans[gi] = (key, batches)
         return batches
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's state loads as it is; every `step` becomes this class's form: an OWN float32 host scalar per parameter
+        (torch's fused / capturable paths keep it on the device -- reading it would synchronise once per parameter per step -- and a
+        state saved by the round-4 HipAdam shares one tensor object among a group's parameters)."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = torch.tensor(float(st['step']), dtype=torch.float32)
+        for g in self.param_groups:
+            g.pop('step_tensor', None)
+        self._plans = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -1142,6 +1142,32 @@ def test_one_launch_adam_matches_torch_adam():
         again = torch.optim.Adam(our_p, lr=3e-4, weight_decay=wd)
         again.load_state_dict(our.state_dict())                                   # the same state layout and keys
         assert float(again.state[our_p[0]]['step']) == 6.0
+        # round-4 advice: every parameter owns its step scalar (a shared tensor object, loaded into torch's single-tensor / foreach
+        # paths, advanced once per PARAMETER); torch's state loads back with the steps as own host scalars
+        steps = [our.state[b]['step'] for b in our_p]
+        assert len({id(t) for t in steps}) == len(steps) and 'step_tensor' not in our.param_groups[0]
+        assert len({id(again.state[b]['step']) for b in our_p}) == len(our_p)
+        fused = torch.optim.Adam(ref_p, lr=3e-4, weight_decay=wd, fused=True)     # keeps `step` on the device
+        import copy
+        fused.load_state_dict(copy.deepcopy(ref.state_dict()))    # (deep copies: load_state_dict keeps same-device tensors as they are)
+        back = HipAdam(our_p, lr=3e-4, weight_decay=wd)
+        back.load_state_dict(copy.deepcopy(fused.state_dict()))
+        assert all(not back.state[b]['step'].is_cuda and float(back.state[b]['step']) == 6.0 for b in our_p)
+        assert len({id(back.state[b]['step']) for b in our_p}) == len(our_p)
+        # a parameter whose first gradient comes late keeps ITS OWN count (one launch per distinct count)
+        late = torch.nn.Parameter(torch.randn(33, generator=g).to(dev))
+        late_ref = torch.nn.Parameter(late.detach().clone())
+        back.add_param_group({'params': [late]})
+        ref.add_param_group({'params': [late_ref]})
+        for a, b in zip(ref_p + [late_ref], our_p + [late]):
+            gr = torch.randn(a.shape, generator=g).to(dev)
+            if a.dim() == 4:
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step(); back.step()
+        assert float(back.state[late]['step']) == 1.0 and float(back.state[our_p[0]]['step']) == 7.0
+        torch.testing.assert_close(late.detach(), late_ref.detach(), rtol=2e-6, atol=1e-8)
+        torch.testing.assert_close(our_p[0].detach(), ref_p[0].detach(), rtol=2e-6, atol=1e-8)
 
 
 def test_relu_bit_planes_leave_every_gradient_bit_equal():

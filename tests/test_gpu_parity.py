@@ -418,6 +418,56 @@ def test_extract_features_harness_reproduces_reference_tree(dev, oracle, tmp_pat
     assert n_checked == len(a)
 
 
+@pytest.mark.timeout(120)
+def test_file_pipeline_raises_instead_of_hanging(dev, tmp_path):
+    """Round-4 advice: a failure in any stage of the extraction harness's file pipeline -- the device issue in the caller's thread,
+    the writer (e.g. a full disk), the reader -- must stop the other stages and come out of run() as the exception, on a tree long
+    enough that the reader is waiting for a free slot when it happens."""
+    from salsa_amd import features, io as sio
+    from salsa_amd.extractor import SalsaExtractor
+    adir, fdir = tmp_path / 'audio', tmp_path / 'feat'
+    adir.mkdir(); fdir.mkdir()
+    for i in range(12):
+        np.save(adir / ('clip%02d.npy' % i), synth_clip(300 + i, 24000))
+    todo = list(enumerate(sorted(os.listdir(adir))))
+
+    class Boom(RuntimeError):
+        pass
+
+    # (i) extract() raises in the caller's thread on the third batch
+    ex = SalsaExtractor(device=dev)
+    pipe = features._FilePipeline(ex)
+    calls = [0]
+    real = pipe.slots[0]['ex'].extract
+    def bad_extract(*a, **k):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise Boom('device issue failed')
+        return real(*a, **k)
+    for sl in pipe.slots:
+        sl['ex'].extract = bad_extract
+    with pytest.raises(Boom):
+        pipe.run(todo, str(adir), str(fdir), 24000, 2)
+    # (ii) the writer fails
+    pipe = features._FilePipeline(SalsaExtractor(device=dev))
+    real_save = sio.save_arrays
+    def bad_save(path, **kw):
+        if path.endswith('clip03.h5') or 'clip03' in os.path.basename(path):
+            raise Boom('no space left on device')
+        return real_save(path, **kw)
+    sio.save_arrays = bad_save
+    try:
+        with pytest.raises(Boom):
+            pipe.run(todo, str(adir), str(fdir), 24000, 2)
+    finally:
+        sio.save_arrays = real_save
+    # (iii) the reader fails (a missing file), and the pipeline object is still usable afterwards
+    with pytest.raises(Exception):
+        pipe.run(todo + [(99, 'missing.npy')], str(adir), str(fdir), 24000, 2)
+    pipe.run(todo, str(adir), str(fdir), 24000, 2)
+    assert len(os.listdir(fdir)) == 12
+
+
 def test_lite_harness_and_python_surface(dev, tmp_path):
     from salsa_amd import io as sio
     from salsa_amd import lite_features
