@@ -66,7 +66,8 @@ __device__ __forceinline__ long geo_off(const Geo &g, long n, int h, int w) { re
 template <bool POOL>
 __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsigned short *__restrict__ y, const float *__restrict__ shift,
                                                 const float4 (&shv)[4], const unsigned short *__restrict__ residual, int relu, long n,
-                                                int th, int tw, int H, int W, int lane, int px, int mb, int rg, const Geo &geo)
+                                                int th, int tw, int H, int W, int lane, int px, int mb, int rg, const Geo &geo,
+                                                const uint2 (*pre)[4] = nullptr /* RES: the tile's residual pieces, loaded at the tile's top */)
 {
     if (POOL) { // inference, RPW == 2: the 2x2 average pool that follows (stem, model_utils.py:224) taken on the float32 values
         // before the single rounding -- the wave's two rows are the vertical pair, the neighbouring lane the horizontal one;
@@ -75,7 +76,12 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         const bool inside = h0 < H && wcol < W;
         uint2 pk[4];
         uint2 rvp[RPW][4];
-        if (residual) { // (all eight pieces requested together: see the plain epilogue below)
+        if (residual && pre) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) rvp[rr][g] = pre[rr][g];
+        } else if (residual) { // (all eight pieces requested together: see the plain epilogue below)
 #pragma unroll
             for (int rr = 0; rr < RPW; rr++) {
                 const long roff = geo_off(geo, n, inside ? h0 + rr : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5);
@@ -127,7 +133,10 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
         // (round 4: the row's four residual pieces are requested together -- fetched inside the g loop the compiler waited
         // `vmcnt(0)` after each one: four dependent round trips per row, in inference and in the data gradients that add a skip branch)
         uint2 rvq[4] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-        if (shift && residual) {
+        if (shift && residual && pre) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) rvq[g] = pre[rr][g];
+        } else if (shift && residual) {
 #pragma unroll
             for (int g = 0; g < 4; g++) rvq[g] = *(const uint2 *)(residual + off + 8 * g);
         }
@@ -479,6 +488,9 @@ constexpr int AFETCH = (HALO_PIECES + 255) / 256;    // load instructions per th
 #ifndef CONV_FETCH_NO_HOIST
 #define CONV_FETCH_NO_HOIST 1
 #endif
+#ifndef CONV_RES_EARLY
+#define CONV_RES_EARLY 1
+#endif
 #ifndef CONV_ORDER
 #define CONV_ORDER 1 // 1: fragments ordered so that consecutive MFMAs never share an accumulator (0: row by row, round 1)
 #endif
@@ -559,7 +571,13 @@ struct XformArgs {
     DropArgs drop;
 };
 
-template <bool POOL, bool STATS = false, bool XF = false>
+// RES (round 5): the launch adds a residual (inference: the block's shortcut; training: the skip branch's gradient in a data
+// gradient).  Loaded inside the epilogue, the residual pieces were YOUNGER than the LDS-direct loads of the tile after next, so the
+// `s_waitcnt vmcnt(0)` in front of their first use drained that prefetch and exposed the residual's own latency twice per tile (once
+// per output row).  Here the tile's eight pieces are requested at the tile's TOP, before the prefetch is issued: they are older,
+// the counted wait that lets the prefetch stay in flight covers them, and they land during the multiply.  16 registers, which
+// the instantiation has once the load offsets are recomputed per tile (CONV_FETCH_NO_HOIST).
+template <bool POOL, bool STATS = false, bool XF = false, bool RES = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const unsigned short *__restrict__ x,
                                                                        const unsigned short *__restrict__ w,
                                                                        unsigned short *__restrict__ y, int N, int H, int W,
@@ -635,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
         // "waiting").  Laundering the two start values makes the offsets loop-variant: ~5 integer instructions per piece per tile,
         // recomputed, and nothing to spill.
         // (Only where it spilled: the plain forward / data-gradient instantiation fits with the offsets hoisted and is 2 - 7 % faster so.)
-        if (STATS || POOL || XF) asm volatile("" : "+v"(hh), "+v"(ww));
+        if (STATS || POOL || XF || RES) asm volatile("" : "+v"(hh), "+v"(ww));
 #endif
 #pragma unroll
         for (int j = 0; j < AFETCH; j++) {
@@ -773,13 +791,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #ifndef CONV_NO_BARRIER // (probe)
         __builtin_amdgcn_s_barrier(); // (a raw barrier: __syncthreads() would drain the loads in flight)
 #endif
+        const int tw = cur.tw, th = cur.th;
+        const long n = cur.n;
+        uint2 rpre[RPW][4];
+        if (RES) { // this tile's residual pieces, requested BEFORE the prefetch below (same addresses as conv64_epilogue's own loads)
+#pragma unroll
+            for (int rr = 0; rr < RPW; rr++) {
+                const int h0 = th * TH + rg * RPW, wcol = tw * TW + px;
+                const int h = POOL ? h0 + rr : h0 + rr;
+                const bool inside = POOL ? (h0 < H && wcol < W) : (h < H && wcol < W);
+                const unsigned short *rp = residual + (geo_off(geo, n, inside ? h : 0, inside ? wcol : 0) + 32 * mb + 4 * (lane >> 5));
+                // (asm: as ordinary loads the compiler waits for them itself at their first use -- with `vmcnt(0)`, because the
+                // prefetch behind them is issued conditionally and it merges the paths -- and drains the prefetch after all; the
+                // counted wait after the multiply is what covers them)
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rpre[rr][0]) : "v"(rp));
+                asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(rpre[rr][1]) : "v"(rp));
+                asm volatile("global_load_dwordx2 %0, %1, off offset:32" : "=v"(rpre[rr][2]) : "v"(rp));
+                asm volatile("global_load_dwordx2 %0, %1, off offset:48" : "=v"(rpre[rr][3]) : "v"(rp));
+            }
+        }
 #if CONV_SPREAD_FETCH
         const FetchCtx fctx = fetch_ctx(cursor_of(pahead), (it + 2) % NBUF, tile + 2 * stride < n_tiles); // issued inside the multiply
 #else
         if (tile + 2 * stride < n_tiles) fetch(cursor_of(pahead), (it + 2) % NBUF); // into the buffer of the tile before
 #endif
-        const int tw = cur.tw, th = cur.th;
-        const long n = cur.n;
         f32x16 acc[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; r++) acc[r] = f32x16{};
@@ -816,10 +851,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_fwd_async_kernel(const uns
 #undef LDS_BA
         if (tile + 2 * stride < n_tiles) WAIT_ALL_BUT_LAST_FETCH();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (RES) // the residual pieces are older than everything the counted wait above lets stay in flight: they have landed
+            asm volatile("" : "+v"(rpre[0][0]), "+v"(rpre[0][1]), "+v"(rpre[0][2]), "+v"(rpre[0][3]), "+v"(rpre[1][0]), "+v"(rpre[1][1]),
+                              "+v"(rpre[1][2]), "+v"(rpre[1][3])
+                         :: "memory");
 #ifdef CONV_NO_EPI // probe: the accumulators are kept alive, nothing is converted or stored
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
 #else
-        conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg, geo);
+        conv64_epilogue<POOL>(acc, y, STATS ? nullptr : shift, shv, residual, relu, n, th, tw, H, W, lane, px, mb, rg, geo, RES ? rpre : nullptr);
         if (STATS) conv64_stats(acc, rs, rq, th, tw, H, W, px, rg);
 #endif
         // XF: tile i+1 -- this thread's pieces landed at the wait above; rewritten here, after the epilogue, where the accumulators
@@ -961,6 +1000,13 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act(const void *x, const void *w, const
     if (!x || !w || !shift || !y || x == y || N <= 0 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH) return -1;
     const C64Plan pl = c64_plan(N, H, W, TH, TW);
     const unsigned nb = (unsigned)(pl.tiles >= 16384 ? CONV_BIG_GRID : pl.tiles >= 512 ? 512 : pl.tiles);
+#if CONV_ASYNC && CONV_RES_EARLY
+    if (residual)
+        hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<false, false, false, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift,
+                           (const unsigned short *)residual, relu, (double *)nullptr, pl.geo);
+    else
+#endif
     hipLaunchKernelGGL(CONV_FWD_KERNEL<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift, (const unsigned short *)residual, relu,
                        (double *)nullptr C64_GEO_ARG(pl));
@@ -976,6 +1022,13 @@ extern "C" int salsa_nn_conv3x3_c64_bias_act_pool(const void *x, const void *w, 
         return -1;
     const C64Plan pl = c64_plan(N, H, W, TH, TW);
     const unsigned nb = (unsigned)(pl.tiles >= 16384 ? CONV_BIG_GRID : pl.tiles >= 512 ? 512 : pl.tiles);
+#if CONV_ASYNC && CONV_RES_EARLY
+    if (residual)
+        hipLaunchKernelGGL((conv3x3_c64_fwd_async_kernel<true, false, false, true>), dim3(nb), dim3(256), 0, (hipStream_t)hip_stream,
+                           (const unsigned short *)x, (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift,
+                           (const unsigned short *)residual, relu, (double *)nullptr, pl.geo);
+    else
+#endif
     hipLaunchKernelGGL(CONV_FWD_KERNEL<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned short *)x,
                        (const unsigned short *)w, (unsigned short *)y, (int)N, pl.Hk, pl.Wk, shift, (const unsigned short *)residual, relu,
                        (double *)nullptr C64_GEO_ARG(pl));
