@@ -1621,7 +1621,11 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
                                                                const unsigned short *__restrict__ x1, const float *__restrict__ coef,
                                                                int relu, float *__restrict__ part /* deterministic mode: [gridDim.x][64*Cin*9] */)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short xs[SW_XS];
+    // (8 spare elements in front: the halo conversion stores every element into all three shifted copies UNCONDITIONALLY -- columns
+    // -2, -1, 32, 33 land in the 8 padding columns of this row or of the one before, which nothing reads; behind `0 <= col < 32`
+    // each of the 18 stores was an EXEC-mask region of its own)
+    __shared__ __attribute__((aligned(16))) unsigned short xs_raw[SW_XS + 8];
+    unsigned short *const xs = xs_raw + 8;
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1650,31 +1654,57 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
         unsigned okx, okg; // validity bits of the halo elements / the tile pieces
         int th, tw;
     };
-    auto fetch = [&](long tile, TileRegs &r) {
-        const int tw = (int)(tile % tiles_w);
-        const int th = (int)((tile / tiles_w) % tiles_h);
-        const long n = tile / ((long)tiles_w * tiles_h);
+    // Tile coordinates by a cursor that steps by the grid size with carries (decoding every tile index with 64-bit divisions --
+    // tile % tiles_w, (tile / tiles_w) % tiles_h, tile / (tiles_w tiles_h) -- was ~230 scalar instructions per tile on one dependent
+    // chain).  Past the end the cursor stays on the last tile (fetched, never used).
+    struct Cursor { int tw, th, n; long t; };
+    const long G = gridDim.x, t_last = n_tiles - 1;
+    const int dgw = (int)(G % tiles_w), dgh = (int)((G / tiles_w) % tiles_h), dgn = (int)(G / ((long)tiles_w * tiles_h));
+    auto cursor_at = [&](long t) {
+        Cursor c;
+        c.t = t; c.tw = (int)(t % tiles_w); c.th = (int)((t / tiles_w) % tiles_h); c.n = (int)(t / ((long)tiles_w * tiles_h));
+        return c;
+    };
+    const Cursor c_last = cursor_at(t_last);
+    auto advance = [&](Cursor &c) { // + G, clamped to the last tile
+        c.t += G;
+        c.tw += dgw;
+        if (c.tw >= tiles_w) { c.tw -= tiles_w; c.th += 1; }
+        c.th += dgh;
+        if (c.th >= tiles_h) { c.th -= tiles_h; c.n += 1; }
+        c.n += dgn;
+        if (c.t >= t_last) c = c_last;
+    };
+    auto fetch = [&](const Cursor &tile, TileRegs &r) {
+        const int tw = tile.tw, th = tile.th;
+        const long n = tile.n;
         const int h0 = th * WT_H, w0 = tw * WT_W;
         r.th = th; r.tw = tw; r.okx = 0u; r.okg = 0u;
+        // one wave-uniform 64-bit base per tensor and image + a 32-bit offset per load, validity by unsigned compares joined with `&`:
+        // written with `&&` and 64-bit element offsets every load was three nested EXEC-mask regions around three 64-bit multiply-adds
+        const float *xb = x + n * xbs;
+        const long pix0 = n * H * W * CH;
+        const unsigned short *gb = dy + pix0, *qb = BN ? x1 + pix0 : nullptr;
+        const int xcs32 = (int)xcs;
 #pragma unroll
         for (int j = 0; j < SW_XPF; j++) {
             const int i = tid + j * 256, cc = i / (WHALO_H * WHALO_W), rr = i - cc * (WHALO_H * WHALO_W);
             const int hh = rr / WHALO_W, ww = rr - hh * WHALO_W;
             const int h = h0 + hh - 1, wc = w0 + ww - 1;
-            const bool ok = i < n_x && h >= 0 && h < H && wc >= 0 && wc < W;
-            r.okx |= ok ? 1u << j : 0u;
-            r.px[j] = x[n * xbs + (ok ? cc * xcs + (long)h * W + wc : 0)];
+            const bool ok = (i < n_x) & ((unsigned)h < (unsigned)H) & ((unsigned)wc < (unsigned)W);
+            r.okx |= (ok ? 1u : 0u) << j;
+            r.px[j] = xb[ok ? (unsigned)(cc * xcs32 + h * W + wc) : 0u];
         }
 #pragma unroll
         for (int j = 0; j < GP; j++) {
             const int i = tid + j * 256, piece = i & 7, p = i >> 3;
             const int hh = p / WT_W, ww = p - hh * WT_W;
             const int h = h0 + hh, wc = w0 + ww;
-            const bool ok = h < H && wc < W;
-            r.okg |= ok ? 1u << j : 0u;
-            const long off = ((n * H + (ok ? h : 0)) * W + (ok ? wc : 0)) * CH + piece * 8;
-            r.pg[j] = *(const uint4 *)(dy + off);
-            if (BN) r.pq[j] = *(const uint4 *)(x1 + off);
+            const bool ok = (h < H) & (wc < W);
+            r.okg |= (ok ? 1u : 0u) << j;
+            const unsigned off = (ok ? (unsigned)((h * W + wc) * CH) : 0u) + (unsigned)(piece * 8);
+            r.pg[j] = *(const uint4 *)(gb + off);
+            if (BN) r.pq[j] = *(const uint4 *)(qb + off);
         }
     };
     // one bf16 pair of the tile: BatchNorm-backward apply on (g, x1) -> dx, rounded to bf16 (a pixel outside the image has
@@ -1717,8 +1747,7 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
                 const unsigned short bits = (unsigned short)(pack_bf16(((r.okx >> j) & 1u) ? r.px[j] : 0.f, 0.f) & 0xffffu); // round to nearest even
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) { // copy kx holds halo columns kx .. kx + 31 at positions 0 .. 31
-                    const int col = ww - kx;
-                    if (col >= 0 && col < WT_W) xs[((cc * WHALO_H + hh) * 3 + kx) * SW_XROW + col] = bits;
+                    xs[((cc * WHALO_H + hh) * 3 + kx) * SW_XROW + ww - kx] = bits;
                 }
             }
         }
@@ -1739,24 +1768,27 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
     };
     TileRegs ra, rb;
     long tile = blockIdx.x; // (< n_tiles: the launch has at most one workgroup per tile)
-    const long G = gridDim.x, t_last = n_tiles - 1;
     // Every fetch is issued unconditionally (past the end: the last tile again, never converted): with a fetch or a tile behind a
     // branch the compiler's wait insertion merges the paths and drains BOTH sets (vmcnt 13 .. 0) where the older set alone
     // is needed (vmcnt 27 .. 14)
-    auto clampt = [&](long t) { return t < t_last ? t : t_last; };
-    fetch(tile, ra);
-    fetch(clampt(tile + G), rb);
+    Cursor nf = cursor_at(tile); // the next tile to request
+    fetch(nf, ra);
+    advance(nf);
+    fetch(nf, rb);
+    advance(nf);
     __syncthreads(); // the zero fill of xs (and nothing else: the loads above land in registers)
     for (; tile + G < n_tiles; tile += 2 * G) {
         raw_barrier(); // the previous tile's LDS reads are done
         convert(ra);
         raw_barrier();
-        fetch(clampt(tile + 2 * G), ra); // in flight during this tile's multiply and the whole next tile
+        fetch(nf, ra); // (tile + 2 G) in flight during this tile's multiply and the whole next tile
+        advance(nf);
         stem_wrw_steps<0>(acc, ga, xa);
         raw_barrier();
         convert(rb);
         raw_barrier();
-        fetch(clampt(tile + 3 * G), rb);
+        fetch(nf, rb); // (tile + 3 G)
+        advance(nf);
         stem_wrw_steps<0>(acc, ga, xa);
     }
     if (tile < n_tiles) {
@@ -1783,7 +1815,8 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
                                          int64_t N, int Cin, int H, int W, void *hip_stream)
 {
     if (!x || !dy || !dw || N <= 0 || Cin <= 0 || Cin > 7 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
-        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin ||
+        x_channel_stride * Cin >= INT32_MAX /* 32-bit element offsets inside an image */)
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     const unsigned nb = (unsigned)(tiles >= 1280 ? 1280 : tiles); // persistent, five per CU (30 KB of LDS each)
@@ -1808,7 +1841,8 @@ extern "C" int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stri
                                             void *hip_stream)
 {
     if (!x || !g || !x1 || !coef || !dw || N <= 0 || Cin <= 0 || Cin > 7 || H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH ||
-        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin)
+        x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin ||
+        x_channel_stride * Cin >= INT32_MAX /* 32-bit element offsets inside an image */)
         return -1;
     const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
     // persistent; this instantiation holds 246 registers (two sets of tile loads in flight): TWO workgroups per CU are resident, so
