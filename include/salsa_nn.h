@@ -101,6 +101,18 @@ int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride, int64_t x_
  * so the full-resolution dx is neither written nor read. */
 int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *g, const void *x1,
                                  const float *coef, int relu, float *dw, int64_t N, int Cin, int H, int W, void *hip_stream);
+
+/* ... and with the BatchNorm backward's REDUCTION folded in as well (round 5): dx = a (g - b - xh k') is linear in the two totals
+ * b = mean(g), k' = mean(g xh), so the pass over (g, x1, x) accumulates G = sum g (x) patch, Xh = sum xh (x) patch, S0 = sum patch,
+ * dbeta = sum g, dgamma = sum g xh per workgroup, and a second small launch combines the slabs: dW = a (G - b S0 - k' Xh).  Replaces
+ * salsa_nn_bn_bwd(dx = NULL) + salsa_nn_conv3x3_stem_wrw_bn (one pass over the 524-MB g and x1 instead of two).  mean / invstd: the
+ * forward's saved statistics; ws: salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes(N, H, W) bytes of device scratch (-5 when smaller); dw is
+ * ADDED to, dgamma / dbeta are written.  Always bit-reproducible (slabs added in a fixed order, float64). */
+size_t salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes(int64_t N, int H, int W);
+int salsa_nn_conv3x3_stem_wrw_bnf(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *g, const void *x1,
+                                  const float *mean, const float *invstd, const float *gamma, const float *beta, int relu, float *dw,
+                                  float *dgamma, float *dbeta, void *ws, size_t ws_bytes, int64_t N, int Cin, int H, int W,
+                                  void *hip_stream);
 /* weight gradient of the same layer: dw float32 [64 co][3][3][64 ci] += sum_pixels dy[p][co] * x[p+tap][ci] (zero it first) */
 int salsa_nn_conv3x3_c64_wrw(const void *x, const void *dy, float *dw, int64_t N, int H, int W, void *hip_stream);
 

@@ -119,6 +119,10 @@ def load():
     L.salsa_nn_conv3x3_c64_xform_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint32, C.c_int64, C.c_int, C.c_int, vp]
     L.salsa_nn_conv3x3_c64_wrw_xform.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_uint32, C.c_int64, C.c_int, C.c_int, vp]
     L.salsa_nn_get_deterministic.argtypes = []
+    L.salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes.restype = C.c_size_t
+    L.salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
+    L.salsa_nn_conv3x3_stem_wrw_bnf.argtypes = [vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, C.c_int64,
+                                                C.c_int, C.c_int, C.c_int, vp]
     L.salsa_nn_conv3x3_c64_stats_blocks.argtypes = [C.c_int64, C.c_int, C.c_int]
     L.salsa_nn_conv3x3_c64_stats.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
     L.salsa_nn_conv3x3_stem_stats_blocks.argtypes = [C.c_int64, C.c_int, C.c_int]
@@ -156,5 +160,5 @@ EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_c
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_fwd_regw', 'salsa_gru_scan_bwd', 'salsa_gru_scan_bwd_regw']
 NN_EXPORTS = ['salsa_nn_avgpool2x2_fwd', 'salsa_nn_avgpool2x2_bwd', 'salsa_nn_conv3x3_c64', 'salsa_nn_conv3x3_c64_bias_act', 'salsa_nn_conv3x3_c64_wrw', 'salsa_nn_conv3x3_stem', 'salsa_nn_conv3x3_c64_bias_act_pool', 'salsa_nn_conv3x3_wide_supported', 'salsa_nn_conv3x3_wide', 'salsa_nn_conv3x3_wide_bias_act', 'salsa_nn_conv3x3_wide_wrw_supported', 'salsa_nn_conv3x3_wide_table_len', 'salsa_nn_conv3x3_wide_tile_count', 'salsa_nn_conv3x3_wide_tables', 'salsa_nn_conv3x3_wide_wrw', 'salsa_nn_bn_supported', 'salsa_nn_bn_workspace_bytes', 'salsa_nn_bn_train_fwd',
               'salsa_nn_bn_eval_fwd', 'salsa_nn_bn_bwd', 'salsa_nn_bn_train_fwd_pool', 'salsa_nn_bn_bwd_pool', 'salsa_nn_conv_filter_bank', 'salsa_nn_conv3x3_c64_stats_blocks', 'salsa_nn_conv3x3_c64_stats', 'salsa_nn_conv3x3_stem_wrw', 'salsa_nn_conv3x3_stem_stats_blocks', 'salsa_nn_conv3x3_stem_stats', 'salsa_nn_conv3x3_stem_wrw_bn', 'salsa_nn_conv1x1_supported', 'salsa_nn_conv1x1', 'salsa_nn_conv1x1_wrw_supported', 'salsa_nn_conv1x1_wrw', 'salsa_nn_seld_loss', 'salsa_nn_seld_loss_bwd', 'salsa_nn_freq_mean_fwd',
-              'salsa_nn_freq_mean_bwd', 'salsa_nn_colsum2', 'salsa_nn_conv3x3_wide_stats', 'salsa_nn_conv3x3_wide_stats_blocks', 'salsa_nn_set_deterministic', 'salsa_nn_get_deterministic', 'salsa_nn_bn_train_finalize', 'salsa_nn_conv3x3_c64_xform_stats', 'salsa_nn_conv3x3_c64_wrw_xform', 'salsa_nn_adam_step', 'salsa_nn_bn_train_fwd_bits',
+              'salsa_nn_freq_mean_bwd', 'salsa_nn_colsum2', 'salsa_nn_conv3x3_wide_stats', 'salsa_nn_conv3x3_wide_stats_blocks', 'salsa_nn_set_deterministic', 'salsa_nn_get_deterministic', 'salsa_nn_conv3x3_stem_wrw_bnf', 'salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes', 'salsa_nn_bn_train_finalize', 'salsa_nn_conv3x3_c64_xform_stats', 'salsa_nn_conv3x3_c64_wrw_xform', 'salsa_nn_adam_step', 'salsa_nn_bn_train_fwd_bits',
               'salsa_nn_bn_train_fwd_pool_bits', 'salsa_nn_bn_bwd_pool_bits']

@@ -770,6 +770,8 @@ class Conv1x1(torch.nn.Conv2d):
 
 
 USE_STEM_FUSED_BWD = os.environ.get('SALSA_STEM_FUSED_BWD', '1') != '0'
+# ... and the BatchNorm backward's reduction in the same pass (round 5: salsa_nn_conv3x3_stem_wrw_bnf); 0: reduce launch + coefficient table
+USE_STEM_BN_REDUCE_FUSED = os.environ.get('SALSA_STEM_BN_REDUCE_FUSED', '1') != '0'
 
 
 class _StemConvBnRelu(torch.autograd.Function):
@@ -819,6 +821,16 @@ class _StemConvBnRelu(torch.autograd.Function):
         ws = torch.empty(L.salsa_nn_bn_workspace_bytes(1, M, Cn) // 8 + 1, dtype=torch.float64, device=x.device)
         coef = torch.empty(7 * Cn, dtype=torch.float32, device=x.device)
         gw = _grad_zeros((64, Cin, 3, 3), x.device)
+        if USE_STEM_BN_REDUCE_FUSED:   # the BatchNorm backward's reduction inside the weight-gradient pass as well (one read of g, x1)
+            nbytes = L.salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes(N, H, W)
+            slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = L.salsa_nn_conv3x3_stem_wrw_bnf(_ptr(x), x.stride(0), x.stride(1), _ptr(g), _ptr(x1), _ptr(save[0]), _ptr(save[1]),
+                                                     _ptr(bn_w), _ptr(bn_b), 1, _ptr(gw), _ptr(dwb[0]), _ptr(dwb[1]), _ptr(slabs), nbytes,
+                                                     N, Cin, H, W, _stream(x))
+            if rc:
+                raise RuntimeError('salsa_nn_conv3x3_stem_wrw_bnf failed (%d)' % rc)
+            return None, gw, dwb[0], dwb[1], None, None, None, None, None
         with torch.cuda.device(x.device):
             rc = L.salsa_nn_bn_bwd(_ptr(g), None, _ptr(x1), None, None, 1, M, Cn, _ptr(bn_w), _ptr(bn_b), _ptr(save[0]), _ptr(save[1]),
                                    1, _ptr(dwb[0]), _ptr(dwb[1]), _ptr(ws), _ptr(coef), 0.0, 0, _stream(x))

@@ -1632,27 +1632,76 @@ __device__ __forceinline__ void stem_wrw_steps(f32x16 &acc, const unsigned ga, c
     }
 }
 
+// MODE 2 (see the kernel): the same input fragment against the masked-gradient tile and the normalised-activation tile; its eight
+// values also go into this lane's share of S0 (v_dot2_f32_bf16 with a pair of ones: one register, where a third product against a
+// fragment of ones would cost sixteen)
+// S0 must leave out the OUTPUT pixels of a tile that hang over the image's right / bottom edge by itself (G and Xh see g = xh = 0
+// there, but those pixels' input patches next to the edge are real): om[hw][q] = the pair of ones for pixel pair q of the lane's eight
+// pixels in column half hw (zero where the pixel is outside), rows outside (rr >= h_left) are dropped per row.
+template <int KS>
+__device__ __forceinline__ void stem_wrw_steps2(f32x16 &acc_g, f32x16 &acc_x, float &s0, float &t, const unsigned ga, const unsigned ga2,
+                                                const unsigned xa, const unsigned (&om)[2][4], const int h_left)
+{
+    if constexpr (KS < 8) {
+        constexpr int rr = KS >> 1, hw = KS & 1;
+        tr_frag fa, fx;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t b;
+        LDS_TR_ISSUE(fa, ga, 2 * ((rr * WT_W + 16 * hw) * ROW));
+        LDS_TR_ISSUE(fx, ga2, 2 * ((rr * WT_W + 16 * hw) * ROW));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(xa), "n"(2 * (rr * 3 * SW_XROW + 16 * hw)));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa.lo), "+v"(fa.hi), "+v"(fx.lo), "+v"(fx.hi), "+v"(b));
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, b);
+        acc_g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa), bv, acc_g, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fx), bv, acc_x, 0, 0, 0);
+        // (one asm statement with its own trailing wait states: a dot product's result needs them before an ordinary vector
+        // instruction may read it, and the compiler's hazard recognizer cannot see into asm statements -- four separate ones let the
+        // add below read t too early; the builtin form was worse: the compiler then read the fragment's registers after re-using them)
+        if (hw == 0) t = 0.f;
+        asm volatile("v_dot2_f32_bf16 %0, %1, %5, %0\n\tv_dot2_f32_bf16 %0, %2, %6, %0\n\tv_dot2_f32_bf16 %0, %3, %7, %0\n\t"
+                     "v_dot2_f32_bf16 %0, %4, %8, %0\n\ts_nop 4"
+                     : "+v"(t)
+                     : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(om[hw][0]), "v"(om[hw][1]), "v"(om[hw][2]), "v"(om[hw][3]));
+        if (hw == 1) s0 += rr < h_left ? t : 0.f;
+        stem_wrw_steps2<KS + 1>(acc_g, acc_x, s0, t, ga, ga2, xa, om, h_left);
+    }
+}
+struct StemBnf { const float *mean, *invstd, *gamma, *beta; }; // MODE 2: the forward's statistics and the affine parameters [64]
+constexpr int SW_SLAB = 2 * 64 * 64 + 3 * 64; // MODE 2: a workgroup's partial sums: G[64][64] (column 63 = dbeta), Xh[64][64], S0[2][64], dgamma[64]
+
 // BN: dy is not the gradient of the convolution's output but of the BatchNorm (+ ReLU) output behind it, and x1 that
 // BatchNorm's input (= this convolution's output): the tile's dx = a (g masked - b - (x1 - mean) k) -- the BatchNorm backward's
 // apply pass, coefficients from salsa_nn_bn_bwd(dx = NULL) -- is formed while the tile goes into LDS, rounded to bf16 exactly
 // as the separate pass would have stored it.  This layer's weight gradient is dx's ONLY reader (the network input needs no
 // gradient), so the 524-MB dx is never written or read: 4 tensor passes become 2.
-template <bool BN>
+// MODE 2 (round 5): the BatchNorm backward's REDUCTION pass folded in as well.  dx = a (g - b - xh k') is linear in the two totals
+// b = mean(g), k' = mean(g xh) that are only known after a pass over (g, x1) -- the pass this kernel makes anyway.  So it multiplies
+// the input patches with the masked gradient g AND with the normalised activation xh = (x1 - mean) invstd,
+//     G[co][c] = sum_p g[p][co] patch[p][c],   Xh[co][c] = sum_p xh[p][co] patch[p][c],   S0[c] = sum_p patch[p][c]  (v_dot2 on the side),
+// gets dbeta = sum g as G's column 63 (the spare eighth input plane holds ones) and adds up dgamma = sum g xh on the way; a small
+// launch afterwards combines the workgroups' partial sums:
+//     dW[co][c] = a[co] (G[co][c] - b[co] S0[c] - k'[co] Xh[co][c]),   a = gamma invstd.
+// The salsa_nn_bn_bwd(dx = NULL) launch (a second read of the 524-MB g and x1, ~145 us) disappears; the operands are g (exact in
+// bf16) and bf16(xh) where MODE 1 rounds dx to bf16: the same order of rounding error.
+template <int MODE>
 #ifndef STEM_WRW_WPS
 #define STEM_WRW_WPS 1
 #endif
-__global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
+__global__ __launch_bounds__(256, MODE == 2 ? 2 : STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(const float *__restrict__ x, long xbs, long xcs,
                                                                const unsigned short *__restrict__ dy, float *__restrict__ dw,
                                                                int N, int Cin, int H, int W,
                                                                const unsigned short *__restrict__ x1, const float *__restrict__ coef,
-                                                               int relu, float *__restrict__ part /* deterministic mode: [gridDim.x][64*Cin*9] */)
+                                                               int relu, float *__restrict__ part /* deterministic mode: [gridDim.x][64*Cin*9]; MODE 2: [gridDim.x][SW_SLAB] */,
+                                                               const StemBnf bnf)
 {
+    constexpr bool BN = MODE != 0;
     // (8 spare elements in front: the halo conversion stores every element into all three shifted copies UNCONDITIONALLY -- columns
     // -2, -1, 32, 33 land in the 8 padding columns of this row or of the one before, which nothing reads; behind `0 <= col < 32`
     // each of the 18 stores was an EXEC-mask region of its own)
     __shared__ __attribute__((aligned(16))) unsigned short xs_raw[SW_XS + 8];
     unsigned short *const xs = xs_raw + 8;
     __shared__ __attribute__((aligned(16))) unsigned short gl[WT_H * WT_W * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned short gl2[MODE == 2 ? WT_H * WT_W * ROW : 8]; // MODE 2: the xh tile
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int mb = wv & 1, nb = wv >> 1; // this wave: co 32*mb.., columns 32*nb..
@@ -1662,8 +1711,17 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
     const unsigned b_lane = 2u * (unsigned)(((ci * WHALO_H + tap / 3) * 3 + tap % 3) * SW_XROW + 8 * kh);
     const unsigned ga = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)gl + a_lane;
     const unsigned xa = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)xs + b_lane;
+    const unsigned ga2 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned short *)gl2 + a_lane;
     for (int i = tid; i < SW_XS / 8; i += 256) ((uint4 *)xs)[i] = make_uint4(0u, 0u, 0u, 0u);
-    f32x16 acc = f32x16{};
+    if (MODE == 2) { // the spare eighth input plane (column 63 = its tap 0) holds ONES: G[co][63] = sum_p g[p][co] = dbeta
+        __syncthreads();
+        for (int i = tid; i < WHALO_H * 3 * SW_XROW; i += 256) xs[7 * WHALO_H * 3 * SW_XROW + i] = 0x3F80;
+    }
+    f32x16 acc = f32x16{}, acc_x = f32x16{};
+    float s0 = 0.f;  // MODE 2: this lane's share of S0[c] (its half of the k-steps' pixels)
+    float s_dg[8];   // MODE 2: this thread's share of dgamma (its pieces always cover the same 8 channels)
+#pragma unroll
+    for (int e = 0; e < 8; e++) s_dg[e] = 0.f;
     const int tiles_w = (W + WT_W - 1) / WT_W, tiles_h = (H + WT_H - 1) / WT_H;
     const long n_tiles = (long)N * tiles_h * tiles_w;
     constexpr int GP = WT_H * WT_W * 8 / 256;
@@ -1738,7 +1796,7 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
     // same 8 channels (piece index = tid & 7), so their 56 coefficients live in registers (a table in LDS cost seven LDS reads
     // per element: 0.43 ms for this kernel); the arithmetic is bn_bwd_apply_kernel's, operation for operation.
     float c_a[8], c_b[8], c_mu[8], c_k[8], c_is[8], c_be[8], c_ga[8];
-    if (BN) {
+    if (MODE == 1) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int ch = (tid & 7) * 8 + e;
@@ -1746,6 +1804,28 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
             c_is[e] = coef[4 * CH + ch]; c_be[e] = coef[5 * CH + ch]; c_ga[e] = coef[6 * CH + ch];
         }
     }
+    if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int ch = (tid & 7) * 8 + e;
+            c_mu[e] = bnf.mean[ch]; c_is[e] = bnf.invstd[ch]; c_ga[e] = bnf.gamma[ch]; c_be[e] = bnf.beta[ch];
+            c_a[e] = c_b[e] = c_k[e] = 0.f;
+        }
+    }
+    // MODE 2: one bf16 pair of the tile -> the masked gradient pair (returned) and the normalised-activation pair (xh2), both as the
+    // matrix operands; dgamma from the unrounded float32 values, as bn_bwd_reduce_kernel forms it
+    auto bnf_pair = [&](const unsigned g2, const unsigned q2, const int e0, const bool inside, unsigned &xh2, float &dg0, float &dg1) -> unsigned {
+        const float g0 = __uint_as_float(g2 << 16), g1 = __uint_as_float(g2 & 0xffff0000u);
+        const float x0 = __uint_as_float(q2 << 16), x1v = __uint_as_float(q2 & 0xffff0000u);
+        const float xh0 = (x0 - c_mu[e0]) * c_is[e0], xh1 = (x1v - c_mu[e0 + 1]) * c_is[e0 + 1];
+        const bool live0 = inside & !(relu && !(xh0 * c_ga[e0] + c_be[e0] > 0.f));
+        const bool live1 = inside & !(relu && !(xh1 * c_ga[e0 + 1] + c_be[e0 + 1] > 0.f));
+        const float gk0 = live0 ? g0 : 0.f, gk1 = live1 ? g1 : 0.f;
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(dg0) : "v"(gk0), "v"(xh0)); // (written out: left to the compiler the eight accumulators
+        asm("v_fmac_f32 %0, %1, %2" : "+v"(dg1) : "v"(gk1), "v"(xh1)); //  cost the kernel ~100 registers -- 353 against 245)
+        xh2 = pack_bf16(inside ? xh0 : 0.f, inside ? xh1 : 0.f);
+        return pack_bf16(gk0, gk1); // (exact: g is a bf16 value or zero)
+    };
     auto bn_pair = [&](const unsigned g2, const unsigned q2, const int e0) -> unsigned {
         float r[2];
 #pragma unroll
@@ -1782,15 +1862,36 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
             const int i = tid + j * 256;
             const bool inside = (r.okg >> j) & 1u;
             uint4 v = r.pg[j];
-            if (BN) {
+            if (MODE == 1) {
                 v.x = bn_pair(r.pg[j].x, r.pq[j].x, 0);
                 v.y = bn_pair(r.pg[j].y, r.pq[j].y, 2);
                 v.z = bn_pair(r.pg[j].z, r.pq[j].z, 4);
                 v.w = bn_pair(r.pg[j].w, r.pq[j].w, 6);
             }
-            if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
+            if (MODE == 2) {
+                uint4 u;
+                v.x = bnf_pair(r.pg[j].x, r.pq[j].x, 0, inside, u.x, s_dg[0], s_dg[1]);
+                v.y = bnf_pair(r.pg[j].y, r.pq[j].y, 2, inside, u.y, s_dg[2], s_dg[3]);
+                v.z = bnf_pair(r.pg[j].z, r.pq[j].z, 4, inside, u.z, s_dg[4], s_dg[5]);
+                v.w = bnf_pair(r.pg[j].w, r.pq[j].w, 6, inside, u.w, s_dg[6], s_dg[7]);
+                *(uint4 *)(gl2 + (long)(i >> 3) * ROW + (i & 7) * 8) = u;
+            } else if (!inside) v = make_uint4(0u, 0u, 0u, 0u);
             *(uint4 *)(gl + (long)(i >> 3) * ROW + (i & 7) * 8) = v;
         }
+    };
+    auto multiply = [&](const int th, const int tw) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+            const int h_left = H - th * WT_H, w_left = W - tw * WT_W;
+            unsigned om[2][4];
+#pragma unroll
+            for (int hw = 0; hw < 2; hw++) {
+                const int nv = w_left - (16 * hw + 8 * kh); // valid pixels among this lane's eight (<= 0: none, >= 8: all)
+#pragma unroll
+                for (int q = 0; q < 4; q++) om[hw][q] = (2 * q < nv ? 0x3F80u : 0u) | (2 * q + 1 < nv ? 0x3F800000u : 0u);
+            }
+            float t = 0.f;
+            stem_wrw_steps2<0>(acc, acc_x, s0, t, ga, ga2, xa, om, h_left);
+        } else stem_wrw_steps<0>(acc, ga, xa);
     };
     TileRegs ra, rb;
     long tile = blockIdx.x; // (< n_tiles: the launch has at most one workgroup per tile)
@@ -1807,21 +1908,46 @@ __global__ __launch_bounds__(256, STEM_WRW_WPS) void conv3x3_stem_wrw_kernel(con
         raw_barrier(); // the previous tile's LDS reads are done
         convert(ra);
         raw_barrier();
+        const int tha = ra.th, twa = ra.tw;
         fetch(nf, ra); // (tile + 2 G) in flight during this tile's multiply and the whole next tile
         advance(nf);
-        stem_wrw_steps<0>(acc, ga, xa);
+        multiply(tha, twa);
         raw_barrier();
         convert(rb);
         raw_barrier();
+        const int thb = rb.th, twb = rb.tw;
         fetch(nf, rb); // (tile + 3 G)
         advance(nf);
-        stem_wrw_steps<0>(acc, ga, xa);
+        multiply(thb, twb);
     }
     if (tile < n_tiles) {
         raw_barrier();
         convert(ra);
         raw_barrier();
-        stem_wrw_steps<0>(acc, ga, xa);
+        multiply(ra.th, ra.tw);
+    }
+    if (MODE == 2) { // this workgroup's slab: G (column 63: dbeta), Xh, S0 (the two lane halves), dgamma
+        float *slab = part + (long)blockIdx.x * SW_SLAB;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int co = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            slab[co * 64 + c] = acc[reg];
+            slab[64 * 64 + co * 64 + c] = acc_x[reg];
+        }
+        if (mb == 0) slab[2 * 64 * 64 + 64 * kh + c] = s0;
+        // dgamma: the 32 threads that share a channel group (tid & 7) through LDS, in a fixed order
+        raw_barrier(); // (the last multiply's reads of gl are done)
+        float *red = (float *)gl; // [8 values][256 threads]
+#pragma unroll
+        for (int e = 0; e < 8; e++) red[e * 256 + tid] = s_dg[e];
+        __syncthreads();
+        if (tid < 64) { // channel (tid & 7) * 8 + (tid >> 3)
+            const int grp = tid & 7, v = tid >> 3;
+            float t = 0.f;
+            for (int q = 0; q < 32; q++) t += red[v * 256 + grp + 8 * q];
+            slab[2 * 64 * 64 + 128 + grp * 8 + v] = t;
+        }
+        return;
     }
     // D[m = co][n = column]: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (c < Cin * 9 && (long)blockIdx.x < n_tiles) {
@@ -1849,9 +1975,9 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * Cin * 9, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
                        (long)x_channel_stride, (const unsigned short *)dy, dw, (int)N, Cin, H, W, (const unsigned short *)nullptr,
-                       (const float *)nullptr, 0, part);
+                       (const float *)nullptr, 0, part, StemBnf{});
     if (part) return salsa_nn_det_finish(part, (int)nb, 64L * Cin * 9, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }
@@ -1859,6 +1985,85 @@ extern "C" int salsa_nn_conv3x3_stem_wrw(const float *x, int64_t x_batch_stride,
 #ifndef STEM_WRW_BN_GRID
 #define STEM_WRW_BN_GRID 512
 #endif
+namespace {
+// MODE 2's second launch: workgroup co adds the slabs' partial sums of its output channel in float64 -- thread (column k = tid & 63,
+// slab lane tid >> 6) takes every 16th slab in ascending order, lane 0 then adds the 16 lanes' sums in lane order: a fixed order,
+// bit-reproducible -- and combines them: dW[co][k] += a (G - b S0[k] - k' Xh), dbeta = sum g, dgamma = sum g xh.
+__global__ __launch_bounds__(1024) void stem_wrw_bnf_finalize_kernel(const float *__restrict__ part, int nslab, double M, int ncol /* Cin * 9 */,
+                                                                     const StemBnf bnf, float *__restrict__ dw, float *__restrict__ dgamma,
+                                                                     float *__restrict__ dbeta)
+{
+    __shared__ double red[5][1024];
+    const int co = blockIdx.x, k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    double sg = 0.0, sx = 0.0, s0 = 0.0, sb = 0.0, sd = 0.0;
+    for (int b0 = sl; b0 < nslab; b0 += 16 * 4) { // four slabs' loads in flight per thread; the additions keep their order
+        float v[4][5];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int b = b0 + 16 * u;
+            const float *q = part + (long)(b < nslab ? b : b0) * SW_SLAB;
+            v[u][0] = q[co * 64 + k];
+            v[u][1] = q[64 * 64 + co * 64 + k];
+            v[u][2] = q[2 * 64 * 64 + k] + q[2 * 64 * 64 + 64 + k]; // S0: the two lane halves
+            v[u][3] = q[co * 64 + 63];                              // dbeta: G's column of ones
+            v[u][4] = q[2 * 64 * 64 + 128 + co];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (b0 + 16 * u < nslab) {
+                sg += (double)v[u][0]; sx += (double)v[u][1]; s0 += (double)v[u][2]; sb += (double)v[u][3]; sd += (double)v[u][4];
+            }
+    }
+    red[0][threadIdx.x] = sg; red[1][threadIdx.x] = sx; red[2][threadIdx.x] = s0; red[3][threadIdx.x] = sb; red[4][threadIdx.x] = sd;
+    __syncthreads();
+    if (sl != 0) return;
+    double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < 16; q++)
+#pragma unroll
+        for (int a = 0; a < 5; a++) t[a] += red[a][q * 64 + k];
+    const double a = (double)bnf.gamma[co] * (double)bnf.invstd[co], bb = t[3] / M, kk = t[4] / M;
+    if (k < ncol) dw[(long)co * ncol + k] += (float)(a * (t[0] - bb * t[2] - kk * t[1]));
+    if (k == 0) {
+        dbeta[co] = (float)t[3];
+        dgamma[co] = (float)t[4];
+    }
+}
+} // namespace
+
+/* workspace of salsa_nn_conv3x3_stem_wrw_bnf: one slab of partial sums per workgroup */
+extern "C" size_t salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes(int64_t N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    return sizeof(float) * SW_SLAB * (size_t)(tiles >= STEM_WRW_BN_GRID ? STEM_WRW_BN_GRID : tiles);
+}
+
+/* The first layer's weight gradient with the WHOLE BatchNorm (+ ReLU) backward behind it folded in (conv3x3_stem_wrw_kernel<2>): g =
+ * gradient of the BatchNorm's output, x1 = its input, both bf16 channels-last; mean / invstd = the forward's saved statistics.  Leaves
+ * dw (ADDED to), dgamma, dbeta; two launches (the pass over g / x1 / x, and the combination of the workgroups' slabs in `ws`), always
+ * bit-reproducible.  Replaces salsa_nn_bn_bwd(dx = NULL) + salsa_nn_conv3x3_stem_wrw_bn: one pass over g and x1 instead of two. */
+extern "C" int salsa_nn_conv3x3_stem_wrw_bnf(const float *x, int64_t x_batch_stride, int64_t x_channel_stride, const void *g,
+                                             const void *x1, const float *mean, const float *invstd, const float *gamma,
+                                             const float *beta, int relu, float *dw, float *dgamma, float *dbeta, void *ws,
+                                             size_t ws_bytes, int64_t N, int Cin, int H, int W, void *hip_stream)
+{
+    if (!x || !g || !x1 || !mean || !invstd || !gamma || !beta || !dw || !dgamma || !dbeta || !ws || N <= 0 || Cin <= 0 || Cin > 7 ||
+        H <= 0 || W <= 0 || N * H * W >= INT32_MAX / CH || x_channel_stride < (int64_t)H * W || x_batch_stride < x_channel_stride * Cin ||
+        x_channel_stride * Cin >= INT32_MAX)
+        return -1;
+    if (ws_bytes < salsa_nn_conv3x3_stem_wrw_bnf_ws_bytes(N, H, W)) return -5;
+    const long tiles = (long)N * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+    const unsigned nb = (unsigned)(tiles >= STEM_WRW_BN_GRID ? STEM_WRW_BN_GRID : tiles);
+    const StemBnf bnf = {mean, invstd, gamma, beta};
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<2>, dim3(nb), dim3(256), 0, st, x, (long)x_batch_stride, (long)x_channel_stride,
+                       (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, (const float *)nullptr, relu,
+                       (float *)ws, bnf);
+    hipLaunchKernelGGL(stem_wrw_bnf_finalize_kernel, dim3(64), dim3(1024), 0, st, (const float *)ws, (int)nb, (double)(N * H * W), Cin * 9,
+                       bnf, dw, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? 0 : -6;
+}
+
 // The same with the BatchNorm (+ ReLU) that follows the first layer differentiated on the fly: g = gradient of the BatchNorm's
 // OUTPUT, x1 = its input (the first layer's output), both bf16 channels-last; coef = the [7][64] table salsa_nn_bn_bwd leaves in
 // coef_ws (call it with dx = NULL: it then skips its apply pass, whose only reader would have been this kernel).
@@ -1877,8 +2082,8 @@ extern "C" int salsa_nn_conv3x3_stem_wrw_bn(const float *x, int64_t x_batch_stri
     int rc = 0;
     float *part = salsa_nn_det_begin((int)nb, 64L * Cin * 9, (hipStream_t)hip_stream, &rc);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
-                       (long)x_channel_stride, (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, coef, relu, part);
+    hipLaunchKernelGGL(conv3x3_stem_wrw_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, x, (long)x_batch_stride,
+                       (long)x_channel_stride, (const unsigned short *)g, dw, (int)N, Cin, H, W, (const unsigned short *)x1, coef, relu, part, StemBnf{});
     if (part) return salsa_nn_det_finish(part, (int)nb, 64L * Cin * 9, dw, (hipStream_t)hip_stream);
     return hipGetLastError() == hipSuccess ? 0 : -6;
 }

@@ -743,14 +743,18 @@ def test_conv_epilogue_statistics_feed_the_batchnorm():
         nn_ops.USE_CONV_STATS = saved
 
 
-def test_first_layer_backward_without_the_batchnorm_apply_pass():
+@pytest.mark.parametrize('reduce_fused', [True, False])
+def test_first_layer_backward_without_the_batchnorm_apply_pass(reduce_fused):
     """_StemConvBnRelu: relu(bn(conv7->64(x))) as one autograd node whose backward hands (g, conv output, BatchNorm
     coefficients) to the weight-gradient kernel instead of materialising the BatchNorm's input gradient
-    (salsa_nn_bn_bwd with dx = NULL + salsa_nn_conv3x3_stem_wrw_bn).  Must match the two-node path (conv -> BatchNormAct2d):
-    output, running statistics and the gradients of the filter, gamma and beta; ragged sizes."""
+    (salsa_nn_bn_bwd with dx = NULL + salsa_nn_conv3x3_stem_wrw_bn) -- or, reduce_fused (the default), folds the BatchNorm
+    backward's reduction into that pass as well (salsa_nn_conv3x3_stem_wrw_bnf: dW = a (G - b S0 - k' Xh) from one read of g and
+    x1).  Must match the two-node path (conv -> BatchNormAct2d): output, running statistics and the gradients of the filter, gamma
+    and beta; ragged sizes; the reduce-fused backward twice gives the same bits."""
     from salsa_amd.crnn import nn_ops
     dev = torch.device('cuda:0')
-    saved = nn_ops.USE_STEM_FUSED_BWD
+    saved, saved_r = nn_ops.USE_STEM_FUSED_BWD, nn_ops.USE_STEM_BN_REDUCE_FUSED
+    nn_ops.USE_STEM_BN_REDUCE_FUSED = reduce_fused
     try:
         for n, cin, h, w in ((2, 7, 40, 70), (1, 7, 9, 33), (3, 4, 17, 5), (4, 7, 64, 200)):
             res = {}
@@ -771,8 +775,20 @@ def test_first_layer_backward_without_the_batchnorm_apply_pass():
             assert res[True][3] == res[False][3] == 1
             for a, b in zip(res[True][:3] + res[True][4:], res[False][:3] + res[False][4:]):
                 torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-6)
+            if reduce_fused:                                                     # bit-reproducible (slabs, fixed order)
+                nn_ops.USE_STEM_FUSED_BWD = True
+                conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = nn_ops.conv_bn_act(conv, bn, x)                          # (the two-node modules of the last pass: same weights)
+                out.backward(gy)
+                first = [t.grad.clone() for t in (conv.weight, bn.weight, bn.bias)]
+                conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = nn_ops.conv_bn_act(conv, bn, x)
+                out.backward(gy)
+                assert all(torch.equal(a, t.grad) for a, t in zip(first, (conv.weight, bn.weight, bn.bias)))
     finally:
-        nn_ops.USE_STEM_FUSED_BWD = saved
+        nn_ops.USE_STEM_FUSED_BWD, nn_ops.USE_STEM_BN_REDUCE_FUSED = saved, saved_r
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
