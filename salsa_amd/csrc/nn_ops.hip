@@ -25,6 +25,32 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
+// Round-5 probes: the 16-byte vector loads / stores of the streaming passes (BatchNorm, pooling) as non-temporal accesses
+// (-DNN_NT_LD=1 / -DNN_NT_ST=1).  Every tensor these passes touch is read or written exactly once per launch.
+#ifndef NN_NT_LD
+#define NN_NT_LD 0
+#endif
+#ifndef NN_NT_ST
+#define NN_NT_ST 0
+#endif
+typedef unsigned nn_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nn_ld16(const void *p)
+{
+    if (NN_NT_LD) {
+        const nn_u4v t = __builtin_nontemporal_load((const nn_u4v *)p);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+    return *(const uint4 *)p;
+}
+__device__ __forceinline__ void nn_st16(void *p, const uint4 v)
+{
+    if (NN_NT_ST) {
+        const nn_u4v t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, (nn_u4v *)p);
+    } else
+        *(uint4 *)p = v;
+}
+
 template <typename V, int L> struct vec_io;
 template <> struct vec_io<f32x4, 4> {
     typedef float4 raw_t;
@@ -39,7 +65,7 @@ template <> struct vec_io<f32x4, 4> {
 };
 template <> struct vec_io<bf16x8, 8> {
     typedef uint4 raw_t;
-    static __device__ __forceinline__ raw_t load_raw(const void *p) { return *(const uint4 *)p; }
+    static __device__ __forceinline__ raw_t load_raw(const void *p) { return nn_ld16(p); }
     static __device__ __forceinline__ void convert(const raw_t &t, float *f)
     {
         const unsigned w[4] = {t.x, t.y, t.z, t.w};
@@ -55,7 +81,7 @@ template <> struct vec_io<bf16x8, 8> {
         unsigned w[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) w[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
-        *(uint4 *)p = make_uint4(w[0], w[1], w[2], w[3]);
+        nn_st16(p, make_uint4(w[0], w[1], w[2], w[3]));
     }
 };
 

@@ -120,6 +120,29 @@ __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * _
 // below 4 GiB.
 template <typename V> __device__ __forceinline__ void st_off(V *base, unsigned byte_off, const V v) { *(V *)((char *)base + byte_off) = v; }
 template <typename V> __device__ __forceinline__ V ld_off(const V *base, unsigned byte_off) { return *(const V *)((const char *)base + byte_off); }
+// Round-5 probe (-DK1_SPILL_NT=1): the spill's 16-byte stores as non-temporal stores ALONE (whole 1-KB wave stores that nothing
+// re-reads before they leave the L2), the 4-byte spectrogram rows -- which the write-back L2 merges into lines -- as plain stores.
+#ifndef K1_SPILL_NT
+#define K1_SPILL_NT 1
+#endif
+typedef float salsa_f4v __attribute__((ext_vector_type(4)));
+#ifndef TR_NT_LD
+#define TR_NT_LD 0 // probe: the tracker's read-once 8-byte loads of channel 0 as non-temporal loads
+#endif
+#ifndef K3_GATHER_NT
+#define K3_GATHER_NT 0 // probe: the covariance kernel's 16-byte gathers as non-temporal loads (they ARE re-read: the +-3-frame halo)
+#endif
+typedef float salsa_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld_off_nt(const float4 *base, unsigned byte_off)
+{
+    const salsa_f4v x = __builtin_nontemporal_load((const salsa_f4v *)((const char *)base + byte_off));
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const float4 v)
+{
+    salsa_f4v x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, (salsa_f4v *)((char *)base + byte_off));
+}
 
 // frames per wave.  Full SALSA: 4 (8 reuses more overlap per wave but leaves a 29 %-full last round of workgroups: measured
 // 2 % slower).  SALSA-Lite, whose items are frame-major and heavier (phase rows instead of the spill): 8 (4 measured 4 % slower)
@@ -301,7 +324,11 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
             const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
-                    st_off(xs, 16u * (unsigned)((t * npairs + pr) * kp.nd + (k - kp.lower)), make_float4(xa.x, xa.y, xb.x, xb.y));
+                {
+                    const unsigned so = 16u * (unsigned)((t * npairs + pr) * kp.nd + (k - kp.lower));
+                    if (K1_SPILL_NT) st_off_nt(xs, so, make_float4(xa.x, xa.y, xb.x, xb.y));
+                    else st_off(xs, so, make_float4(xa.x, xa.y, xb.x, xb.y));
+                }
                 if (k >= kp.spec_lo && k < kp.spec_hi) {
                     const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + (k - kp.spec_lo));
                     st_off(o, off, spec(pa, c0, k - kp.spec_lo));
@@ -392,7 +419,11 @@ __device__ __forceinline__ void tracker_load(const KParams &kp, const float4 *__
         int t = c0 + first + i - 2;
         if (t >= Tn) t = Tn - 1;
         while (t < 0) t += Tn;
-        x[i] = active ? *(const float2 *)&x0[t * stride] : make_float2(0.f, 0.f); // channel 0 = .xy of pair 0
+        if (TR_NT_LD) {
+            const salsa_f2v v = active ? __builtin_nontemporal_load((const salsa_f2v *)&x0[t * stride]) : salsa_f2v{0.f, 0.f};
+            x[i] = make_float2(v.x, v.y);
+        } else
+            x[i] = active ? *(const float2 *)&x0[t * stride] : make_float2(0.f, 0.f); // channel 0 = .xy of pair 0
     }
 }
 
@@ -713,6 +744,9 @@ constexpr int K3_OW = K3_NT + 8; // columns of the LDS output tile: a block's bi
 #ifndef K3_STAGE_LDS
 #define K3_STAGE_LDS 0
 #endif
+#ifndef K3_OUT_NT
+#define K3_OUT_NT 1
+#endif
 #ifndef K3_PK_WAVES
 #define K3_PK_WAVES 4 // waves per SIMD the register allocation is held to (4: 128 VGPRs, 3: 168)
 #endif
@@ -917,8 +951,8 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
                     (void)ro; (void)boff;
 #else
                     const unsigned r = ro[k];
-                    xa[k] = ld_off(xclip, r + boff);
-                    xc[k] = ld_off(xclip, r + boff + half);
+                    xa[k] = K3_GATHER_NT ? ld_off_nt(xclip, r + boff) : ld_off(xclip, r + boff);
+                    xc[k] = K3_GATHER_NT ? ld_off_nt(xclip, r + boff + half) : ld_off(xclip, r + boff + half);
 #endif
                 }
             }
@@ -1053,7 +1087,10 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
             const int q = seg >> 2;
             for (int i = tid; i < 3 * nft * q; i += K3_NT) {
                 const int row = i / q, col = i - row * q, c = row / nft, ft = row - c * nft;
-                *(float4 *)(of + ((long)(c * Tn + t0 + ft) * kp.F + bin0 + 4 * col)) = *(const float4 *)(otile + (c * K3_FT + ft) * K3_OW + 4 * col);
+                float4 *dst = (float4 *)(of + ((long)(c * Tn + t0 + ft) * kp.F + bin0 + 4 * col));
+                const float4 val = *(const float4 *)(otile + (c * K3_FT + ft) * K3_OW + 4 * col);
+                if (K3_OUT_NT) st_off_nt(dst, 0u, val); // (round-5 probe, -DK3_OUT_NT=1: rows written once, never re-read by this kernel)
+                else *dst = val;
             }
         } else {
             for (int i = tid; i < 3 * nft * seg; i += K3_NT) {
