@@ -24,6 +24,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CONV_WIDE_STORE
 #define CONV_WIDE_STORE 1 // 16-byte epilogue stores through v_permlane32_swap (0: the 8-byte stores of rounds 1-2)
 #endif
+#ifndef STEM_OUT_NT
+#define STEM_OUT_NT 0
+#endif
+#ifndef CONV64_OUT_NT
+#define CONV64_OUT_NT 0 // round-5 probe: the plain epilogue's 16-byte output stores as non-temporal stores (written once; the input's halo rows are what the L2 should keep)
+#endif
 constexpr int CH = 64;            // channels in = out
 constexpr int ROW = 72;           // padded channel stride in LDS (bf16 elements): 144 bytes
 #ifndef CONV_RPW
@@ -171,7 +177,14 @@ __device__ __forceinline__ void conv64_epilogue(const f32x16 (&acc)[RPW], unsign
 #ifdef CONV_NO_STORE // probe: everything computed, nothing written
             if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
 #endif
-            if (inside) *(uint4 *)(o + 8 * g) = v;
+            if (inside) {
+#if CONV64_OUT_NT
+                typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u4v_t{v.x, v.y, v.z, v.w}, (u4v_t *)(o + 8 * g));
+#else
+                *(uint4 *)(o + 8 * g) = v;
+#endif
+            }
         }
 #else
         if (inside) {
@@ -1215,7 +1228,14 @@ __global__ __launch_bounds__(256, STEM_FWD_WPS) void conv3x3_stem_fwd_kernel(con
             const int p = it * 8 + (lane >> 3), piece = lane & 7;
             const uint4 v = *(const uint4 *)(strip + p * ROW + piece * 8);
             const int wcol = tw * TW + p;
-            if ((h < H) & (wcol < W) STEM_STORE_COND) *(uint4 *)(yb + (unsigned)((h * W + wcol) * CH + piece * 8)) = v;
+            if ((h < H) & (wcol < W) STEM_STORE_COND) {
+#if STEM_OUT_NT // round-5 probe: the first layer's output stores non-temporal
+                typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u4v_t{v.x, v.y, v.z, v.w}, (u4v_t *)(yb + (unsigned)((h * W + wcol) * CH + piece * 8)));
+#else
+                *(uint4 *)(yb + (unsigned)((h * W + wcol) * CH + piece * 8)) = v;
+#endif
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next row overwrites the strip
     }

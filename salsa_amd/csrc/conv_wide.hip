@@ -24,6 +24,9 @@
 #include <utility>
 #include "nn_det.h"
 
+#ifndef WIDE_OUT_NT
+#define WIDE_OUT_NT 0
+#endif
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -363,7 +366,14 @@ __global__ __launch_bounds__(64 * WV) void conv3x3_wide_kernel(const unsigned sh
             for (int g = 0; g < 4; g += 2) { // swap(A, B): lanes 32-63 of A <-> lanes 0-31 of B
                 const auto sx = __builtin_amdgcn_permlane32_swap(pk[g].x, pk[g + 1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(pk[g].y, pk[g + 1].y, false, false);
-                if (inside) *(uint4 *)(o + ct * 32 + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                if (inside) {
+#if WIDE_OUT_NT // round-5 probe: the output's 16-byte stores non-temporal
+                    typedef unsigned u4v_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(u4v_t{sx[0], sy[0], sx[1], sy[1]}, (u4v_t *)(o + ct * 32 + 8 * g));
+#else
+                    *(uint4 *)(o + ct * 32 + 8 * g) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+#endif
+                }
             }
 #else
 #pragma unroll

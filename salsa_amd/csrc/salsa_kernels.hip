@@ -112,6 +112,15 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // (Non-temporal stores for the spectrogram rows / spill were measured SLOWER -- 0.54 vs 0.49 ms: the write-back L2 merges the
 // 4-byte row stores into full lines, which nt stores forgo -- so plain stores are used throughout.)
+// |x|^2 of a complex64 spectrum value in float32, as ONE explicitly written FMA of an explicitly rounded product.  Written
+// `x.x * x.x + x.y * x.y` the compiler is free to contract it either way round (or not at all), and did so differently in two
+// unrolled instances of the STFT kernel once the code around it changed (session 3: the spectrogram of bins 128 - 191 moved by one
+// ulp against the fused kernel's, which the bit-identity test of the two schedules caught).
+__device__ __forceinline__ float power32(const float2 x)
+{
+    const float t = x.x * x.x;
+    return __builtin_fmaf(x.y, x.y, t);
+}
 __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
 // Addressing: a wave-uniform base pointer (SGPR pair) + a 32-bit unsigned BYTE offset per lane lets the compiler use the
@@ -146,6 +155,11 @@ __device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const
 
 // frames per wave.  Full SALSA: 4 (8 reuses more overlap per wave but leaves a 29 %-full last round of workgroups: measured
 // 2 % slower).  SALSA-Lite, whose items are frame-major and heavier (phase rows instead of the spill): 8 (4 measured 4 % slower)
+// K1_INTERLEAVE (round-5 probe): the four waves of a workgroup take frames base + w, base + w + 4, ... instead of four consecutive
+// frames each, so the 212 samples per channel two consecutive frames share are requested by sibling waves at about the same time.
+#ifndef K1_INTERLEAVE
+#define K1_INTERLEAVE 0
+#endif
 template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : 4;
 };
@@ -166,10 +180,11 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bx = blockIdx.x;
     const int Ns = kp.N, Tn = kp.T;
     constexpr int K1_NF = NF;
-    const int t_begin = (blockIdx.x * 4 + w) * K1_NF;
+    constexpr int K1_TSTEP = K1_INTERLEAVE ? 4 : 1;
+    const int t_begin = K1_INTERLEAVE ? bx * 4 * K1_NF + w : (bx * 4 + w) * K1_NF;
     cplx<T> *z = buf[w];
 
     // Register diet (occupancy): only the first twiddle of each pass stays in registers, its powers are rebuilt by a
@@ -217,7 +232,8 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
 #else
     constexpr bool PAIR_MAJOR = !LITE;
 #endif
-    const int nfr_ = Tn - t_begin < K1_NF ? Tn - t_begin : K1_NF;
+    const int nleft_ = (Tn - t_begin + K1_TSTEP - 1) / K1_TSTEP; // frames t_begin, t_begin + K1_TSTEP, ... below Tn
+    const int nfr_ = nleft_ < K1_NF ? nleft_ : K1_NF;
     const int psel = LITE ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
     auto item_frame = [&](int item) {
         if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / npairs;
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
         return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1;
     };
     auto load_item = [&](int item, float *y0, float *y1) {
-        const int t = t_begin + item_frame(item);
+        const int t = t_begin + K1_TSTEP * item_frame(item);
         const int c0 = 2 * item_pair(item);
         const int base = t * kp.hop - N / 2;
         const unsigned ch0 = 4u * (unsigned)(planar ? c0 * Ns : c0), ch1 = ch0 + 4u * (unsigned)(planar ? Ns : 1); // byte offsets
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
 
     for (int item = 0; item < nitems; item++) {
-        const int t = t_begin + item_frame(item);
+        const int t = t_begin + K1_TSTEP * item_frame(item);
         const int pr = item_pair(item);
         load_item(item, y0, y1);
         cplx<T> v[R];
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
             salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
             const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
             const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
-            const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+            const float pa = power32(xa), pb = power32(xb);
             if (!LITE) {
                 if (kp.feature == SALSA_FEATURE_SALSA && k >= kp.lower && k < kp.upper)
                 {
@@ -1290,7 +1306,7 @@ __global__ __launch_bounds__(FZ_NT, 1) void fused_kernel(const KParams kp, const
                 const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
                 if (k >= kp.lower && k < kp.upper) slot[pr * nd + (k - kp.lower)] = make_float4(xa.x, xa.y, xb.x, xb.y);
                 if (own) {
-                    const float pa = xa.x * xa.x + xa.y * xa.y, pb = xb.x * xb.x + xb.y * xb.y;
+                    const float pa = power32(xa), pb = power32(xb);
                     if (k >= kp.spec_lo && k < kp.spec_hi) {
                         const unsigned off = 4u * (unsigned)((c0 * Tn + t) * F + (k - kp.spec_lo));
                         st_off(o, off, spec(pa, c0, k - kp.spec_lo));
