@@ -160,8 +160,11 @@ __device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const
 #ifndef K1_INTERLEAVE
 #define K1_INTERLEAVE 0
 #endif
+#ifndef K1_NF_FULL
+#define K1_NF_FULL 4
+#endif
 template <bool LITE> struct k1_cfg {
-    static constexpr int NF = LITE ? 8 : 4;
+    static constexpr int NF = LITE ? 8 : K1_NF_FULL;
 };
 
 // SC (round 4): the instantiation launched when a scaler is attached keeps the [4][F] mean / std tables in LDS.  It is a separate
