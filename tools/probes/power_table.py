@@ -50,4 +50,10 @@ for cin, H, W in ((128, 160, 50), (256, 80, 25), (512, 40, 12)):
     run('wide forward %d -> %d, 32 x %d x %d' % (cin, cin, H, W), lambda: nn_ops._conv_wide(xw, ww), lambda us: '%.0f TFLOP/s' % (2.0 * 32 * H * W * cin * cin * 9 / us / 1e6))
 ys = np.stack([synth_clip(2021 + i) for i in range(32)]); au = torch.from_numpy(ys).to(dev); ex = SalsaExtractor()
 run('feature path (three kernels), 32 x 60 s', lambda: ex.extract(au), lambda us: '%.2f TB/s algorithmic, 4.34 GB real' % (1597619200 / us / 1e6))
+with ex.issue_prefix(1):
+    run('STFT kernel alone (prefix issue)', lambda: ex.extract(au), lambda us: '%.2f TB/s real (2.34 GB)' % (2.34e9 / us / 1e6))
+with ex.issue_prefix(2):
+    run('STFT + tracker (prefix issue)', lambda: ex.extract(au), lambda us: '')
+ex.set_fused(1)
+run('fused schedule (STFT, tracker, fused STFT + cov/eig)', lambda: ex.extract(au), lambda us: '')
 stop.set(); th.join()
