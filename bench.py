@@ -245,6 +245,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    power = None
+    if rank == 0:                                       # package power / shader clock over the timed regions (bench_crnn.PowerSampler)
+        from bench_crnn import PowerSampler
+        power = PowerSampler()
+        import atexit
+        atexit.register(power.close)
     for _ in range(args.warmup):
         ex.extract(audio, out=out)
     block_s = []
@@ -294,12 +300,27 @@ def main():
             return float(np.median(ts))
 
         prefix, prefix_note = {}, None
+        power_k1 = power_step = None
+
+        def power_loop(fn, seconds=2.0):
+            """the hwmon power figure is a moving average with a time constant of several hundred ms: the timed blocks (0.1 s) are over
+            before it has risen.  So, OUTSIDE every timed region, the same launches run for ~2 s more and the last 60 % of that is read."""
+            if power is None:
+                return None
+            t_start = time.time()
+            while time.time() - t_start < seconds:
+                for _ in range(args.steps):
+                    fn()
+                torch.cuda.synchronize()
+            return power.stats(t_start + 0.4 * seconds, time.time())
         if args.feature == 'salsa':
             with ex.issue_prefix(1):                           # (restores plain issue on exit, exceptions included)
                 p1 = wall_ms(args.steps)
+                power_k1 = power_loop(lambda: ex.extract(audio, out=out))
             with ex.issue_prefix(2):
                 p2 = wall_ms(args.steps)
             p3 = wall_ms(args.steps)                           # the whole path, timed the same way as its prefixes
+            power_step = power_loop(lambda: ex.extract(audio, out=out))
             prefix = {'stft_logspec': p1, 'noise_floor_tracker': p2 - p1, 'cov_eig': p3 - p2}
             scale = (1e3 * elapsed / args.steps) / p3          # ... then scaled so the three add up to the headline step
             prefix = {k: v * scale for k, v in prefix.items()}
@@ -385,6 +406,10 @@ def main():
                                  'frac': dom['frac'], 'traffic': dom.get('traffic')},
                     'secondary_bound': {'unit': 'fraction of SIMD cycles issuing a VALU instruction (float64 in the STFT and the tracker: peak %.1f TFLOP/s; packed float32 in cov_eig since round 4)' % F64_VALU_PEAK_TFLOPS,
                                         'per_kernel': {k['name']: k['f64_valu_util'] for k in kernels}},
+                    # what the package drew over the timed blocks, and while the dominant kernel ran ALONE (the [STFT]-only prefix
+                    # issues above): at the power cap with the shader clock below its 2.4 GHz, energy -- not overlap -- is the bound
+                    'power': {'whole_step': power_step,
+                              'stft_logspec_alone': power_k1},
                     'kernels': kernels}
         if args.streams > 1:
             # independent batches on separate streams: the latency-bound tracker of one step hides under the STFT /
@@ -533,12 +558,12 @@ def main():
 
     crnn = config4 = infer = None
     if not args.no_crnn and args.feature == 'salsa':
-        crnn = leg('crnn', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup))
+        crnn = leg('crnn', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup, power=power))
         # ---- BASELINE config 4: raw 8-s MIC chunks -> SALSA-MIC on device -> the reference's augmentation -> training step
         if not args.no_config4:
             torch.cuda.empty_cache()
             config4 = leg('config4', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup,
-                                                         on_the_fly=True, augment=True))
+                                                         on_the_fly=True, augment=True, power=power))
         # ---- BASELINE config 5 (reported, not part of the metric): 32 x 60-s clips per GPU per step through SALSA + CRNN forward
         if not args.no_infer:
             def _infer():
@@ -546,7 +571,7 @@ def main():
                 from salsa_amd.crnn.train import Trainer
                 torch.cuda.empty_cache()
                 return infer_bench(SimpleNamespace(clips=32, sub_batch=32, steps=args.infer_steps, warmup=3), rank, world, dev,
-                                   Trainer(dev, ddp=False), audio=infer_audio)
+                                   Trainer(dev, ddp=False), audio=infer_audio, power=power)
             infer = leg('inference', _infer)
 
     if world > 1:

@@ -39,7 +39,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0           # dense bf16 MFMA peak, MI355X_MICROARC
 GFLOP_PER_CHUNK_FWD = 44.74 + 0.19       # conv + GRU forward per 8-s chunk (probed)
 
 
-def infer_bench(args, rank, world, dev, tr, audio=None):
+def infer_bench(args, rank, world, dev, tr, audio=None, power=None):
     """Batched inference (config 5): per step, `clips` 60-s FOA clips per GPU go raw audio -> SALSA features (HIP) ->
     normalise-on-load (fused into the extraction) -> CRNN forward (bf16) -> SED probabilities + xyz at label rate, all on device.  Clips are
     sharded over ranks, no collective.  `audio`: this rank's [clips][4][N] device tensor (bench.py hands over its seeded
@@ -89,6 +89,14 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    pw = None
+    if power is not None and world == 1:   # outside the timed region (the hwmon power figure is a slow moving average): ~2 s more, last 60 % read
+        tw0 = time.time()
+        while time.time() - tw0 < 2.0:
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+        pw = power.stats(tw0 + 0.8, time.time())
     for _ in range(args.steps):
         step(timed=True)
     if world > 1:
@@ -107,6 +115,7 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
         'p50_latency_ms_per_clip': round(p50, 2),
         'p90_latency_ms_per_clip': round(1e3 * lat[min(len(lat) - 1, (9 * len(lat)) // 10)], 2),
         'latency_samples': len(lat),
+        'power': pw,
         'latency_note': 'a clip is answered when its %d-clip sub-batch is: per-clip latency = sub-batch wall time (amortised: %.3f ms per clip)' % (sub, p50 / sub),
         'config': {'workload': 'batched inference: %d x 60-s 4-ch clips per GPU per step, SALSA-FOA + CRNN forward, '
                                'sub-batches of %d' % (args.clips, sub), 'parallelism': 'clips sharded over %d GPUs' % world}})
@@ -115,8 +124,78 @@ def infer_bench(args, rank, world, dev, tr, audio=None):
 N_ROT = 4          # distinct device-resident batches rotating through the timed training loops
 
 
+class PowerSampler:
+    """Package power and shader clock of the GPU while a timed region runs (round 5: the STFT kernel and the 64 -> 64 convolutions hold
+    the package AT its 1400-W cap with the clock throttled, profiles/r5_power_probe.txt -- so the bench line carries what the part drew).
+    A helper PROCESS polls the amdgpu hwmon files (power1_input in microwatts, freq1_input = sclk in Hz) of every card it can see at
+    ~200 Hz into a temporary file; stats(t0, t1) picks the card that drew the most in [t0, t1] (time.time() stamps).  Measurement
+    garnish only: any failure makes it report None, never an exception."""
+    _SRC = ("import glob,os,sys,time\n"
+            "ds=[d for d in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')) if os.path.exists(d+'/power1_input')]\n"
+            "fs=[(open(d+'/power1_input'),open(d+'/freq1_input') if os.path.exists(d+'/freq1_input') else None) for d in ds]\n"
+            "caps=[open(d+'/power1_cap').read().strip() if os.path.exists(d+'/power1_cap') else '0' for d in ds]\n"
+            "o=open(sys.argv[1],'w'); o.write('# '+' '.join(caps)+'\\n')\n"
+            "def rd(f):\n"
+            "    f.seek(0); return f.read().strip() or '0'\n"
+            "pp=os.getppid()\n"
+            "while os.getppid()==pp:\n"
+            "    t=time.time(); o.write('%.6f %s\\n'%(t,' '.join(rd(p)+' '+(rd(q) if q else '0') for p,q in fs))); o.flush()\n"
+            "    time.sleep(max(0.0,0.005-(time.time()-t)))\n")
+
+    def __init__(self):
+        self.proc, self.path = None, None
+        try:
+            import glob
+            import subprocess
+            import tempfile
+            if not glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_input'):
+                return
+            fd, self.path = tempfile.mkstemp(prefix='salsa_power_', suffix='.txt')
+            os.close(fd)
+            self.proc = subprocess.Popen([sys.executable, '-c', self._SRC, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def stats(self, t0, t1):
+        if self.proc is None:
+            return None
+        try:
+            import numpy as np
+            caps, rows = None, []
+            for ln in open(self.path):
+                if ln.startswith('#'):
+                    caps = [float(x) / 1e6 for x in ln[1:].split()]
+                    continue
+                v = ln.split()
+                if len(v) >= 3 and t0 <= float(v[0]) <= t1:
+                    rows.append([float(x) for x in v[1:]])
+            if len(rows) < 3:
+                return None
+            a = np.asarray(rows)
+            pw, ck = a[:, 0::2] / 1e6, a[:, 1::2] / 1e6
+            c = int(np.argmax(pw.mean(axis=0)))
+            return {'cap_w': caps[c] if caps and c < len(caps) else None, 'mean_w': round(float(pw[:, c].mean()), 1),
+                    'max_w': round(float(pw[:, c].max()), 1), 'sclk_mhz_mean': round(float(ck[:, c].mean()), 0),
+                    'sclk_mhz_min': round(float(ck[:, c].min()), 0), 'samples': int(len(rows)),
+                    'source': 'amdgpu hwmon power1_input / freq1_input of the busiest card, polled at ~200 Hz by a helper process over ~1.2 s of the same launches run right after the timed region (the figure is a slow moving average)'}
+        except Exception:
+            return None
+
+    def close(self):
+        try:
+            if self.proc is not None:
+                self.proc.kill()
+                self.proc.wait(timeout=5)
+            if self.path:
+                os.unlink(self.path)
+        except Exception:
+            pass
+        self.proc = None
+
+
+
 def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False, augment=False, fp32_grads=False,
-                n_frames=640, amp_dtype='default', force_ddp=False):
+                n_frames=640, amp_dtype='default', force_ddp=False, power=None):
     """CRNN training throughput (BASELINE.json config 3; config 4 with on_the_fly): forward + loss + backward + Adam on
     `batch` 8-s chunks per GPU per step, bf16 autocast; for world > 1 a bucketed gradient all-reduce on RCCL (grad_sync.py; SALSA_GRAD_SYNC=ddp: torch DDP)
     overlapped with the backward.  The process group must already be initialised for world > 1.  Every rank calls this;
@@ -177,6 +256,14 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    pw = None
+    if power is not None and world == 1:   # OUTSIDE the timed region: the hwmon power figure is a slow moving average, so ~2 s more of
+        tw0 = time.time()                  # the same steps run and the last 60 % of that is read (bench.py power_loop, same reason)
+        while time.time() - tw0 < 2.0:
+            for _ in range(10):
+                step()
+            sync()
+        pw = power.stats(tw0 + 0.8, time.time())
     ranks = 1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -199,6 +286,7 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
                    'parallelism': 'dp%d' % world, 'grad_allreduce': 'fp32' if fp32_grads else 'bf16'},
         'roofline': {'bound': 'mfma', 'achieved': round(tflops / world, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tflops / world / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                     'power': pw,
                      'note': 'per GPU; 134.8 GFLOP per chunk (3x the 44.93 GFLOP forward); convolutions: %s' % nn_ops.conv_backend_note()},
         'final_loss': float(loss)}
 
