@@ -248,7 +248,7 @@ def main():
     power = None
     if rank == 0:                                       # package power / shader clock over the timed regions (bench_crnn.PowerSampler)
         from bench_crnn import PowerSampler
-        power = PowerSampler()
+        power = PowerSampler(dev)
         import atexit
         atexit.register(power.close)
     for _ in range(args.warmup):

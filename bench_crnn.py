@@ -128,10 +128,12 @@ class PowerSampler:
     """Package power and shader clock of the GPU while a timed region runs (round 5: the STFT kernel and the 64 -> 64 convolutions hold
     the package AT its 1400-W cap with the clock throttled, profiles/r5_power_probe.txt -- so the bench line carries what the part drew).
     A helper PROCESS polls the amdgpu hwmon files (power1_input in microwatts, freq1_input = sclk in Hz) of every card it can see at
-    ~200 Hz into a temporary file; stats(t0, t1) picks the card that drew the most in [t0, t1] (time.time() stamps).  Measurement
+    ~200 Hz into a temporary file; the card is this process's GPU, matched by PCI address (every card and the busiest one as a fallback); stats(t0, t1) takes time.time() stamps.  Measurement
     garnish only: any failure makes it report None, never an exception."""
     _SRC = ("import glob,os,sys,time\n"
             "ds=[d for d in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')) if os.path.exists(d+'/power1_input')]\n"
+            "own=[d for d in ds if len(sys.argv)>2 and sys.argv[2] and sys.argv[2] in os.path.realpath(d)]\n"
+            "ds=own or ds\n"
             "fs=[(open(d+'/power1_input'),open(d+'/freq1_input') if os.path.exists(d+'/freq1_input') else None) for d in ds]\n"
             "caps=[open(d+'/power1_cap').read().strip() if os.path.exists(d+'/power1_cap') else '0' for d in ds]\n"
             "o=open(sys.argv[1],'w'); o.write('# '+' '.join(caps)+'\\n')\n"
@@ -142,9 +144,15 @@ class PowerSampler:
             "    t=time.time(); o.write('%.6f %s\\n'%(t,' '.join(rd(p)+' '+(rd(q) if q else '0') for p,q in fs))); o.flush()\n"
             "    time.sleep(max(0.0,0.005-(time.time()-t)))\n")
 
-    def __init__(self):
-        self.proc, self.path = None, None
+    def __init__(self, device=None):
+        self.proc, self.path, self.slot = None, None, ''
         try:
+            try:    # this process's GPU by its PCI address (a node shows the hwmon files of every GPU, other tenants' included)
+                import torch
+                pr = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+                self.slot = '%04x:%02x:%02x.' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            except Exception:
+                self.slot = ''
             import glob
             import subprocess
             import tempfile
@@ -152,7 +160,7 @@ class PowerSampler:
                 return
             fd, self.path = tempfile.mkstemp(prefix='salsa_power_', suffix='.txt')
             os.close(fd)
-            self.proc = subprocess.Popen([sys.executable, '-c', self._SRC, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            self.proc = subprocess.Popen([sys.executable, '-c', self._SRC, self.path, self.slot], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         except Exception:
             self.proc = None
 
@@ -177,7 +185,8 @@ class PowerSampler:
             return {'cap_w': caps[c] if caps and c < len(caps) else None, 'mean_w': round(float(pw[:, c].mean()), 1),
                     'max_w': round(float(pw[:, c].max()), 1), 'sclk_mhz_mean': round(float(ck[:, c].mean()), 0),
                     'sclk_mhz_min': round(float(ck[:, c].min()), 0), 'samples': int(len(rows)),
-                    'source': 'amdgpu hwmon power1_input / freq1_input of the busiest card, polled at ~200 Hz by a helper process over ~1.2 s of the same launches run right after the timed region (the figure is a slow moving average)'}
+                    'pci': self.slot or None, 'cards_polled': int(pw.shape[1]),
+                    'source': 'amdgpu hwmon power1_input / freq1_input of this GPU (matched by PCI address; the busiest card if that failed), polled at ~200 Hz by a helper process over ~1.2 s of the same launches run right after the timed region (the figure is a slow moving average)'}
         except Exception:
             return None
 
