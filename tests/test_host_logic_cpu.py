@@ -180,3 +180,29 @@ def test_bench_termination_hook_fires_while_the_main_thread_is_blocked(tmp_path)
     p.send_signal(signal.SIGTERM)
     out, _ = p.communicate(timeout=30)
     assert p.returncode == 3 and out.strip().splitlines()[-1] == '{"status": "partial"}'
+
+
+def test_power_sampler_degrades_to_none_without_hwmon_files(tmp_path):
+    """bench.py's power garnish (bench_crnn.PowerSampler) must never break a bench run: without the amdgpu hwmon files (this container)
+    it reports None; its helper script is valid Python and stops when its parent is gone."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench_crnn
+    ps = bench_crnn.PowerSampler()
+    try:
+        assert ps.stats(time.time() - 1.0, time.time()) is None or isinstance(ps.stats(time.time() - 1.0, time.time()), dict)
+    finally:
+        ps.close()
+    compile(bench_crnn.PowerSampler._SRC, 'power_helper', 'exec')
+    # the parser on a synthetic log: two cards, the second one busy
+    ps2 = bench_crnn.PowerSampler.__new__(bench_crnn.PowerSampler)
+    ps2.proc, ps2.slot = object(), ''
+    ps2.path = str(tmp_path / 'log.txt')
+    t0 = 1000.0
+    with open(ps2.path, 'w') as f:
+        f.write('# 1400000000 1400000000\n')
+        for i in range(10):
+            f.write('%.3f 250000000 150000000 1390000000 2000000000\n' % (t0 + 0.01 * i))
+    st = ps2.stats(t0, t0 + 1.0)
+    assert st['mean_w'] == 1390.0 and st['sclk_mhz_mean'] == 2000.0 and st['cap_w'] == 1400.0 and st['samples'] == 10
