@@ -190,7 +190,8 @@ def main():
     ap.add_argument('--no-infer', action='store_true', help='skip the batched-inference leg (BASELINE config 5)')
     ap.add_argument('--no-config4', action='store_true', help='skip the on-the-fly SALSA-MIC + augmentation training leg (BASELINE config 4)')
     ap.add_argument('--tolerate-crnn-failure', action='store_true', help='exit 0 even if a CRNN-side leg (crnn / config4 / inference) failed')
-    ap.add_argument('--infer-steps', type=int, default=20)
+    ap.add_argument('--infer-steps', type=int, default=5, help='timed steps of the inference leg; a step is the WHOLE --infer-clips job once through')
+    ap.add_argument('--infer-clips', type=int, default=1024, help='clips of the whole inference job, sharded over the GPUs (BASELINE config 5: 1024)')
     ap.add_argument('--crnn-steps', type=int, default=20)
     ap.add_argument('--crnn-warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=1, help='extra leg: K steps round-robin over this many HIP streams / plans (reported as pipelined, never `value`)')
@@ -471,10 +472,7 @@ def main():
                 pcie['harness'] = harness_bench(fmt, fmax, args.batch, n_samples, host)
 
     # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the data-parallel run)
-    infer_audio = audio if (args.feature == 'salsa' and fmt == 'foa' and args.batch == 32 and abs(args.seconds - 60) < 1e-9) else None
-    del ex, out
-    if infer_audio is None:
-        del audio
+    del ex, out, audio
     torch.cuda.empty_cache()
     failures = []
     done = {}                                    # the CRNN-side legs as they finish (what a bail-out can still report)
@@ -564,14 +562,15 @@ def main():
             torch.cuda.empty_cache()
             config4 = leg('config4', lambda: train_bench(rank, world, dev, batch=32, steps=args.crnn_steps, warmup=args.crnn_warmup,
                                                          on_the_fly=True, augment=True, power=power))
-        # ---- BASELINE config 5 (reported, not part of the metric): 32 x 60-s clips per GPU per step through SALSA + CRNN forward
+        # ---- BASELINE config 5 (reported, not part of the metric): --infer-clips (1024) distinct 60-s clips in all, sharded over
+        # the ranks, through SALSA + CRNN forward + DCASE rows, sub-batches of 32 (bench_crnn.infer_bench)
         if not args.no_infer:
             def _infer():
                 from types import SimpleNamespace
                 from salsa_amd.crnn.train import Trainer
                 torch.cuda.empty_cache()
-                return infer_bench(SimpleNamespace(clips=32, sub_batch=32, steps=args.infer_steps, warmup=3), rank, world, dev,
-                                   Trainer(dev, ddp=False), audio=infer_audio, power=power)
+                return infer_bench(SimpleNamespace(clips=args.infer_clips, sub_batch=32, steps=args.infer_steps, warmup=1), rank, world, dev,
+                                   Trainer(dev, ddp=False), power=power)
             infer = leg('inference', _infer)
 
     if world > 1:

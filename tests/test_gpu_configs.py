@@ -29,7 +29,7 @@ def dev():
 def test_config2_batch32_full_size_properties(dev, oracle):
     """BASELINE config 2 exactly as bench.py runs it: 32 x 60-s FOA clips in ONE call (939 MB of spill, 32-bit per-clip
     offsets at their largest).  Size-independent properties: determinism, the first and the last clip bit-equal to their
-    solo runs (batch invariance across the whole workspace), zero band above upper_bin, unit-norm FOA vectors, and two
+    solo runs (batch invariance across the whole workspace), zero band above upper_bin, unit-norm FOA vectors, and eight
     clips of the batch against the oracle."""
     from bench import make_batch
     B, n = 32, 60 * 24000
@@ -49,7 +49,7 @@ def test_config2_batch32_full_size_properties(dev, oracle):
     for i in (0, B - 1):
         solo = ex.extract(a[i:i + 1].contiguous())
         assert torch.equal(solo[0], out2[i]), 'clip %d depends on its batch neighbours' % i
-    for i in (13, B - 1):
+    for i in (0, 5, 9, 13, 18, 22, 27, B - 1):                           # 8 of the 32 clips against the oracle (a quarter of the headline workload)
         ref, aux = oracle.extract_salsa(ys[i], return_aux=True)
         _check(out2[i].cpu().numpy(), ref, aux['margin'])
 
@@ -260,6 +260,108 @@ def test_config5_end_to_end_inference_matches_torch_layers(dev):
         assert np.median(da) <= 5, np.median(da)
 
 
+def test_config5_one_gpu_share_128_distinct_clips_sharded(dev):
+    """BASELINE config 5 at ONE GPU's share (1024 clips / 8 GPUs = 128, sub-batches of 32) through the product's sharded engine
+    (salsa_amd.crnn.infer.infer_clips_sharded): 128 DISTINCT seeded clips resident in HBM -> features -> CRNN forward -> DCASE
+    rows on the host.  Checked: every clip answered, in the sorted-name order, distinct clips give distinct rows; three clips of
+    different sub-batches against their SOLO runs (batch invariance through the extractor, the CRNN and the pipelined engine);
+    one clip against the same weights on torch / MIOpen layers; latency stamps cover every clip exactly once."""
+    from salsa_amd.crnn import model as M, nn_ops
+    from salsa_amd.crnn.infer import infer_clips_sharded
+    from salsa_amd.crnn.testing import seeded_fill
+    from salsa_amd.crnn.train import Trainer
+    from salsa_amd.synth import synth_clips_device
+    n_clips, sub = 128, 32
+    audio = synth_clips_device(7000, n_clips, 60 * 24000, device=dev)
+    assert not torch.equal(audio[0], audio[1])
+    ex = _extractor()
+    ex.set_scaler(np.full((4, 1, 200), -60.0, np.float32), np.full((4, 1, 200), 12.0, np.float32))
+    tr = Trainer(dev, total_steps=10)
+    seeded_fill(tr.raw_model, 11)
+    names = ['clip%04d' % i for i in range(n_clips)]
+    index = {n: i for i, n in enumerate(names)}
+    seen = {}
+
+    def featurize(group):
+        idx = [index[n] for n in group]
+        assert idx == list(range(idx[0], idx[0] + len(idx)))               # contiguous ranges of the sorted list
+        return ex.extract(audio[idx[0]:idx[0] + len(idx)])[:, :, :4800]
+
+    def forward(x):
+        p, d = tr.infer(x)
+        seen[len(seen)] = (p.clone(), d.clone())
+        return p, d
+
+    p0, _ = tr.infer(featurize(names[:sub]))
+    thr = float(torch.quantile(p0.flatten().float()[:1 << 20], 0.9).item())
+    seen.clear()
+    stamps = []
+    rows = infer_clips_sharded(names[::-1], featurize, forward, rank=0, world=1, sub_batch=sub, sed_threshold=thr, stamps=stamps)
+    assert sorted(rows) == names and len(seen) == n_clips // sub
+    assert sorted((a, b) for a, b, _, _ in stamps) == [(i, i + sub) for i in range(0, n_clips, sub)]
+    assert all(t1 > t0 for _, _, t0, t1 in stamps)
+    assert all(len(r) > 50 for r in rows.values())
+    assert rows[names[0]] != rows[names[1]] and rows[names[40]] != rows[names[100]]
+    # the second rank's share of a 2-rank job is the second half of the sorted list, with the same answers
+    half = infer_clips_sharded(names, featurize, tr.infer, rank=1, world=2, sub_batch=sub, sed_threshold=thr, gather=False)
+    assert sorted(half) == names[64:] and all(half[n] == rows[n] for n in half)
+    # batch invariance: clips 3, 45 and 127 alone
+    for i in (3, 45, 127):
+        p_b, d_b = seen[i // sub][0][i % sub], seen[i // sub][1][i % sub]
+        p_s, d_s = tr.infer(ex.extract(audio[i:i + 1])[:, :, :4800])
+        assert float((p_s[0] - p_b).abs().max()) <= 2e-2 and float((d_s[0] - d_b).abs().max()) <= 4e-2, i
+        solo = infer_clips_sharded([names[i]], lambda g: ex.extract(audio[i:i + 1])[:, :, :4800], tr.infer, sub_batch=sub,
+                                   sed_threshold=thr)[names[i]]
+        sure = (p_b - thr).abs().cpu().numpy() > 2e-2
+        assert {(r[0], r[1]) for r in solo if sure[r[0], r[1]]} == {(r[0], r[1]) for r in rows[names[i]] if sure[r[0], r[1]]}
+    # one clip against torch / MIOpen layers (every hand-written CRNN kernel off)
+    x = ex.extract(audio[77:78])[:, :, :4800].contiguous()
+    try:
+        nn_ops.USE_HIP_POOL = nn_ops.USE_HIP_BN = nn_ops.USE_HIP_CONV = False
+        M.FUSED_GRU = False
+        p_off, d_off = tr.infer(x)
+    finally:
+        nn_ops.USE_HIP_POOL = nn_ops.USE_HIP_BN = nn_ops.USE_HIP_CONV = True
+        M.FUSED_GRU = True
+    p_on, d_on = seen[77 // sub][0][77 % sub], seen[77 // sub][1][77 % sub]
+    assert float((p_off[0] - p_on).abs().max()) <= 3e-2 and float((d_off[0] - d_on).abs().max()) <= 6e-2
+
+
+def test_bench_eight_ranks_on_one_gpu_with_the_drivers_command():
+    """The driver's scaling run, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 8 --steps K --warmup W`, dry-run on the ONE GPU of this box (SALSA_BENCH_SHARE_GPU=1: gloo process group, the
+    eight ranks share cuda:0; the timing means nothing, the control flow is the real one): eight ranks in every leg, world read back
+    from the process group, the 1024-clip inference job sharded 128 per rank, ONE JSON line, last on stdout, and the CPU-baseline
+    leg (rank 0, after the process group is gone) inside the cores this container may use."""
+    import json
+    import subprocess
+    from oracle.cpu_bench import effective_cpus
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SALSA_BENCH_SHARE_GPU='1', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
+           '--blocks', '2', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    json_lines = [ln for ln in out_lines if ln.startswith('{')]
+    assert len(json_lines) == 1 and out_lines[-1] == json_lines[0]          # ONE line, from rank 0 only, last
+    line = json.loads(json_lines[0])
+    assert line['n_gpus'] == 8 and line['rccl_ranks'] == 8 and line['value'] > 0 and line['scaling'] == 'weak'
+    assert len(line['blocks_ms']) == 2 and line['config']['sharding'].startswith('clips/8')
+    for leg in ('crnn', 'config4'):
+        assert line[leg]['n_gpus'] == 8 and line[leg]['rccl_ranks'] == 8 and line[leg]['value'] > 0, leg
+        assert line[leg]['config']['parallelism'] == 'dp8'
+    inf = line['inference']
+    assert inf['n_gpus'] == 8 and inf['config']['clips'] == 1024 and inf['config']['clips_per_gpu'] == 128
+    assert inf['latency_samples'] == 1024 and inf['value'] > 0              # every rank's clips stamped exactly once per step
+    assert inf['p50_latency_ms_per_clip'] <= inf['p50_latency_from_arrival_ms'] <= inf['max_latency_from_arrival_ms']
+    cpu = line['cpu_baseline']
+    assert cpu is not None and cpu['value'] > 0 and 1 <= cpu['cores'] <= effective_cpus()['effective_cores']
+    assert all(c['cores'] <= effective_cpus()['effective_cores'] for c in cpu.get('configs', []))
+    assert 'status' not in line
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -363,7 +465,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['SALSA_BENCH_SHARE_GPU'] = '1'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '2', '--no-cpu-baseline'],
+                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '2', '--infer-clips', '128', '--no-cpu-baseline'],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
@@ -371,7 +473,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['value'] > 0
     for leg in ('crnn', 'config4'):
         assert line[leg]['n_gpus'] == 2 and line[leg]['rccl_ranks'] == 2 and line[leg]['value'] > 0, leg
-    assert line['inference']['value'] > 0
+    assert line['inference']['value'] > 0 and line['inference']['config']['clips_per_gpu'] == 64
+    assert line['inference']['latency_samples'] == 2 * 128
 
 
 def _sharded_harness_worker(rank, world, port, cfg):
@@ -428,7 +531,7 @@ def test_bench_n2_failure_in_a_crnn_leg_still_prints_the_feature_half():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(SALSA_BENCH_SHARE_GPU='1', SALSA_BENCH_FAIL_LEG='config4', SALSA_BENCH_LEG_TIMEOUT='45')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
-                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '2', '--no-cpu-baseline'],
+                        '--blocks', '1', '--crnn-steps', '2', '--crnn-warmup', '1', '--infer-steps', '1', '--infer-clips', '64', '--no-cpu-baseline'],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode != 0
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
