@@ -77,6 +77,8 @@ struct KParams {
     const float *sc_std;
     unsigned long long *stats; // optional solver counters (salsa_plan_set_stats), or NULL
     int force_f64;             // SALSA_FLAG_FORCE_F64: the float64 instantiation of the covariance / eigen kernel
+    unsigned *doubt32;         // [B][32-bin group][T] bit mask of the TF bins whose coherence test the quartic could not decide
+                               // (salsa_math.h SALSA_GATE_DOUBT; decided by gate_doubt_kernel after the launch), or NULL (ungated plans)
 };
 
 constexpr int FEATURE_LOGSPEC_ONLY = 3;
@@ -812,6 +814,10 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
     const int bin0 = blockIdx.z * K3_NT;
     const int nbc = kp.nd - bin0 < K3_NT ? kp.nd - bin0 : K3_NT; // bins of this tile
     if (tid == 0) count = 0, nslow = 0;
+    if (kp.doubt32 && tid < K3_FT * (K3_NT / 32)) { // this tile's words of the doubt mask (no other workgroup touches them): zero before any atomicOr below
+        const int ft = tid % K3_FT, g32 = bin0 / 32 + tid / K3_FT, n32 = (kp.nd + TR_BINS - 1) / TR_BINS;
+        if (ft < nft && g32 < n32) kp.doubt32[((long)b * n32 + g32) * Tn + t0 + ft] = 0u;
+    }
     if (NHOP >= 0 && tid < K3_FT + 2 * NHOP) {
         int tt = t0 - NHOP + tid;
         while (tt < 0) tt += Tn;
@@ -918,6 +924,8 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
             slow[atomicAdd(&nslow, 1)] = (unsigned short)(((t - t0) << 8) | (bin - bin0));
             return;
         }
+        if (er.doubt && kp.doubt32 && !ungated) // the threshold sits ON a root of the quartic: what is emitted below is provisional,
+            atomicOr(&kp.doubt32[((long)b * ((kp.nd + TR_BINS - 1) / TR_BINS) + (bin >> 5)) * Tn + t], 1u << (bin & 31)); // gate_doubt_kernel decides
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || ungated) {
@@ -1120,6 +1128,69 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
     }
 }
 
+// The TF bins cov_eig_kernel flagged in kp.doubt32 -- the threshold mu1 / cond numerically ON a root of the characteristic quartic, which
+// then cannot decide "s0 > s1 * cond" (:106): multiple eigenvalues at the threshold lose float64 to sqrt / cube-root precision -- decided
+// on the matrix: float64 covariance from the spill, eigenvalues by Jacobi rotations (salsa_math.h herm4_rank1_by_jacobi, the oracle's
+// method), eigenvector by the general adjugate path, and the bin's three values rewritten.  On natural signals the mask is empty:
+// the launch reads B * ceil(nd / 32) * T words (3.7 MB for 32 x 60-s clips) and exits.  Round 6.
+template <bool FEAT>
+__global__ __launch_bounds__(256) void gate_doubt_kernel(const KParams kp, const float4 *__restrict__ Xs, float *__restrict__ out_feat,
+                                                         double *__restrict__ out_eig, unsigned char *__restrict__ gate)
+{
+    const int Tn = kp.T, n32 = (kp.nd + TR_BINS - 1) / TR_BINS, stride = 2 * kp.nd;
+    const long nwords = (long)kp.B * n32 * Tn;
+    const bool foa = kp.format == SALSA_FORMAT_FOA;
+    for (long wi = (long)blockIdx.x * blockDim.x + threadIdx.x; wi < nwords; wi += (long)gridDim.x * blockDim.x) {
+        unsigned word = kp.doubt32[wi];
+        if (!word) continue;
+        const int t = (int)(wi % Tn), g32 = (int)((wi / Tn) % n32), b = (int)(wi / ((long)Tn * n32));
+        while (word) {
+            const int j = __ffs((int)word) - 1;
+            word &= word - 1u;
+            const int bin = 32 * g32 + j;
+            const float4 *xb = Xs + (long)b * Tn * stride + bin;
+            salsa::herm4<double> R = {};
+            for (int k = -kp.n_hop; k <= kp.n_hop; k++) { // the cold loop's covariance, term for term
+                int tt = t + k;
+                while (tt < 0) tt += Tn;
+                while (tt >= Tn) tt -= Tn;
+                const float4 a = xb[tt * stride], c = xb[tt * stride + kp.nd];
+                const cplx<double> x[4] = {{(double)a.x, (double)a.y}, {(double)a.z, (double)a.w},
+                                           {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
+                salsa::herm4_rank1_add(R, x);
+            }
+            const bool rank1 = salsa::herm4_rank1_by_jacobi(R, kp.cond);
+            double e[3] = {0.0, 0.0, 0.0};
+            if (rank1) {
+                const salsa::eig_result<double> er = salsa::herm4_gate_eigvec<2>(R, kp.cond, kp.inv_cond, true, !foa);
+                const int k = bin + kp.lower;
+                const double den = kp.flex ? (double)((float)(k == 0 ? 1 : k) * (float)kp.delta) : kp.delta * (double)k;
+                if (foa) salsa::normalise_foa(er.u, e, false);
+                else salsa::normalise_mic(er.u, den, e);
+            } else if (FEAT && kp.flex && !kp.tracking) {
+                e[0] = __builtin_nan(""); // "failed the test" for flex_allpass_kernel, as cov_eig_kernel marks it
+            }
+            if (FEAT) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) out_feat[(((long)b * kp.OC + 4 + i) * Tn + t) * kp.F + bin] = (float)e[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; i++) out_eig[(((long)b * 3 + i) * kp.nd + bin) * Tn + t] = e[i];
+                if (gate) gate[((long)b * kp.nd + bin) * Tn + t] = rank1 ? 2 : 1;
+            }
+        }
+    }
+}
+
+template <bool FEAT>
+static void launch_gate_doubt(const KParams &kp, hipStream_t s, const float4 *Xs, float *out_feat, double *out_eig, unsigned char *gate)
+{
+    if (!kp.doubt32) return;
+    const long nwords = (long)kp.B * ((kp.nd + TR_BINS - 1) / TR_BINS) * kp.T;
+    const unsigned blocks = (unsigned)(nwords < 256L * 1024 ? (nwords + 255) / 256 : 1024);
+    hipLaunchKernelGGL(gate_doubt_kernel<FEAT>, dim3(blocks ? blocks : 1u), dim3(256), 0, s, kp, Xs, out_feat, out_eig, gate);
+}
+
 template <bool FEAT>
 static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const float4 *Xs, const unsigned *valid,
                            float *out_feat, double *out_eig, unsigned char *gate)
@@ -1134,6 +1205,7 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
     else
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, -1>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
+    launch_gate_doubt<FEAT>(kp, s, Xs, out_feat, out_eig, gate); // (a no-op unless kp.doubt32: gated plans)
 }
 
 // ------------------------------------------------------------------------------------------------------------ fused K1 + K3
@@ -1359,7 +1431,13 @@ __global__ __launch_bounds__(FZ_NT, 1) void fused_kernel(const KParams kp, const
                                        {(double)c.x, (double)c.y}, {(double)c.z, (double)c.w}};
             salsa::herm4_rank1_add(Rm, x);
         }
-        const salsa::eig_result<double> er = salsa::herm4_gate_eigvec<2>(Rm, kp.cond, kp.inv_cond, false, MIC);
+        salsa::eig_result<double> er = salsa::herm4_gate_eigvec<2>(Rm, kp.cond, kp.inv_cond, false, MIC);
+        if (er.doubt) { // the threshold sits ON a root of the quartic (salsa_math.h SALSA_GATE_DOUBT): decided on the matrix, in place --
+                        // the three-kernel path's gate_doubt_kernel reads the spill, which this kernel's records have overwritten
+            const bool r1 = salsa::herm4_rank1_by_jacobi(Rm, kp.cond);
+            if (r1) er = salsa::herm4_gate_eigvec<2>(Rm, kp.cond, kp.inv_cond, true, MIC);
+            er.rank1 = r1;
+        }
         if (!er.rank1) return false;
         if (MIC) salsa::normalise_mic(er.u, kp.delta * (double)(bl + kp.lower), e);
         else salsa::normalise_foa(er.u, e, false);
@@ -2143,18 +2221,21 @@ int salsa_output_shape(const salsa_plan *pl, int64_t n_samples, int *C, int64_t 
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// one [B][32-bin group][T] uint32 bit mask (the tracker's gate masks; the doubt mask of the coherence test), rounded up to whole
+// 64-frame chunks and 64-bin groups
+static size_t mask_bytes(int batch, size_t T, int nd) { return align256((size_t)batch * ((T + 63) / 64) * ((nd + 63) / 64) * 64 * 8); }
 
 size_t salsa_workspace_bytes(const salsa_plan *pl, int batch, int64_t n_samples)
 {
     if (!pl || batch <= 0 || n_samples <= 0 || pl->p.feature_type != SALSA_FEATURE_SALSA) return 0;
     const size_t T = 1 + n_samples / pl->p.hop_len;
-    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + align256((size_t)batch * ((T + 63) / 64) * ((pl->nd + 63) / 64) * 64 * 8) + 256;
+    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + 2 * mask_bytes(batch, T, pl->nd) + 256; // spill, gate masks, doubt mask
 }
 
 size_t salsa_eigvec_workspace_bytes(const salsa_plan *pl, int batch, int n_bins, int64_t n_frames)
 {
     if (!pl || batch <= 0 || n_bins <= 0 || n_frames <= 0) return 0;
-    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + align256((size_t)batch * ((n_frames + 63) / 64) * ((n_bins + 63) / 64) * 64 * 8) + 256;
+    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + 2 * mask_bytes(batch, (size_t)n_frames, n_bins) + 256;
 }
 
 static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
@@ -2266,6 +2347,8 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
         Xs = (float4 *)d_workspace;
         valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
+        if ((kp.tracking || kp.flex) && kp.cond > 1.0 && kp.nd > 0)
+            kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)kp.T, kp.nd));
     }
     pl->n_kernels = 0;
     const long T = kp.T;
@@ -2280,6 +2363,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         float *o = d_out + (size_t)g0 * 7 * T * kp.F;
         float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
         unsigned *vm = valid ? valid + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T : nullptr; // [b][32-bin group][t]
+        if (kp.doubt32) gp.doubt32 = kp.doubt32 + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T;
         const bool two = split && full && gp.nd > 0;
         gp.pair_sel = two ? 0 : -1;
         // timing mode with a repeat count (salsa_plan_set_timing(plan, K > 1)): every kernel is launched K times back to
@@ -2501,6 +2585,7 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     kp.feature = SALSA_FEATURE_SALSA;
     float4 *Xs = (float4 *)d_workspace;
     unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
+    if ((kp.tracking || kp.flex) && kp.cond > 1.0) kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
     const long total = (long)batch * n_bins * n_frames * 2;
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
@@ -2536,6 +2621,7 @@ int salsa_eigvec_feature_batch(salsa_plan *pl, const float *d_X, int batch, int 
     kp.feature = SALSA_FEATURE_SALSA;
     float4 *Xs = (float4 *)d_workspace;
     unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
+    if ((kp.tracking || kp.flex) && kp.cond > 1.0) kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
     const long total = (long)batch * n_bins * n_frames * 2;
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());

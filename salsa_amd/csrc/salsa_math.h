@@ -271,6 +271,78 @@ template <typename T> SALSA_HD void herm4_adj_diag(const herm4<T> &A, const mino
     dg[3] = re_mul(cconj(a02), m.s3) - re_mul(cconj(a12), m.s1) + A.d[2] * m.s0;         //  a20 s3 - a21 s1 + a22 s0
 }
 
+// The coherence test decided ON THE MATRIX (round 6): eigenvalues of a Hermitian 4x4 by cyclic complex Jacobi rotations (what the CPU
+// oracle uses for np.linalg.svd, accurate to ~1e-16 ||A|| whatever the eigenvalue multiplicities) -> s0 > s1 * cond
+// (salsa_feature_extraction.py:106).  The quartic's Taylor coefficients cannot decide the test when the threshold mu1 / cond sits on a
+// MULTIPLE root: with mu2 ~ mu3 (~ mu4) the value q(c) is a product of two (three) small factors, so float64 resolves mu1 / mu2
+// against cond only to ~sqrt(eps) (eps^(1/3)) -- found by tests/test_gpu_pk_stress.py's `degenerate_tail` family, where the float64
+// gate flipped against the oracle at margins of 7e-6.  Used when |q(c)| < SALSA_GATE_DOUBT, i.e. when c is numerically ON a root:
+// never on natural signals (|mu1 / cond - mu2| < ~3e-11 for a simple mu2).  On the device herm4_gate_eigvec only FLAGS such a bin
+// (eig_result::doubt; inlining ~600 instructions of rotations took the production kernel from 128 to 150 VGPRs + scratch): the
+// kernels record it in a bit mask and gate_doubt_kernel (salsa_kernels.hip) decides it here after the launch.  On the host
+// (tests/hostemu) the call is made in place.
+#ifndef SALSA_GATE_DOUBT
+#define SALSA_GATE_DOUBT 1e-12   // on the trace-1..2 scale; q(c) is evaluated to ~1e-14 there (64 operations on terms <= 1.5)
+#endif
+SALSA_HD bool herm4_rank1_by_jacobi(const herm4<double> &A, double cond)
+{
+    double ar[4][4], ai[4][4];
+    {
+        int k = 0;
+        for (int i = 0; i < 4; i++) {
+            ar[i][i] = A.d[i];
+            ai[i][i] = 0.0;
+            for (int j = i + 1; j < 4; j++, k++) {
+                ar[i][j] = A.o[k].re; ai[i][j] = A.o[k].im;
+                ar[j][i] = A.o[k].re; ai[j][i] = -A.o[k].im;
+            }
+        }
+    }
+    const double tr = ar[0][0] + ar[1][1] + ar[2][2] + ar[3][3];
+    for (int sweep = 0; sweep < 12; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < 4; p++)
+            for (int q = p + 1; q < 4; q++) off += ar[p][q] * ar[p][q] + ai[p][q] * ai[p][q];
+        if (off <= 1e-34 * tr * tr) break;
+        for (int p = 0; p < 4; p++)
+            for (int q = p + 1; q < 4; q++) {
+                const double xr = ar[p][q], xi = ai[p][q];
+                const double r2 = xr * xr + xi * xi;
+                if (r2 == 0.0) continue;
+                const double r = sqrt(r2);
+                // a_pq = r e^{i phi}; U = D G with D_qq = e^{-i phi} (makes the pivot real) and G the real rotation that zeroes it
+                const double er = xr / r, ei = xi / r;
+                const double tau = (ar[q][q] - ar[p][p]) / (2.0 * r);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+                const double uqp_r = -sn * er, uqp_i = sn * ei, uqq_r = c * er, uqq_i = -c * ei;
+                for (int i = 0; i < 4; i++) { // A <- A U (columns p, q)
+                    const double pr = ar[i][p], pi = ai[i][p], qr = ar[i][q], qi = ai[i][q];
+                    ar[i][p] = pr * c + (qr * uqp_r - qi * uqp_i);
+                    ai[i][p] = pi * c + (qr * uqp_i + qi * uqp_r);
+                    ar[i][q] = pr * sn + (qr * uqq_r - qi * uqq_i);
+                    ai[i][q] = pi * sn + (qr * uqq_i + qi * uqq_r);
+                }
+                for (int j = 0; j < 4; j++) { // A <- U^H A (rows p, q)
+                    const double pr = ar[p][j], pi = ai[p][j], qr = ar[q][j], qi = ai[q][j];
+                    ar[p][j] = c * pr + (uqp_r * qr + uqp_i * qi);
+                    ai[p][j] = c * pi + (uqp_r * qi - uqp_i * qr);
+                    ar[q][j] = sn * pr + (uqq_r * qr + uqq_i * qi);
+                    ai[q][j] = sn * pi + (uqq_r * qi - uqq_i * qr);
+                }
+                ar[p][q] = ai[p][q] = ar[q][p] = ai[q][p] = 0.0;
+                ai[p][p] = ai[q][q] = 0.0;
+            }
+    }
+    int i1 = 0;
+    double l1 = ar[0][0];
+    for (int i = 1; i < 4; i++)
+        if (ar[i][i] > l1) { l1 = ar[i][i]; i1 = i; }
+    double l2 = -1e300;
+    for (int i = 0; i < 4; i++)
+        if (i != i1 && ar[i][i] > l2) l2 = ar[i][i];
+    return l1 > l2 * cond;
+}
 // Result of the per-TF-bin solve.
 template <typename T> struct eig_result {
     bool rank1;      // coherence test s0 > s1*cond (salsa_feature_extraction.py:106)
@@ -278,6 +350,7 @@ template <typename T> struct eig_result {
     cplx<T> u[4];    // principal eigenvector (arbitrary scale and phase); valid when computed
     bool col0;       // u is column 0 of adj(A - mu1 I): u[0] is REAL (its imaginary part is exactly 0)
     bool fallback;   // PATH 1 only: the bin passed the gate but its column-0 pivot is too small -- solve it again with PATH 2
+    bool doubt;      // device only: |q(mu1/cond)| < SALSA_GATE_DOUBT, rank1 is provisional -- herm4_rank1_by_jacobi decides (gate_doubt_kernel)
 };
 
 // Gate + principal eigenvector of a Hermitian PSD 4x4 R (any positive scale).
@@ -317,6 +390,7 @@ SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, 
     res.rank1 = false;
     res.col0 = false;
     res.fallback = false;
+    res.doubt = false;
     res.margin = 0;
     res.u[0] = {(T)1, (T)0};
     res.u[1] = res.u[2] = res.u[3] = {(T)0, (T)0};
@@ -378,6 +452,16 @@ SALSA_HD eig_result<T> herm4_gate_eigvec(const herm4<T> &R, T cond, T inv_cond, 
         if (t0 != (T)0) { var += ((t0 < 0) != (prev < 0)); prev = t0; }
         res.rank1 = (var == 1);
         res.margin = t0;
+        if (sizeof(T) == 8 && fabs(t0) < (T)SALSA_GATE_DOUBT) { // c numerically ON a root of q: the quartic cannot tell
+#if defined(__HIP_DEVICE_COMPILE__)
+            res.doubt = true;
+#else
+            herm4<double> Ad;
+            for (int i = 0; i < 4; i++) Ad.d[i] = (double)A.d[i];
+            for (int k = 0; k < 6; k++) Ad.o[k] = {(double)A.o[k].re, (double)A.o[k].im};
+            res.rank1 = herm4_rank1_by_jacobi(Ad, (double)cond);
+#endif
+        }
     }
     if (!res.rank1 && !need_vector_always) return res;
     // B = A - mu1 I ; adj(B) column with the largest |diagonal cofactor|.  Only the diagonal changes, so B's 2x2 minors

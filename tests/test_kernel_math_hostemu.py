@@ -192,6 +192,37 @@ def test_solver_stress_controlled_spectra(emu):
 
 
 
+def test_gate_with_multiple_eigenvalues_at_the_threshold_is_decided_on_the_matrix(emu):
+    """Round 6 (found by tests/test_gpu_pk_stress.py, family `degenerate_tail`): with mu2 ~ mu3 (~ mu4) AT mu1 / cond the quartic's
+    value there is a product of two (three) tiny factors, so its sign resolves mu1 / mu2 against cond only to sqrt(eps) (eps^(1/3)):
+    the float64 gate flipped against LAPACK at margins of 7e-6.  |q(mu1 / cond)| < SALSA_GATE_DOUBT now hands the decision to Jacobi
+    rotations on the matrix (salsa_math.h herm4_rank1_by_jacobi): the gate follows np.linalg.eigvalsh down to margins of 1e-12."""
+    emu.hostemu_solve.argtypes = [C.POINTER(C.c_double)] * 2 + [C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    rng = np.random.RandomState(5)
+    checked = flips_possible = 0
+    for cond in (5.0, 2.0):
+        for m in (3e-5, 1e-6, 1e-7, 1e-8, 1e-9, 1e-10, 1e-11):
+            for sign in (-1.0, 1.0):
+                for jit in (0.0, 1e-7, 1e-9, 1e-12):
+                    for scale in (1.0, 1e-8, 1e+4):
+                        l2 = (1.0 / cond) * (1.0 + sign * m)
+                        lam = np.array([1.0, l2, l2 * (1.0 - jit * rng.rand()), l2 * (1.0 - jit * rng.rand())]) * scale
+                        Q, _ = np.linalg.qr(rng.randn(4, 4) + 1j * rng.randn(4, 4))
+                        R = (Q * lam) @ Q.conj().T
+                        R = (R + R.conj().T) / 2
+                        w = np.linalg.eigvalsh(R)[::-1]
+                        margin = (w[0] - cond * w[1]) / w[0]
+                        if abs(margin) < 2e-13:                           # inside LAPACK's own resolution
+                            continue
+                        d, o = _pack(R)
+                        rank1, u = C.c_int(), np.zeros(8)
+                        emu.hostemu_solve(_dp(d), _dp(o), cond, 0, C.byref(rank1), _dp(u))
+                        assert bool(rank1.value) == (margin > 0), (cond, m, sign, jit, scale, margin)
+                        checked += 1
+                        flips_possible += abs(margin) < 1e-5
+    assert checked > 300 and flips_possible > 200
+
+
 def _feature(emu, R, cond=5.0, gated=True, fmt='foa', dk=0.86, f32=False):
     emu.hostemu_feature.argtypes = ([C.POINTER(C.c_double)] * 2 + [C.c_double, C.c_int, C.c_int, C.c_double, C.c_int] +
                                     [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_double)])
