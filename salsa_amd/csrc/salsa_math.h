@@ -721,8 +721,10 @@ SALSA_HD herm4<pk2f> herm4_pk_from_windows(const cov4pk &R0, const cov4pk &R1, i
 
 // Gate + column-0 eigenvector of two Hermitian PSD matrices whose traces were scaled into [1, 2).  `live`: bit j = frame j is
 // wanted (the other lane may hold anything, NaN included: it is carried along and ignored).  cond > 1.
+// `study` (host error study only, tools/pk_coeff_study.py; NULL in every kernel): receives the four Taylor coefficients t0..t3 of q at
+// c = mu1 / cond, mu1, the last Newton step and c, as this float32 code computed them (the prefilter is bypassed so that every frame reports).
 template <bool WANT_IMAG>
-SALSA_HD pk_eig herm4_gate_eigvec_pk(const herm4<pk2f> &A, float cond, float inv_cond, int live)
+SALSA_HD pk_eig herm4_gate_eigvec_pk(const herm4<pk2f> &A, float cond, float inv_cond, int live, pk2f *study = nullptr)
 {
     pk_eig res;
     res.pass = 0;
@@ -744,7 +746,7 @@ SALSA_HD pk_eig herm4_gate_eigvec_pk(const herm4<pk2f> &A, float cond, float inv
 #pragma unroll
     for (int j = 0; j < 2; j++)
         if (!(p2[j] >= need[j])) act &= ~(1 << j);
-    if (!act) return res;
+    if (!act && !study) return res;
     const minors4<pk2f> m = herm4_minors(A);
     pk2f dg[4];
     herm4_adj_diag(A, m, dg);
@@ -777,6 +779,7 @@ SALSA_HD pk_eig herm4_gate_eigvec_pk(const herm4<pk2f> &A, float cond, float inv
     const pk2f t1 = ((4.f * c + k3) * c + k2) * c + a1;
     const pk2f t2 = (6.f * c + k3) * c + a2;
     const pk2f t3 = 4.f * c + a3;
+    if (study) study[0] = t0, study[1] = t1, study[2] = t2, study[3] = t3, study[4] = mu1, study[5] = last, study[6] = c;
     int pass = 0, unsure = 0;
 #pragma unroll
     for (int j = 0; j < 2; j++) {

@@ -231,3 +231,74 @@ int hostemu_pk_pairs(const float *X, long n, double cond, int format, double dk,
     return 0;
 }
 }
+
+extern "C" {
+// Round 6, the error budget of the packed solve's gate certificate: for every frame of every pair item
+// (layout as hostemu_pk_pairs): t32 [2n][7] = the Taylor coefficients t0..t3 of the characteristic quartic at c = mu1 / cond, mu1, the
+// last Newton step and c as the float32 pair code computes them from its float32 covariance; t64 [2n][7] = t0..t3 of the EXACT
+// covariance's quartic (long double) evaluated at that same float32 c, the exact mu1 (Newton in long double), 0, c.  So
+// |t32[k] - t64[k]|, k < 4, is the coefficient + evaluation error alone (what SALSA_PK_GATE_TOL must cover, whether or not Newton had
+// converged), and |t32[4] - t64[4]| the error of mu1 (meaningful where the kernel's convergence test |last| <= 4e-6 mu1 holds).
+int hostemu_pk_coeffs(const float *X, long n, double cond, double *t32, double *t64)
+{
+    typedef long double L;
+    for (long i = 0; i < n; i++) {
+        const float *x = X + i * 8 * 4 * 2;
+        auto fr = [&](int k, pk2f *v) { for (int c = 0; c < 4; c++) v[c] = pk2f{x[(k * 4 + c) * 2], x[(k * 4 + c) * 2 + 1]}; };
+        cov4pk Cc = {}, C0, C1;
+        pk2f v[4];
+        for (int k = 1; k <= 6; k++) { fr(k, v); cov4pk_rank1(Cc, Cc, v); }
+        fr(0, v); cov4pk_rank1(C0, Cc, v);
+        fr(7, v); cov4pk_rank1(C1, Cc, v);
+        int odd = 0;
+        const herm4<pk2f> A = herm4_pk_from_windows(C0, C1, odd);
+        pk2f st[7];
+        for (int q = 0; q < 7; q++) st[q] = pk_splat(0.f);
+        (void)herm4_gate_eigvec_pk<false>(A, (float)cond, (float)(1.0 / cond), 3 & ~odd, st);
+        for (int j = 0; j < 2; j++) {
+            herm4<L> R = {};
+            for (int k = j; k < j + 7; k++) {
+                cplx<L> w[4];
+                for (int c = 0; c < 4; c++) w[c] = {(L)x[(k * 4 + c) * 2], (L)x[(k * 4 + c) * 2 + 1]};
+                herm4_rank1_add(R, w);
+            }
+            const double tr = (double)(R.d[0] + R.d[1] + R.d[2] + R.d[3]);
+            double *o32 = t32 + (2 * i + j) * 7, *o64 = t64 + (2 * i + j) * 7;
+            for (int q = 0; q < 7; q++) o32[q] = (double)st[q][j], o64[q] = 0.0;
+            if (!(tr > 0.0) || ((odd >> j) & 1)) { for (int q = 0; q < 7; q++) o32[q] = o64[q] = NAN; continue; }
+            // the power of two the float32 code scaled ITS trace by (a trace within rounding of a power of two may land on either side)
+            const double tr32 = (double)A.d[0][j] + (double)A.d[1][j] + (double)A.d[2][j] + (double)A.d[3][j];
+            const L sc = (L)exp2(rint(log2(tr32 / tr)));
+            for (int c = 0; c < 4; c++) R.d[c] *= sc;
+            for (int k = 0; k < 6; k++) { R.o[k].re *= sc; R.o[k].im *= sc; }
+            L nrm = 0;
+            for (int k = 0; k < 6; k++) nrm += R.o[k].re * R.o[k].re + R.o[k].im * R.o[k].im;
+            const L e1 = R.d[0] + R.d[1] + R.d[2] + R.d[3];
+            const L e2 = R.d[0] * R.d[1] + R.d[0] * R.d[2] + R.d[0] * R.d[3] + R.d[1] * R.d[2] + R.d[1] * R.d[3] + R.d[2] * R.d[3] - nrm;
+            const minors4<L> m = herm4_minors(R);
+            L dg[4];
+            herm4_adj_diag(R, m, dg);
+            const L e3 = dg[0] + dg[1] + dg[2] + dg[3];
+            const L e4 = m.s0 * m.c5 - re_mul(m.s1, m.c4) + re_mul(m.s2, m.c3) + re_mul(m.s3, m.c2) - re_mul(m.s4, m.c1) + re_mul(m.s5, m.c0);
+            const L a3 = -e1, a2 = e2, a1 = -e3, a0 = e4;
+            L xr = e1; // Newton from the trace (>= mu1), monotone descent
+            for (int it = 0; it < 400; it++) {
+                const L q = (((xr + a3) * xr + a2) * xr + a1) * xr + a0;
+                const L dq = ((4 * xr + 3 * a3) * xr + 2 * a2) * xr + a1;
+                if (!(dq > 0)) break;
+                const L stp = q / dq;
+                if (!(stp > 0)) break;
+                xr -= stp;
+            }
+            const L c = (L)st[6][j];
+            o64[0] = (double)((((c + a3) * c + a2) * c + a1) * c + a0);
+            o64[1] = (double)(((4 * c + 3 * a3) * c + 2 * a2) * c + a1);
+            o64[2] = (double)((6 * c + 3 * a3) * c + a2);
+            o64[3] = (double)(4 * c + a3);
+            o64[4] = (double)xr;
+            o64[6] = (double)c;
+        }
+    }
+    return 0;
+}
+}
