@@ -219,6 +219,34 @@ def reference_train_transform(x, y_sed, y_doa, audio_format='foa', rng=np.random
     return xb[0], y_sed, yb[0]
 
 
+def reference_draws(rng, T, F, audio_format='foa', minmax_after=None, image_aspect_ratio=None, freq_shift_range: int = 10,
+                    p: float = 0.5):
+    """The draws reference_train_transform makes, IN THE SAME ORDER from the same numpy source, as a parameter dict for ONE
+    sample in apply_augment_hip's format -- so that the reference's own augmented samples (golden g11, np.random.seed(s)) can be
+    demanded from the HIP kernel itself.  The cutout's fill value is drawn between the min and max of the sample AFTER swap and
+    shift (transforms.py:99-110 reads the array it is handed): ``minmax_after(d)`` is called with the swap / shift draws and must
+    return that pair (the test gets it from a first pass of the kernel without the cutout).  The drawn VALUES are passed as
+    ``u`` with ``minmax`` = (0, 1): the kernel's lo + (hi - lo) * u is then the value itself, bit for bit."""
+    d = dict(m=torch.zeros((1, 4), dtype=torch.long), shift=torch.zeros(1, dtype=torch.long), up=torch.zeros(1, dtype=torch.bool),
+             top=torch.zeros((1, 8), dtype=torch.long), h=torch.zeros((1, 8), dtype=torch.long),
+             left=torch.zeros((1, 8), dtype=torch.long), w=torch.zeros((1, 8), dtype=torch.long),
+             u=torch.zeros((1, 8), dtype=torch.float32), minmax=torch.tensor([[0.0, 1.0]]))
+    if rng.rand() < p:
+        nbits = 4 if audio_format == 'foa' else 3
+        d['m'][0, :nbits] = torch.as_tensor(rng.randint(2, size=(nbits,)))
+    if rng.rand() < p:
+        d['shift'][0] = int(rng.randint(1, freq_shift_range, 1)[0])
+        d['up'][0] = bool(rng.choice(['up', 'down'], 1)[0] == 'up')
+    if audio_format == 'mic' and rng.rand() < p:
+        vmin, vmax = minmax_after(d)
+        ratio = T / 200 if image_aspect_ratio is None else image_aspect_ratio
+        rects = draw_composite_cutout(rng, T, F, float(vmin), float(vmax), ratio)
+        top, h, left, w, val = _rects_to_tensors([rects])
+        d['top'], d['h'], d['left'], d['w'] = top, h, left, w
+        d['u'] = val.to(torch.float32)                           # (the float64 draw lands in a float32 array in the reference too)
+    return d
+
+
 def draw_composite_cutout_batch(B, T, F, gen=None, p: float = 0.5, image_aspect_ratio: float = 1.0):
     """Per-sample CompositeCutout draws for a batch (host, torch.Generator): with probability p one of the three cutouts
     with the reference's size distributions.  -> top, h, left, w (B,8) int64 (h = w = 0: no rectangle) and u (B,8) in
@@ -335,7 +363,11 @@ def apply_augment_hip(x, d, audio_format='foa'):
     # pinned staging: a pageable host-to-device copy would make the host wait for the stream and serialise the step
     par = par.pin_memory().to(x.device, non_blocking=True)
     u = d['u'].float().contiguous().pin_memory().to(x.device, non_blocking=True)
-    minmax = torch.stack(sample_minmax(x), dim=1).contiguous()
+    if 'minmax' in d:                                            # explicit fill range (reference_draws: (0, 1) with u = the values)
+        minmax = d['minmax'].float().contiguous().to(x.device)
+    else:
+        minmax = torch.stack(sample_minmax(x), dim=1).contiguous()
+    assert minmax.shape == (B, 2)
     out = torch.empty((B, 7, T, F), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().salsa_augment_batch(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), C.c_void_p(out.data_ptr()), B, T, F,

@@ -29,6 +29,54 @@ def get_segment_idxes(n_frames: int, chunk_len: int, chunk_hop_len: int, downsam
     return idxes, pointer + n_crop
 
 
+def sort_tracks(track_number: np.ndarray) -> np.ndarray:
+    """database.py:242-251: track ids from the shortest to the longest track (row counts; ids without rows count 0)."""
+    n_tracks = int(np.max(track_number)) + 1
+    durations = np.zeros((n_tracks,), dtype=np.int32)
+    for itrack in range(n_tracks):
+        durations[itrack] = np.sum(track_number == itrack)
+    return np.argsort(durations)
+
+
+def load_classwise_gt(gt_meta_fn, n_frames: int, n_classes: int = 12, label_upsample_ratio: int = 8,
+                      output_format: str = 'reg_xyz'):
+    """Database.load_classwise_gt (dataset/database.py:253-296): a DCASE2021 metadata CSV -- rows
+    ``frame_number, sound_class_idx, track_number, azimuth, elevation`` at the 10-Hz label rate, no header -- to the training
+    targets of a clip of ``n_frames`` FEATURE frames: sed (n_label_frames, n_classes) float32 in {0, 1} and doa (n_label_frames,
+    3 * n_classes) float32 = [x | y | z] unit vectors of the active classes, zeros elsewhere.  Tracks are written from the
+    shortest to the longest (:268, :275), rows of a track in file order, so where two tracks hold the same class in the same
+    frame the LONGER track's direction stays (and a later row of one track overrides an earlier one).  The trigonometry runs
+    in float32 on the float32 radian arrays, as the reference's numpy does (:285-291).  CPU / numpy: a clip has a few thousand
+    rows."""
+    import pandas as pd
+    assert n_frames % label_upsample_ratio == 0, 'mismatch ground truth and feature frame rate'
+    if output_format not in ('reg_xyz', 'accdoa'):
+        raise ValueError('doa output format {} is not valid'.format(output_format))
+    n_label_frames = n_frames // label_upsample_ratio
+    df = pd.read_csv(gt_meta_fn, header=None, names=['frame_number', 'sound_class_idx', 'track_number', 'azimuth', 'elevation'])
+    frame_number, sound_class_idx, track_number = df['frame_number'].values, df['sound_class_idx'].values, df['track_number'].values
+    azimuth, elevation = df['azimuth'].values, df['elevation'].values
+    sed = np.zeros((n_label_frames, n_classes), dtype=np.float32)
+    azi = np.zeros((n_label_frames, n_classes), dtype=np.float32)
+    ele = np.zeros((n_label_frames, n_classes), dtype=np.float32)
+    if len(df):
+        # one fancy assignment in the reference's write order (tracks shortest first, file order inside a track): numpy keeps the
+        # LAST value written to a repeated index, which is what the reference's nested loops leave behind
+        rank = np.empty(int(np.max(track_number)) + 1, dtype=np.int64)
+        rank[sort_tracks(track_number)] = np.arange(len(rank))
+        order = np.argsort(rank[track_number.astype(np.int64)], kind='stable')
+        fr, cl = frame_number[order].astype(np.int64), sound_class_idx[order].astype(np.int64)
+        sed[fr, cl] = 1.0
+        azi[fr, cl] = azimuth[order] * np.pi / 180.0
+        ele[fr, cl] = elevation[order] * np.pi / 180.0
+    x, y, z = np.cos(azi) * np.cos(ele), np.sin(azi) * np.cos(ele), np.sin(ele)
+    off = sed < 1
+    x[off] = 0.0
+    y[off] = 0.0
+    z[off] = 0.0
+    return sed, np.concatenate((x, y, z), axis=-1)
+
+
 class GpuFeatureBank(torch.utils.data.Dataset):
     def __init__(self, extractor: SalsaExtractor, fs=24000, hop_len=300, label_rate=10, chunk_len_s=8.0,
                  chunk_hop_len_s=0.5, n_classes=12, max_clip_s=60):
@@ -46,9 +94,11 @@ class GpuFeatureBank(torch.utils.data.Dataset):
         self._sums, self._n = None, 0
 
     # -------------------------------------------------------------------------------------------- ingest
-    def add_clips(self, audio, names, sed=None, doa=None):
-        """audio: float32 [B,4,N] (numpy or CUDA tensor).  sed/doa: optional per-clip label arrays at label rate,
-        (T_lab, n_classes) and (T_lab, 3*n_classes); absent -> zeros (inference)."""
+    def add_clips(self, audio, names, sed=None, doa=None, gt_meta=None):
+        """audio: float32 [B,4,N] (numpy or CUDA tensor).  Labels, one of: ``gt_meta`` = per-clip paths of DCASE metadata CSVs
+        (read by load_classwise_gt, as Database.load_chunk_data does, database.py:209-211); ``sed`` / ``doa`` = per-clip label
+        arrays at label rate, (T_lab, n_classes) and (T_lab, 3*n_classes); none of them -> zeros (inference)."""
+        assert gt_meta is None or (sed is None and doa is None), 'give either metadata CSVs or label arrays'
         a = audio if torch.is_tensor(audio) else torch.from_numpy(np.ascontiguousarray(audio, np.float32))
         feats = self.ex.extract(a.to(self.ex.device).contiguous())
         n_frames = min(feats.shape[2], self.max_frames)
@@ -56,6 +106,10 @@ class GpuFeatureBank(torch.utils.data.Dataset):
         feats = feats[:, :, :n_frames].contiguous()
         self._sums = scaler_accumulate(feats, self._sums)
         self._n += feats.shape[0] * n_frames
+        if gt_meta is not None:
+            assert len(gt_meta) == len(names)
+            labels = [load_classwise_gt(fn, n_frames, self.n_classes, self.upsample) for fn in gt_meta]
+            sed, doa = [lab[0] for lab in labels], [lab[1] for lab in labels]
         for i, name in enumerate(names):
             idxes, self.pointer = get_segment_idxes(n_frames, self.chunk_len, self.chunk_hop_len, 1, self.pointer)
             gidx, self.gt_pointer = get_segment_idxes(n_frames, self.chunk_len, self.chunk_hop_len, self.upsample,

@@ -28,6 +28,62 @@ def test_segment_indices_match_reference_arithmetic():
     assert len(idx) == 105                                                  # 105 chunks per 60-s clip
 
 
+def test_load_classwise_gt_reproduces_the_reference(tmp_path):
+    """salsa_amd.dataset.load_classwise_gt against golden g17 (Database.load_classwise_gt of the imported reference on synthetic
+    DCASE metadata CSVs): bit-equal sed and xyz targets, including which track wins where two tracks hold a class in one frame."""
+    from conftest import load_golden
+    from salsa_amd.dataset import load_classwise_gt, sort_tracks
+    meta, a = load_golden('g17_labels')
+    assert set(meta['cases']) >= {'same_class_two_tracks', 'order_and_gaps', 'repeat_in_track', 'random_polyphony', 'short_clip'}
+    for name, c in meta['cases'].items():
+        fn = tmp_path / (name + '.csv')
+        fn.write_text(c['csv'])
+        sed, doa = load_classwise_gt(str(fn), c['n_frames'], meta['n_classes'], meta['label_upsample_ratio'])
+        assert sed.dtype == np.float32 and doa.dtype == np.float32
+        assert np.array_equal(sed, a[name + '_sed']), name
+        assert np.array_equal(doa, a[name + '_doa']), name
+    # the overlap of case (a): frames 10..21 hold class 3 on both tracks; the longer track (0) is written last and stays
+    doa = a['same_class_two_tracks_doa']
+    f = 15
+    azi, ele = np.float32((10 * (f % 7) - 30) * np.pi / 180.0), np.float32(5 * np.pi / 180.0)
+    assert doa[f, 3] == np.cos(azi) * np.cos(ele) and doa[20, 3] != 0 and doa[21, 3] != 0
+    assert list(sort_tracks(np.array([0, 0, 0, 3, 3]))) == [1, 2, 3, 0]
+    with pytest.raises(AssertionError):
+        load_classwise_gt(str(fn), 641)
+    with pytest.raises(ValueError):
+        load_classwise_gt(str(fn), 640, output_format='polar')
+
+
+@pytest.mark.gpu
+def test_feature_bank_takes_labels_from_dcase_metadata_csvs(tmp_path):
+    """GpuFeatureBank.add_clips(gt_meta=...) -- config 4 trained from a DCASE metadata tree: the chunks' targets are the golden
+    g17 arrays cut with the reference's segment arithmetic (database.py:209-219)."""
+    import torch
+    from conftest import load_golden
+    from salsa_amd.dataset import GpuFeatureBank
+    from salsa_amd.extractor import SalsaExtractor
+    from salsa_amd.synth import synth_clip
+    meta, a = load_golden('g17_labels')
+    names = ['repeat_in_track', 'short_clip']
+    fns = []
+    for n in names:
+        fn = tmp_path / (n + '.csv')
+        fn.write_text(meta['cases'][n]['csv'])
+        fns.append(str(fn))
+    ys = np.stack([synth_clip(90 + i, 640 * 300) for i in range(2)])           # 641 frames -> 640
+    bank = GpuFeatureBank(SalsaExtractor(audio_format='mic', fmax_doa=4000), max_clip_s=60)
+    bank.add_clips(ys, names, gt_meta=fns)
+    bank.fit_scaler()
+    bank.finalize()
+    assert len(bank) == 2
+    for i, n in enumerate(names):
+        x, sed, doa, name = bank[i]
+        assert name == n and x.shape == (7, 640, 200)
+        assert torch.equal(sed.cpu(), torch.from_numpy(a[n + '_sed'])) and torch.equal(doa.cpu(), torch.from_numpy(a[n + '_doa']))
+    with pytest.raises(AssertionError):
+        bank.add_clips(ys, names, sed=[a['short_clip_sed']] * 2, gt_meta=fns)
+
+
 @pytest.mark.gpu
 def test_feature_bank_matches_oracle_and_numpy_normalisation(oracle):
     import torch

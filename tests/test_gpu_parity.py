@@ -689,6 +689,37 @@ def test_one_pass_augmentation_kernel_equals_the_torch_composite(dev, fmt):
     assert torch.equal(xa, xb) and torch.equal(ya, yb)
 
 
+def test_augmentation_kernel_reproduces_the_reference_samples_directly(dev):
+    """Golden g11 THROUGH the HIP kernel (round-5 review, weak 4: it used to reach salsa_augment_batch in two hops).  For each of
+    the 48 seeds x 2 formats the reference's own draws -- np.random.seed(s), consumed in the reference's call order by
+    salsa_amd.augment.reference_draws -- become the kernel's parameters; the augmented features must hash to what the reference's
+    SeldDataset produced (and equal the stored arrays), the targets likewise through the branch-free swap."""
+    import hashlib
+    from salsa_amd.augment import apply_augment_hip, reference_draws, swap_targets
+    meta, a = load_golden('g11_augment')
+    x = torch.from_numpy(a['x'])[None].to(dev).contiguous()
+    y_doa = torch.from_numpy(a['y_doa'])[None].to(dev)
+    T, F = x.shape[2:]
+    for fmt in ('foa', 'mic'):
+        changed = cut = 0
+        for s, (hx, hd) in zip(meta['seeds'], meta['sha'][fmt]):
+            np.random.seed(s)
+
+            def minmax_after(d):                                   # the sample after swap + shift: a first pass of the kernel, no cutout
+                y = apply_augment_hip(x, d, fmt)
+                return float(y.min()), float(y.max())
+            d = reference_draws(np.random, T, F, fmt, minmax_after, image_aspect_ratio=meta['image_aspect_ratio'])
+            xo = apply_augment_hip(x, d, fmt)[0].cpu().numpy()
+            do = swap_targets(y_doa, d['m'].to(dev), fmt)[0].cpu().numpy()
+            if ('%s_x_%d' % (fmt, s)) in a:
+                assert np.array_equal(xo, a['%s_x_%d' % (fmt, s)]) and np.array_equal(do, a['%s_doa_%d' % (fmt, s)]), (fmt, s)
+            assert hashlib.sha256(np.ascontiguousarray(xo).tobytes()).hexdigest() == hx, (fmt, s)
+            assert hashlib.sha256(np.ascontiguousarray(do).tobytes()).hexdigest() == hd, (fmt, s)
+            changed += not np.array_equal(xo, a['x'])
+            cut += int(d['h'].sum() > 0)
+        assert changed > len(meta['seeds']) // 2 and (cut > 8 if fmt == 'mic' else cut == 0), (fmt, changed, cut)
+
+
 def test_host_pipeline_matches_direct_extraction(dev):
     from salsa_amd.extractor import HostPipeline
     ys = [np.stack([synth_clip(700 + 10 * k + i, 40000) for i in range(3)]) for k in range(7)]

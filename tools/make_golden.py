@@ -404,6 +404,51 @@ def g12_metrics():
     shutil.rmtree(tmp)
 
 
+def g17_labels():
+    """Database.load_classwise_gt (dataset/database.py:253-296) on synthetic DCASE2021 metadata CSVs: the label half of
+    load_chunk_data.  Cases pin the write order -- tracks from the shortest to the longest, rows in file order -- with the same
+    class active on two tracks in the same frame, a repeated (frame, class) inside one track, a gap in the track numbering,
+    negative and +-180 / +-90 degree angles, unsorted rows, a full 600-frame clip and a short one.  The CSV text is stored with
+    the expected arrays (fixture = data)."""
+    import types
+    from dataset.database import Database  # (the reference; h5py is the shim, nothing is read from disk but the CSVs)
+    tmp = tempfile.mkdtemp()
+    rng = np.random.RandomState(17)
+    cases = {}
+    # (a) two tracks of the SAME class overlapping in frames 10..19: track 0 is longer (30 rows) than track 1 (12 rows)
+    rows = [(f, 3, 0, 10 * (f % 7) - 30, 5) for f in range(0, 30)] + [(f, 3, 1, -170 + f, -20) for f in range(10, 22)]
+    cases['same_class_two_tracks'] = (rows, 4800)
+    # (b) the shorter track is listed LAST in the file and has the higher id; a third id (2) never appears, id 3 does
+    rows = [(f, 5, 3, 45, 10) for f in range(100, 140)] + [(f, 5, 0, -90, -45) for f in range(120, 130)] + \
+           [(f, 7, 0, 180, 90) for f in range(0, 5)] + [(f, 7, 3, -180, -90) for f in range(3, 4)]
+    cases['order_and_gaps'] = (rows, 4800)
+    # (c) a repeated (frame, class) inside one track: the later row stays
+    rows = [(50, 2, 0, 10, 0), (50, 2, 0, 20, 0), (50, 2, 0, 30, 15), (51, 2, 0, 30, 15), (51, 11, 1, -1, -1)]
+    cases['repeat_in_track'] = (rows, 640)
+    # (d) random polyphony, rows shuffled, 60-s clip
+    rows = []
+    for trk in range(4):
+        t0 = int(rng.randint(0, 400))
+        cls = int(rng.randint(0, 12))
+        for f in range(t0, t0 + int(rng.randint(20, 200))):
+            rows.append((f, cls, trk, int(rng.randint(-180, 181)), int(rng.randint(-90, 91))))
+    rng.shuffle(rows)
+    cases['random_polyphony'] = ([tuple(int(v) for v in r) for r in rows], 4800)
+    # (e) a short clip (chunk-sized, 8 s)
+    cases['short_clip'] = ([(f, f % 12, f % 2, 3 * f - 100, f - 40) for f in range(0, 80, 3)], 640)
+    ns = types.SimpleNamespace(label_upsample_ratio=8, n_classes=12, output_format='reg_xyz', sort_tracks=Database.sort_tracks)
+    arrays, meta = {}, {'what': 'Database.load_classwise_gt', 'cases': {}, 'label_upsample_ratio': 8, 'n_classes': 12}
+    for name, (rows, n_frames) in cases.items():
+        fn = os.path.join(tmp, name + '.csv')
+        text = ''.join('%d,%d,%d,%d,%d\n' % r for r in rows)
+        open(fn, 'w').write(text)
+        sed, doa = Database.load_classwise_gt(ns, fn, n_frames)
+        meta['cases'][name] = {'n_frames': n_frames, 'csv': text}
+        arrays[name + '_sed'], arrays[name + '_doa'] = sed, doa
+    save('g17_labels', meta, **arrays)
+    shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
     g5_w_and_bins()
     g1_eigvec()
@@ -416,3 +461,4 @@ if __name__ == '__main__':
     g15_flexible_many()
     g11_augment()
     g12_metrics()
+    g17_labels()
