@@ -89,7 +89,7 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
         cfg_path = os.path.join(tmp, 'cfg.yml')
         yaml.safe_dump(cfg, open(cfg_path, 'w'))
         secs = n_clips * n_samples / 24000.0
-        res = {'clips': n_clips, 'tree': 'float32 .npy clips on %s, feature files %s' % ('tmpfs' if base else 'the temp dir', 'HDF5' if sio.HAVE_H5PY else '.npz (no h5py here)')}
+        res = {'clips': n_clips, 'tree': 'float32 .npy clips on %s, feature files %s' % ('tmpfs' if base else 'the temp dir', 'HDF5' if sio.HAVE_H5PY else 'raw .npy (no h5py here)')}
         for name, flag in (('pipelined', True), ('serial', False)):
             features.USE_FILE_PIPELINE = flag
             features.extract_features(data_config=cfg_path, task='feature', batch_size=batch)        # warm-up: plans, pinned slots
@@ -111,7 +111,7 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
             sio.save_arrays(os.path.join(tmp, 'probe_%d.h5' % i), feature=one)
         t_w = (time.perf_counter() - t0) / 8 * n_clips
         res['file_io_alone'] = {'read_s': round(t_r, 3), 'write_s_one_thread': round(t_w, 3),
-                                'note': 'np.load of every clip; save_arrays of every feature file from one thread (the pipeline writes with 8)'}
+                                'note': 'np.load of every clip; save_arrays of every feature file, both from ONE thread (the pipeline reads and writes with pools of threads)'}
         res['pcie_bound_s'] = round(n_clips / batch * (host.nbytes + one.nbytes * batch) / 55e9, 3)
         return res
     finally:
@@ -233,6 +233,8 @@ def main():
         dist.init_process_group('gloo') if share else dist.init_process_group('nccl', device_id=dev)
         rccl_ranks = dist.get_world_size()          # read back from the process group, not from the command line
 
+    from salsa_amd import _lib as _salsa_lib
+    build_flags = _salsa_lib.build_flags()
     ex = SalsaExtractor(audio_format=fmt, feature_type=args.feature, fmax_doa=fmax, device=dev)
     if args.fused:
         ex.set_fused(args.fused)
@@ -499,6 +501,7 @@ def main():
             'dtype': ('f64 (STFT, noise-floor tracker, eigen-solve cold list) + packed f32 (covariance and eigen-solve of the certified frames)'
                       if args.feature == 'salsa' else 'f64 (STFT) + f32 (log-spectrogram, phase differences)'),
             'data': 'synthetic',
+            'build_flags': build_flags or 'product build (no -D)',
             'config': {'workload': 'Full SALSA %s (eigenvector path): batch %dx%.0f-s 4-ch 24 kHz clips per GPU, '
                                    'feature-extract only, n_fft 512 hop 300 fmax_doa %d cond 5 tracking on'
                                    % (fmt.upper(), args.batch, args.seconds, fmax) if args.feature == 'salsa' else

@@ -92,6 +92,10 @@ typedef struct salsa_params {
 typedef struct salsa_plan salsa_plan;
 
 int salsa_abi_version(void);
+/* "" for the product's build (salsa_amd/_lib.py build_command(): no -D at all).  Otherwise what this library was built with: " PROBE"
+ * when -DSALSA_PROBE_BUILD admitted the timing-probe switches of salsa_amd/csrc (most of which compute wrong results on purpose), then
+ * " NAME=value" for every overridden tunable -- so that an A/B or probe library loaded in place of the product identifies itself. */
+const char *salsa_build_flags(void);
 const char *salsa_last_error(void);
 
 /* lower_bin, upper_bin (exclusive) and the lite spectrogram cutoff bin, bit-exact integer arithmetic of the reference */

@@ -50,6 +50,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     L.salsa_abi_version.restype = C.c_int
+    L.salsa_build_flags.restype = C.c_char_p
     L.salsa_last_error.restype = C.c_char_p
     L.salsa_bin_limits.argtypes = [C.c_int] * 4 + [ip, ip, ip]
     L.salsa_compress_matrix.argtypes = [C.c_int, C.c_int, fp]
@@ -144,15 +145,25 @@ def load():
     L.salsa_multichannel_workspace_bytes.restype = C.c_size_t
     L.salsa_multichannel_workspace_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
     L.salsa_extract_multichannel.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, C.c_size_t, vp]
+    flags = L.salsa_build_flags().decode()
+    if flags:                                        # an A/B or probe library (SALSA_HIP_LIB / tools/dev_build.sh with -D...): say so, loudly
+        import sys
+        sys.stderr.write('salsa_amd: %s was NOT built with the product\'s flags:%s%s\n'
+                         % (LIB_PATH, flags, ' -- a PROBE build computes wrong results on purpose' if ' PROBE' in flags else ''))
     _lib = L
     return L
+
+
+def build_flags() -> str:
+    """'' for the product's build; otherwise the probe marker / overridden tunables the loaded library reports (salsa_build_flags)."""
+    return load().salsa_build_flags().decode()
 
 
 def last_error() -> str:
     return load().salsa_last_error().decode()
 
 
-EXPORTS = ['salsa_abi_version', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
+EXPORTS = ['salsa_abi_version', 'salsa_build_flags', 'salsa_last_error', 'salsa_bin_limits', 'salsa_compress_matrix', 'salsa_plan_create',
            'salsa_plan_destroy', 'salsa_output_shape', 'salsa_workspace_bytes', 'salsa_extract_batch',
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_eigvec_feature_batch', 'salsa_plan_set_stats', 'salsa_plan_set_fused', 'salsa_plan_set_timing',
            'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_plan_set_pipeline', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',

@@ -5,6 +5,7 @@
 // these kernels are bound by the HBM traffic of their activations (98 / 49 / 15 MB per layer), not by the matrix pipe, and are
 // written for few instructions and enough waves in flight rather than for MFMA utilisation.  (MIOpen's implicit-GEMM path with
 // its cast / transpose helper kernels took 0.44 ms of a 13.4 ms training step for them.)
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "nn_det.h"

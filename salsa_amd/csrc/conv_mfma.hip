@@ -10,6 +10,7 @@
 // pixels spread over all banks), the next tile's loads in flight during the current tile's MFMAs.
 // Also here: the first layer's kernel (Cin <= 8 -> 64, reads the extractor's planar float32 output; "stem layer" below) and
 // the 64 -> 64 weight gradient (transposing LDS reads; "weight gradient" below).
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>

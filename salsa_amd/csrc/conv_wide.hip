@@ -19,6 +19,7 @@
 //     of a ds_read_b128 then touch all 64 banks exactly once (rows 4 apart would otherwise collide 4-way).
 // K loop: for each 32-channel chunk: stage X once; for each filter row r: stage the 3 taps' weights; 3 taps x 2 k16 steps
 // x 2*(TN/32) MFMAs per wave.  The data gradient is the same kernel on dy with the filter flipped and transposed.
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>

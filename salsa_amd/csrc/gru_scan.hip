@@ -5,6 +5,7 @@
 // becomes ONE launch per layer: a workgroup owns one (sample, direction) sequence, thread j owns hidden unit j, h lives
 // in LDS, and W_hh (768 KB fp32 per direction) is streamed from L2 every step with coalesced rows -- every workgroup of a
 // direction reads the same weights, so they stay L2-resident.  float32 throughout (same arithmetic as nn.GRU fp32).
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/salsa_gru.h"

@@ -1,5 +1,6 @@
 // nn_ops.hip -- gfx950 kernels for the memory-bound layers of the SELD CRNN (C ABI: include/salsa_nn.h).
 // Everything here is a streaming pass: 16-byte accesses, channels-last so that a thread's vector is contiguous.
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 

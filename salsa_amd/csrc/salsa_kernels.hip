@@ -20,6 +20,7 @@
 //
 // Arithmetic types follow the reference (see DESIGN.md "Precision"): STFT evaluated in float64 and rounded to
 // float32, log-spectrogram in float32, tracker / covariance / eigen-solve in float64.
+#include "build_guard.h" // probe switches need -DSALSA_PROBE_BUILD; SALSA_BUILD_FLAGS (generated: tools/gen_build_guard.py)
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdio.h>
@@ -112,8 +113,10 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (Non-temporal stores for the spectrogram rows / spill were measured SLOWER -- 0.54 vs 0.49 ms: the write-back L2 merges the
-// 4-byte row stores into full lines, which nt stores forgo -- so plain stores are used throughout.)
+// Store policy (round 5, profiles/r5_ab_nt_stores.txt): the 16-byte write-once streams -- K1's spill (K1_SPILL_NT) and K3's rows of
+// channels 4 - 6 (K3_OUT_NT) -- leave as NON-TEMPORAL stores (nothing re-reads them before they leave the L2, and the audio lines
+// consecutive frames share stay cached longer); the 4-byte spectrogram rows stay PLAIN stores: the write-back L2 merges them into
+// full lines, which nt stores forgo (all-nt was measured slower, 0.54 vs 0.49 ms).  The fused kernel's ring / row stores are plain.
 // |x|^2 of a complex64 spectrum value in float32, as ONE explicitly written FMA of an explicitly rounded product.  Written
 // `x.x * x.x + x.y * x.y` the compiler is free to contract it either way round (or not at all), and did so differently in two
 // unrolled instances of the STFT kernel once the code around it changed (session 3: the spectrogram of bins 128 - 191 moved by one
@@ -131,8 +134,8 @@ __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * _
 // below 4 GiB.
 template <typename V> __device__ __forceinline__ void st_off(V *base, unsigned byte_off, const V v) { *(V *)((char *)base + byte_off) = v; }
 template <typename V> __device__ __forceinline__ V ld_off(const V *base, unsigned byte_off) { return *(const V *)((const char *)base + byte_off); }
-// Round-5 probe (-DK1_SPILL_NT=1): the spill's 16-byte stores as non-temporal stores ALONE (whole 1-KB wave stores that nothing
-// re-reads before they leave the L2), the 4-byte spectrogram rows -- which the write-back L2 merges into lines -- as plain stores.
+// Production default since round 5 (0 = plain stores, for A/B): the spill's 16-byte stores as non-temporal stores ALONE (whole 1-KB
+// wave stores that nothing re-reads before they leave the L2); the 4-byte spectrogram rows stay plain (see the store policy above).
 #ifndef K1_SPILL_NT
 #define K1_SPILL_NT 1
 #endif
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
                 const int row = i / q, col = i - row * q, c = row / nft, ft = row - c * nft;
                 float4 *dst = (float4 *)(of + ((long)(c * Tn + t0 + ft) * kp.F + bin0 + 4 * col));
                 const float4 val = *(const float4 *)(otile + (c * K3_FT + ft) * K3_OW + 4 * col);
-                if (K3_OUT_NT) st_off_nt(dst, 0u, val); // (round-5 probe, -DK3_OUT_NT=1: rows written once, never re-read by this kernel)
+                if (K3_OUT_NT) st_off_nt(dst, 0u, val); // (production default since round 5: rows written once, never re-read by this kernel)
                 else *dst = val;
             }
         } else {
@@ -2045,6 +2048,7 @@ static int launch_stft_multi(salsa_plan *pl, const KParams &kp, const float *d_a
 extern "C" {
 
 int salsa_abi_version(void) { return SALSA_ABI_VERSION; }
+const char *salsa_build_flags(void) { return SALSA_BUILD_FLAGS; }
 const char *salsa_last_error(void) { return g_err; }
 
 int salsa_bin_limits(int fs, int n_fft, int fmin_doa, int fmax_doa, int *lower_bin, int *upper_bin, int *cutoff_bin)

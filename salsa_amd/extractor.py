@@ -80,6 +80,8 @@ class SalsaExtractor:
         self._prefix_mode = False
         self._scaler = None
         self._pipe = None                            # (n_groups, split_pairs, graph) once set_pipeline / set_groups was called
+        self._stats = None                           # solver counters (set_stats)
+        self._fused = 0                              # schedule of extract() (set_fused)
 
     def copy_plan_state_to(self, other: 'SalsaExtractor'):
         """Re-apply to ``other`` (built from kwargs()) the plan state attached AFTER construction: the fused scaler and the
@@ -90,6 +92,8 @@ class SalsaExtractor:
             other.set_scaler(None)
         if self._pipe is not None:
             other.set_pipeline(*self._pipe)
+        if self._fused != other._fused:              # (the clones of a file pipeline must run the caller's schedule)
+            other.set_fused(self._fused)
 
     def kwargs(self):
         """the constructor arguments of this extractor (to build further plans with the same parameters: one per pipeline slot)"""
@@ -240,6 +244,8 @@ class SalsaExtractor:
 
     def read_stats(self):
         """{'items', 'gated_frames', 'cold_frames', 'tiles'} accumulated by the covariance / eigen launches since the last read"""
+        if self._stats is None:
+            raise RuntimeError('read_stats(): no counters attached -- call set_stats(True) first')
         v = self._stats.cpu().tolist()
         self._stats.zero_()
         return dict(items=v[0], gated_frames=v[1], cold_frames=v[2], tiles=v[3])

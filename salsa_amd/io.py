@@ -3,7 +3,9 @@ feature / scaler files out (h5py 'feature', 'mean', 'std' datasets, :380-382, :2
 
 h5py is not installed in the build image or on the GPU box.  When it is importable the files are real HDF5 with the
 reference's dataset names, so the reference's Database (dataset/database.py:87-96, :193-195) reads them unchanged;
-otherwise the same arrays go to ``<name>.npz`` next to where the ``.h5`` would be (same keys), and load_* reads either.
+otherwise a clip's ``'feature'`` array goes to ``<name>.npy`` next to where the ``.h5`` would be (round 6: one header + one raw
+write of the pinned buffer -- the ``.npz`` twin of rounds 1 - 5 spent 27 of its 39 ms per clip in the zip layer's CRC-32) and
+multi-array files (the scaler's ``'mean'`` / ``'std'``) to ``<name>.npz``; load_* reads all three.
 """
 import os
 
@@ -40,49 +42,113 @@ def load_audio(path: str, sr: int) -> np.ndarray:
     return np.ascontiguousarray(x.T)
 
 
+def audio_shape(path: str, sr: int):
+    """(n_channels, n_samples) of a clip from its HEADER alone (the file pipeline groups clips by length before any sample is
+    read); the rate check of load_audio applies."""
+    if path.endswith('.npy'):
+        with open(path, 'rb') as f:
+            shape, _, _ = _npy_header(f)
+        assert len(shape) == 2, '{}: expected a (n_channels, n_samples) array'.format(path)
+        return int(shape[0]), int(shape[1])
+    from scipy.io import wavfile
+    rate, data = wavfile.read(path, mmap=True)
+    if rate != sr:
+        raise ValueError('{}: sample rate {} != configured fs {} (resampling is not supported)'.format(path, rate, sr))
+    return (1, int(data.shape[0])) if data.ndim == 1 else (int(data.shape[1]), int(data.shape[0]))
+
+
+def _npy_header(f):
+    """-> (shape, fortran_order, dtype) of an open .npy file, positioned at the data"""
+    major, _ = np.lib.format.read_magic(f)
+    return np.lib.format.read_array_header_1_0(f) if major == 1 else np.lib.format.read_array_header_2_0(f)
+
+
+def load_audio_into(path: str, sr: int, dst: np.ndarray, planar: bool = True) -> None:
+    """load_audio(path, sr) written INTO ``dst`` -- (n_channels, n_samples) float32 when ``planar``, (n_samples, n_channels) otherwise
+    -- without an intermediate array where the file already holds that layout: a float32 C-order .npy is read straight into the
+    (pinned) destination with one readinto()."""
+    if path.endswith('.npy') and planar and dst.flags.c_contiguous and dst.dtype == np.float32:
+        with open(path, 'rb') as f:
+            shape, fortran, dtype = _npy_header(f)
+            if tuple(shape) == dst.shape and not fortran and dtype == np.float32:
+                mv = memoryview(dst).cast('B')
+                got = 0
+                while got < len(mv):                    # (readinto may return short counts on some file systems)
+                    k = f.readinto(mv[got:])
+                    if not k:
+                        raise IOError('{}: truncated .npy payload'.format(path))
+                    got += k
+                return
+    a = load_audio(path, sr)
+    dst[...] = a if planar else a.T
+
+
 def _alt(path):
     return os.path.splitext(path)[0] + '.npz'
 
 
+def _alt_npy(path):
+    return os.path.splitext(path)[0] + '.npy'
+
+
+def _write_npy(path: str, a: np.ndarray) -> None:
+    """np.save(path, a) for a C-contiguous array as ONE header + ONE write of its buffer (np.save of an array that lives in
+    pinned memory goes through tobytes(): a second copy of 27 MB per clip)"""
+    a = np.ascontiguousarray(a)
+    with open(path, 'wb') as f:
+        np.lib.format.write_array_header_1_0(f, np.lib.format.header_data_from_array_1_0(a))
+        f.write(memoryview(a).cast('B'))
+
+
 def save_arrays(path_h5: str, **arrays) -> str:
-    """Write float32 datasets to ``path_h5`` (HDF5 when h5py exists, else the .npz twin).  Returns the path written."""
+    """Write float32 datasets to ``path_h5``: HDF5 when h5py exists; else a lone 'feature' array as the raw ``.npy`` twin and
+    anything else as the ``.npz`` twin.  Returns the path written."""
     if HAVE_H5PY:
         import h5py
         with h5py.File(path_h5, 'w') as hf:
             for k, v in arrays.items():
                 hf.create_dataset(k, data=v, dtype=np.float32)
         return path_h5
+    if set(arrays) == {'feature'}:
+        out = _alt_npy(path_h5)
+        _write_npy(out, np.asarray(arrays['feature'], np.float32))
+        return out
     out = _alt(path_h5)
     np.savez(out, **{k: np.asarray(v, np.float32) for k, v in arrays.items()})
     return out
 
 
 def load_arrays(path: str) -> dict:
-    """Read a feature / scaler file by the container its EXTENSION names: ``.npz`` -> numpy, ``.h5`` -> h5py; a ``.h5``
-    name whose file is absent (or unreadable without h5py) falls back to its ``.npz`` twin."""
+    """Read a feature / scaler file by the container its EXTENSION names: ``.npz`` / ``.npy`` -> numpy (a ``.npy`` file is a
+    clip's 'feature' array), ``.h5`` -> h5py; a ``.h5`` name whose file is absent (or unreadable without h5py) falls back to its
+    ``.npy`` / ``.npz`` twin."""
     if path.endswith('.npz'):
         z = np.load(path)
         return {k: z[k] for k in z.files}
+    if path.endswith('.npy'):
+        return {'feature': np.load(path)}
     if os.path.exists(path) and HAVE_H5PY:
         import h5py
         with h5py.File(path, 'r') as hf:
             return {k: hf[k][:] for k in hf.keys()}
+    if os.path.exists(_alt_npy(path)):
+        return {'feature': np.load(_alt_npy(path))}
     if os.path.exists(path) and not os.path.exists(_alt(path)):
-        raise RuntimeError('{} is HDF5 and h5py is not installed here (no .npz twin next to it)'.format(path))
+        raise RuntimeError('{} is HDF5 and h5py is not installed here (no .npy / .npz twin next to it)'.format(path))
     z = np.load(_alt(path))
     return {k: z[k] for k in z.files}
 
 
 def feature_files(feature_dir: str):
-    """Sorted feature files of a split directory, ONE name per clip: when both containers of a clip are present the
-    ``.h5`` is listed if h5py can read it, else the ``.npz``."""
+    """Sorted feature files of a split directory, ONE name per clip: when several containers of a clip are present the
+    ``.h5`` is listed if h5py can read it, else the ``.npy``, else the ``.npz``."""
+    rank = {'.h5': 0 if HAVE_H5PY else 3, '.npy': 1, '.npz': 2}
     by_stem = {}
     for f in os.listdir(feature_dir):
         stem, ext = os.path.splitext(f)
-        if ext not in ('.h5', '.npz'):
+        if ext not in rank:
             continue
         cur = by_stem.get(stem)
-        prefer_h5 = HAVE_H5PY
-        if cur is None or (ext == '.h5') == prefer_h5:
+        if cur is None or rank[ext] < rank[os.path.splitext(cur)[1]]:
             by_stem[stem] = f
     return sorted(by_stem.values())

@@ -55,3 +55,56 @@ def test_params_struct_layout_matches_header():
     # 6 ints, double (8-aligned), 7 ints, pad -> 64 bytes with natural alignment
     assert C.sizeof(_lib.SalsaParams) == 80
     assert _lib.SalsaParams.cond_num.offset == 24
+
+
+def test_probe_switches_are_quarantined_and_the_default_build_says_so(lib, tmp_path):
+    """Round-5 review, item 7: ~37 timing-probe switches (most of them wrong-result on purpose) and ~68 tunables live in the
+    production translation units.  (1) salsa_amd/csrc/build_guard.h -- generated, checked here to be current -- makes any probe
+    switch a compile ERROR unless -DSALSA_PROBE_BUILD is given too; (2) the product's build command carries no -D at all;
+    (3) the library says what it was built with: salsa_build_flags() is empty for the product."""
+    import subprocess
+    import sys
+    from salsa_amd import _lib
+    gen = os.path.join(ROOT, 'tools', 'gen_build_guard.py')
+    assert subprocess.run([sys.executable, gen, '--check']).returncode == 0, 'build_guard.h is stale: python tools/gen_build_guard.py'
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_build_guard
+    switches, tunables = gen_build_guard.scan()
+    assert {'CONV_ZERO_SRC', 'CONV_PROBE_ROLL', 'CONV_FETCH_COLMAJOR', 'WIDE_X_ZERO', 'TR_PROBE_NO_CONSUME', 'FZ_PROBE_NOSOLVE',
+            'GRU_PROBE_BWD_NO_LOAD', 'BN_PROBE_NO_Y', 'STEM_NO_STORE'} <= set(switches)
+    assert {'K1_SPILL_NT', 'K3_OUT_NT', 'K3_FT_N', 'SALSA_PK_GATE_TOL', 'CONV_RES_EARLY'} <= set(tunables)
+    csrc = os.path.join(ROOT, 'salsa_amd', 'csrc')
+    for f in os.listdir(csrc):                                   # every translation unit starts from the guard
+        if f.endswith('.hip'):
+            assert '#include "build_guard.h"' in open(os.path.join(csrc, f)).read(), f
+    assert not [a for a in _lib.build_command() if a.startswith('-D')]
+    assert lib.salsa_build_flags() == b'' and _lib.build_flags() == ''
+    # the guard itself (plain preprocessor: g++ suffices): a probe switch alone is refused, with the marker it is admitted and named
+    tu = tmp_path / 'tu.cpp'
+    tu.write_text('#include "build_guard.h"\nconst char *flags = SALSA_BUILD_FLAGS;\n#include <stdio.h>\nint main() { puts(flags); return 0; }\n')
+    exe = str(tmp_path / 'tu')
+    base = ['g++', '-I', csrc, str(tu), '-o', exe]
+    for sw in ('CONV_ZERO_SRC', 'TR_PROBE_NO_CONSUME', 'K1_FRAME_MAJOR'):
+        r = subprocess.run(base + ['-D' + sw], capture_output=True, text=True)
+        assert r.returncode != 0 and 'SALSA_PROBE_BUILD' in r.stderr, sw
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == ''
+    assert subprocess.run(base + ['-DCONV_ZERO_SRC', '-DSALSA_PROBE_BUILD', '-DK3_FT_N=16'], capture_output=True).returncode == 0
+    assert subprocess.run([exe], capture_output=True, text=True).stdout.strip() == 'PROBE K3_FT_N=16'
+
+
+def test_hand_issued_residual_loads_are_not_touched_before_their_wait():
+    """Round-5 advisor (medium): conv_mfma.hip's early residual loads are bare asm global loads the compiler cannot see as in flight;
+    only its register allocation keeps a copy / spill away from their destination registers until the counted wait.  The ISA of
+    every build is checked (tools/asm_async_loads.py); the checker itself is checked on two synthetic listings."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import asm_async_loads as chk
+    n, bad = chk.check(os.path.join(ROOT, 'salsa_amd', 'csrc', 'conv_mfma.hip'))
+    assert n >= 8 and not bad, bad
+    good = ['_Zk:', ';;#ASMSTART', 'global_load_dwordx2 v[10:11], v[2:3], off', ';;#ASMEND', 'v_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:9], a[0:15]',
+            's_waitcnt vmcnt(2)', 'v_pk_add_f32 v[20:21], v[10:11], v[12:13]', '.Lfunc_end0:']
+    assert chk.check_lines(good) == (1, [])
+    for touch in ('v_mov_b32_e32 v40, v10', 'scratch_store_dwordx2 off, v[10:11], s32 offset:16', 'v_add_f32_e32 v11, v1, v2'):
+        n, bad = chk.check_lines(good[:5] + [touch] + good[5:])
+        assert n == 1 and len(bad) == 1 and bad[0][4] == touch

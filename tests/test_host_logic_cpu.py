@@ -206,3 +206,37 @@ def test_power_sampler_degrades_to_none_without_hwmon_files(tmp_path):
             f.write('%.3f 250000000 150000000 1390000000 2000000000\n' % (t0 + 0.01 * i))
     st = ps2.stats(t0, t0 + 1.0)
     assert st['mean_w'] == 1390.0 and st['sclk_mhz_mean'] == 2000.0 and st['cap_w'] == 1400.0 and st['samples'] == 10
+
+
+def test_clip_readers_shape_from_header_and_read_into_place(tmp_path):
+    """the file pipeline's reader primitives (round 6): audio_shape reads only the header; load_audio_into fills a caller's
+    (pinned) slot -- straight from the file for a float32 .npy in the slot's layout, through load_audio otherwise -- and the raw
+    .npy feature twin round-trips (one header + one write of the buffer)."""
+    from scipy.io import wavfile
+    from salsa_amd import io as sio
+    rng = np.random.RandomState(2)
+    a = (rng.uniform(-1, 1, (4, 5000)) * 0.5).astype(np.float32)
+    np.save(tmp_path / 'a.npy', a)
+    np.save(tmp_path / 'a64.npy', a.astype(np.float64))
+    wavfile.write(tmp_path / 'c.wav', 24000, a.T)
+    for name in ('a.npy', 'a64.npy', 'c.wav'):
+        assert sio.audio_shape(str(tmp_path / name), 24000) == (4, 5000)
+        dst = np.zeros((4, 5000), np.float32)
+        sio.load_audio_into(str(tmp_path / name), 24000, dst)
+        assert np.array_equal(dst, a), name
+        dst_t = np.zeros((5000, 4), np.float32)
+        sio.load_audio_into(str(tmp_path / name), 24000, dst_t, planar=False)
+        assert np.array_equal(dst_t, a.T), name
+    with pytest.raises(ValueError):
+        sio.audio_shape(str(tmp_path / 'c.wav'), 48000)
+    (tmp_path / 'short.npy').write_bytes((tmp_path / 'a.npy').read_bytes()[:-100])
+    with pytest.raises(IOError):
+        sio.load_audio_into(str(tmp_path / 'short.npy'), 24000, np.zeros((4, 5000), np.float32))
+    f = rng.randn(7, 50, 200).astype(np.float32)
+    w = sio.save_arrays(str(tmp_path / 'x.h5'), feature=f)
+    if not sio.HAVE_H5PY:
+        assert w.endswith('x.npy') and np.array_equal(np.load(w), f)
+    assert np.array_equal(sio.load_arrays(str(tmp_path / 'x.h5'))['feature'], f) and np.array_equal(sio.load_arrays(w)['feature'], f)
+    w2 = sio.save_arrays(str(tmp_path / 'foa_feature_scaler.h5'), mean=f[:4, :1], std=f[:4, :1] + 1)
+    got = sio.load_arrays(str(tmp_path / 'foa_feature_scaler.h5'))
+    assert set(got) == {'mean', 'std'} and (sio.HAVE_H5PY or w2.endswith('.npz'))
