@@ -112,6 +112,9 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
         t_w = (time.perf_counter() - t0) / 8 * n_clips
         res['file_io_alone'] = {'read_s': round(t_r, 3), 'write_s_one_thread': round(t_w, 3),
                                 'note': 'np.load of every clip; save_arrays of every feature file, both from ONE thread (the pipeline reads and writes with pools of threads)'}
+        res['timed_region'] = ('one extract_features(task=\'feature\') call: YAML parse, emptying the previous run\'s split folder (the reference does, '
+                               ':344), plan lookup, reads -> pinned slots -> device -> features -> pinned slots -> feature files; the pipeline\'s pinned slots '
+                               'and plans are cached per process (the warm-up call built them)')
         res['pcie_bound_s'] = round(n_clips / batch * (host.nbytes + one.nbytes * batch) / 55e9, 3)
         return res
     finally:

@@ -160,15 +160,24 @@ class _FilePipeline:
         self.error = None
 
     def _buffers(self, sl, batch, n_samples):
+        """Views of the slot's staging for (batch, n_samples); the flat pinned / device arrays behind them only ever GROW (a tree of
+        ragged clips used to re-pin its slots at every new length)."""
         if sl['n'] == (batch, n_samples):
             return
         torch, ex = self.torch, sl['ex']
         shape = (batch, 4, n_samples) if ex.audio_layout == 'planar' else (batch, n_samples, 4)
         oshape = (batch,) + tuple(ex.output_shape(n_samples))
-        sl['h_in'] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
-        sl['d_in'] = torch.empty(shape, dtype=torch.float32, device=ex.device)
-        sl['d_out'] = torch.empty(oshape, dtype=torch.float32, device=ex.device)
-        sl['h_out'] = torch.empty(oshape, dtype=torch.float32, pin_memory=True)
+        n_in, n_out = int(np.prod(shape)), int(np.prod(oshape))
+        if sl.get('cap_in', 0) < n_in:
+            sl['f_h_in'] = torch.empty(n_in, dtype=torch.float32, pin_memory=True)
+            sl['f_d_in'] = torch.empty(n_in, dtype=torch.float32, device=ex.device)
+            sl['cap_in'] = n_in
+        if sl.get('cap_out', 0) < n_out:
+            sl['f_d_out'] = torch.empty(n_out, dtype=torch.float32, device=ex.device)
+            sl['f_h_out'] = torch.empty(n_out, dtype=torch.float32, pin_memory=True)
+            sl['cap_out'] = n_out
+        sl['h_in'], sl['d_in'] = sl['f_h_in'][:n_in].view(shape), sl['f_d_in'][:n_in].view(shape)
+        sl['d_out'], sl['h_out'] = sl['f_d_out'][:n_out].view(oshape), sl['f_h_out'][:n_out].view(oshape)
         sl['n'] = (batch, n_samples)
 
     def _fail(self, e):
@@ -203,8 +212,9 @@ class _FilePipeline:
         for sl in self.slots:
             self.free.put(sl)
         t_read, t_write = [0.0], [0.0]
+        t_wait = {'main_for_reader': 0.0, 'writer_for_device': 0.0, 'reader_for_slot': 0.0, 'wall': time.perf_counter()}
 
-        cap = max(1, min(batch_size, len(todo)))         # clips per slot
+        cap = max(1, min(batch_size, SLOT_CLIPS, len(todo)))   # clips per slot (batch_size is the caller's upper bound per device call)
 
         def reader():
             pool = ThreadPoolExecutor(self.readers)
@@ -240,7 +250,9 @@ class _FilePipeline:
                     if n not in open_:
                         if len(open_) >= self.depth - 2:    # never hold every slot half-filled: flush the fullest bucket
                             close(max(open_, key=lambda k: len(open_[k][1])))
+                        t0w = time.perf_counter()
                         sl = self._take(self.free)
+                        t_wait['reader_for_slot'] += time.perf_counter() - t0w
                         if sl is _STOP:
                             return
                         self._buffers(sl, cap, n)
@@ -267,7 +279,9 @@ class _FilePipeline:
                     sl = self._take(self.inflight)
                     if sl is None or sl is _STOP:
                         return
+                    t0w = time.perf_counter()
                     sl['done'].synchronize()
+                    t_wait['writer_for_device'] += time.perf_counter() - t0w
                     t0 = time.perf_counter()
                     feats = sl['h_out'].numpy()
                     def save(k):
@@ -287,7 +301,9 @@ class _FilePipeline:
         n_batches = 0
         try:
             while not self.stop.is_set():                   # (a failed stage: launch nothing more, not even what is already queued)
+                t0w = time.perf_counter()
                 sl = self._take(self.filled)
+                t_wait['main_for_reader'] += time.perf_counter() - t0w
                 if sl is None or sl is _STOP:
                     break
                 b = len(sl['items'])
@@ -315,13 +331,58 @@ class _FilePipeline:
             e, self.error = self.error, None
             raise e
         if stats is not None:
-            stats.update(batches=n_batches, read_s=t_read[0], write_s=t_write[0])
+            t_wait['wall'] = time.perf_counter() - t_wait['wall']
+            stats.update(batches=n_batches, read_s=t_read[0], write_s=t_write[0], **t_wait)
 
 
 _STOP = object()
+_PIPELINES = {}
 
 
+def _pipeline_for(ex):
+    """The file pipeline of extractors with these parameters on this device, built once per process: its plans, streams and --
+    above all -- its pinned host slots outlive an extract_features() call (round 6: every call built a new extractor and with it
+    a new pipeline, and pinning 6 GB of slots cost more than extracting a 64-clip tree).  The caller's extractor becomes slot 0's
+    plan holder; post-construction state (scaler, schedule) is re-applied to every slot by run()."""
+    key = (str(ex.device),) + tuple(sorted((k, str(v)) for k, v in ex.kwargs().items()))
+    pipe = _PIPELINES.get(key)
+    if pipe is None:
+        pipe = _PIPELINES[key] = _FilePipeline(ex)
+    else:
+        pipe.exs[0] = ex                                    # state source for copy_plan_state_to (same parameters by construction)
+        pipe.slots[0]['ex'] = ex
+    return pipe
+
+
+def release_file_pipelines():
+    """Drop the cached pipelines (pinned host slots, device buffers, plans)."""
+    _PIPELINES.clear()
+
+
+SLOT_CLIPS = 8     # clips per pipeline slot: small slots overlap read / copy / extract / copy / write sooner and pin 4x less host memory
+                   # than 32-clip ones; the device does 8 x 60-s clips in ~0.45 ms, far below a slot's 8 ms of PCIe time
 USE_FILE_PIPELINE = os.environ.get('SALSA_FILE_PIPELINE', '1') != '0'
+
+
+def _rmtree_parallel(path, threads: int = 8):
+    """shutil.rmtree(path, ignore_errors=True) with the directory's own files unlinked from a few threads first: emptying last run's
+    split folder (:344) is freeing 27 MB of page cache / tmpfs per clip, 2.5 ms each from one thread -- twice what extracting the
+    clip takes (tools/probes/harness_profile.py)."""
+    try:
+        files = [e.path for e in os.scandir(path) if e.is_file(follow_symlinks=False)]
+    except OSError:
+        files = []
+    if len(files) > 2 * threads:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def rm(p):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(rm, files))
+    shutil.rmtree(path, ignore_errors=True)
 
 
 def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear=True, stats=None):
@@ -330,7 +391,7 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
     shard = (rank, world): this process takes a contiguous range of the sorted file list (salsa_amd.distributed)."""
     torch = _torch()
     if clear:
-        shutil.rmtree(feature_dir, ignore_errors=True)      # the reference empties the split's folder first (:344)
+        _rmtree_parallel(feature_dir)                       # the reference empties the split's folder first (:344)
     os.makedirs(feature_dir, exist_ok=True)
     audio_fn_list = sorted(os.listdir(audio_dir))
     todo = list(enumerate(audio_fn_list))
@@ -339,9 +400,7 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
         lo, hi = shard_range(len(todo), *shard)
         todo = todo[lo:hi]
     if USE_FILE_PIPELINE and todo:
-        pipe = getattr(ex, '_file_pipeline', None)
-        if pipe is None:
-            pipe = ex._file_pipeline = _FilePipeline(ex)
+        pipe = _pipeline_for(ex)
         with torch.cuda.device(ex.device):
             pipe.run(todo, audio_dir, feature_dir, fs, batch_size, stats)
         return
