@@ -126,7 +126,15 @@ __device__ __forceinline__ float power32(const float2 x)
     const float t = x.x * x.x;
     return __builtin_fmaf(x.y, x.y, t);
 }
-__device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(fmaxf(1e-10f, p)); } // 10*log10(max(1e-10,p))
+// max(a, b) as ONE v_max_f32: fmaxf() first canonicalises its operand (a second v_max_f32 v, v, v per value -- a quieting no-op for
+// anything but a signalling NaN, which no arithmetic here produces); same result, NaN handling included (IEEE maxNum)
+__device__ __forceinline__ float max_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * __log2f(max_raw(1e-10f, p)); } // 10*log10(max(1e-10,p))
 
 // Addressing: a wave-uniform base pointer (SGPR pair) + a 32-bit unsigned BYTE offset per lane lets the compiler use the
 // "saddr" form of global loads/stores; `ptr[int_index]` instead costs two or three 64-bit VALU instructions per access
@@ -134,6 +142,10 @@ __device__ __forceinline__ float db10(float p) { return 3.01029995663981195f * _
 // below 4 GiB.
 template <typename V> __device__ __forceinline__ void st_off(V *base, unsigned byte_off, const V v) { *(V *)((char *)base + byte_off) = v; }
 template <typename V> __device__ __forceinline__ V ld_off(const V *base, unsigned byte_off) { return *(const V *)((const char *)base + byte_off); }
+// base + zero-extended lane offset + a COMPILE-TIME byte constant added after the extension: the constant lands in the load's
+// immediate offset field (inside the 32-bit sum it cannot -- the unsigned addition may wrap as far as the compiler knows -- and
+// costs a v_add_u32 per load)
+template <typename V> __device__ __forceinline__ V ld_off_c(const V *base, unsigned byte_off, int const_bytes) { return *(const V *)((const char *)base + byte_off + const_bytes); }
 // Production default since round 5 (0 = plain stores, for A/B): the spill's 16-byte stores as non-temporal stores ALONE (whole 1-KB
 // wave stores that nothing re-reads before they leave the L2); the 4-byte spectrogram rows stay plain (see the store policy above).
 #ifndef K1_SPILL_NT
@@ -168,6 +180,9 @@ __device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const
 #ifndef K1_NF_FULL
 #define K1_NF_FULL 4
 #endif
+#ifndef K1_STD
+#define K1_STD 1 // the STD instantiations of stft_kernel for the dataset scripts' layout (0: always the general kernel; bit-identical)
+#endif
 template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : K1_NF_FULL;
 };
@@ -175,7 +190,15 @@ template <bool LITE> struct k1_cfg {
 // SC (round 4): the instantiation launched when a scaler is attached keeps the [4][F] mean / std tables in LDS.  It is a separate
 // instantiation because the 8 KB of LDS and the 168-register cap cost the plain path 4 % (0.458 -> 0.477 ms) when they were
 // unconditional; SC = false is the round-3 kernel, bit for bit (and still honours a scaler, through global loads).
-template <int N, typename T, bool LITE, int NF, int NPAIRS = 2, bool SC = false>
+// STD (round 6, the ISA audit of profiles/r6_k1_isa.txt): the dataset scripts' spectrogram layout known at COMPILE time -- n_fft 512,
+// planar audio, both channel pairs in one launch, high-frequency compression on (rows 0..191 = bins 1..192, rows 192..199 = eight
+// bins each), and no scaler unless SC holds it in LDS.  Of the ~900 instructions an item issued, ~330 were not the FFT: sixteen
+// load addresses rebuilt per item (the stride was a run-time value: planar | interleaved), a run-time 7-iteration tail loop in the
+// compressed rows, the Nyquist bin unpacked and tested although W never reads it (:163-171), a scaler branch + division sequence
+// compiled into all eleven store sites, and exec-mask juggling around band tests whose answers are fixed per register.  Same
+// arithmetic in the same order: outputs are bit-identical (tests: goldens, fused-vs-three-kernel identity).  The DOA band stays a
+// run-time range (FOA 1..192, MIC 1..85, any fmin / fmax).
+template <int N, typename T, bool LITE, int NF, int NPAIRS = 2, bool SC = false, bool STD = false>
 __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     constexpr int NP = fft_cfg<N>::NP;
     constexpr int NB = N / 2 + 1;
     __shared__ cplx<T> buf[4][N];
-    __shared__ float pw[4][2][64];               // powers of the compressed band (<= 63 bins) of the wave's two channels
+    __shared__ __attribute__((aligned(16))) float pw[4][2][64]; // powers of the compressed band (<= 63 bins) of the wave's two channels (STD reads them 16 bytes at a time)
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y, bx = blockIdx.x;
@@ -229,7 +252,8 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
     // path -- no per-load branching; frames that overlap a clip end take the reflect path (np.pad(mode='reflect'); one
     // fold suffices because Ns > N/2, checked on the host).
-    const bool planar = kp.layout == SALSA_LAYOUT_PLANAR;
+    static_assert(!STD || (N == 512 && !LITE && NPAIRS == 2), "STD is the dataset scripts' full-SALSA configuration");
+    const bool planar = STD ? true : kp.layout == SALSA_LAYOUT_PLANAR;
     const int sstride = planar ? 1 : nch;
     // Item order.  Full SALSA: PAIR-major (all the wave's frames of channels 0/1, then of channels 2/3), so consecutive
     // items re-read the 41 % of samples that overlapping frames share while they are still in L2 (frame-major order
@@ -241,8 +265,8 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     constexpr bool PAIR_MAJOR = !LITE;
 #endif
     const int nleft_ = (Tn - t_begin + K1_TSTEP - 1) / K1_TSTEP; // frames t_begin, t_begin + K1_TSTEP, ... below Tn
-    const int nfr_ = nleft_ < K1_NF ? nleft_ : K1_NF;
-    const int psel = LITE ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
+    const int nfr_ = STD ? __builtin_amdgcn_readfirstlane(nleft_ < K1_NF ? nleft_ : K1_NF) : (nleft_ < K1_NF ? nleft_ : K1_NF);
+    const int psel = (LITE || STD) ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
     auto item_frame = [&](int item) {
         if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / npairs;
         return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1;
@@ -261,8 +285,13 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
             const unsigned q = (unsigned)(base + lane) * step;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                y0[r] = ld_off(clip, ch0 + q + (unsigned)(r * (N / R)) * step);
-                y1[r] = ld_off(clip, ch1 + q + (unsigned)(r * (N / R)) * step);
+                if (STD) { // planar, 4-byte stride: the eight strided points of a channel are one address + immediates r * 256
+                    y0[r] = ld_off_c(clip, ch0 + q, r * (N / R) * 4);
+                    y1[r] = ld_off_c(clip, ch1 + q, r * (N / R) * 4);
+                } else {
+                    y0[r] = ld_off(clip, ch0 + q + (unsigned)(r * (N / R)) * step);
+                    y1[r] = ld_off(clip, ch1 + q + (unsigned)(r * (N / R)) * step);
+                }
             }
         } else {
 #pragma unroll
@@ -284,6 +313,7 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
     // log-spectrogram value of channel c, feature f; with a scaler attached also (x - mean) / std (database.py:197-202)
     auto spec = [&](const float p, const int c, const int f) -> float {
         const float v = db10(p);
+        if (STD && !SC) return v;                 // (the launch guarantees: no scaler attached)
         if (SC) {
             const int i = c * kp.F + f;
             return kp.sc_mean ? (v - sct0[i]) / sct1[i] : v;
@@ -394,18 +424,64 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
                 }
             }
         };
+        // STD: register r holds bins 64 r .. 64 r + 63, so with spec_lo = 1, spec_hi = 193, ident = 192 the spectrogram-row / compressed-
+        // band membership of a bin is fixed per register: r = 0 -- rows for every lane but lane 0 (bin 0: W has no row for it);
+        // r = 1, 2 -- rows, all lanes; r = 3 -- lane 0 is bin 192 (row 191), lanes 1..63 are bins 193..255 of the compressed rows.
+        auto emit_std = [&](auto rc, const cplx<T> a, const cplx<T> bm) {
+            constexpr int r = decltype(rc)::value;
+            const int k = lane + 64 * r;
+            cplx<T> Xa, Xb;
+            salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
+            const float2 xa = make_float2((float)Xa.re, (float)Xa.im);
+            const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
+            const float pa = power32(xa), pb = power32(xb);
+            if (k >= kp.lower && k < kp.upper) {
+                const unsigned so = 16u * (unsigned)((t * 2 + pr) * kp.nd + (k - kp.lower));
+                if (K1_SPILL_NT) st_off_nt(xs, so, make_float4(xa.x, xa.y, xb.x, xb.y));
+                else st_off(xs, so, make_float4(xa.x, xa.y, xb.x, xb.y));
+            }
+            if (r < 3 ? (r > 0 || lane > 0) : lane == 0) {
+                const unsigned off = 4u * (unsigned)((c0 * Tn + t) * 200 + (k - 1));
+                st_off(o, off, spec(pa, c0, k - 1));
+                st_off(o, off + plane, spec(pb, c0 + 1, k - 1));
+            } else if (r == 3) {
+                pw[w][0][lane - 1] = pa;
+                pw[w][1][lane - 1] = pb;
+            }
+        };
 #pragma unroll
         for (int r = 0; r < R / 2; r++) {
             // mirror of k = lane + 64 r is N-k = (64-lane) + 64 (R-1-r): register R-1-r of lane 64-lane;
             // lane 0: N - 64 r = 64 (R-r), its own register (R-r) mod R
             cplx<T> bm = {__shfl(v[R - 1 - r].re, mlane), __shfl(v[R - 1 - r].im, mlane)};
             if (lane == 0) bm = v[(R - r) & (R - 1)];
-            emit_bin(lane + 64 * r, v[r], bm, x0keep[r]);
+            if constexpr (STD) {
+                if (r == 0) emit_std(std::integral_constant<int, 0>{}, v[r], bm);
+                else if (r == 1) emit_std(std::integral_constant<int, 1>{}, v[r], bm);
+                else if (r == 2) emit_std(std::integral_constant<int, 2>{}, v[r], bm);
+                else emit_std(std::integral_constant<int, 3>{}, v[r], bm);
+            } else {
+                emit_bin(lane + 64 * r, v[r], bm, x0keep[r]);
+            }
             __builtin_amdgcn_sched_barrier(0); // one bin at a time: keeps the live set (and the VGPR count) small
         }
-        if (lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2], x0keep[R / 2]);
+        if (!STD && lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2], x0keep[R / 2]); // (STD: bin 256 is in no DOA band, row or compressed row)
         // ---- compressed high-frequency rows of W: sum of 8 (last row 7) bins times 1/8
-        if (!LITE && kp.compress) {
+        if constexpr (STD) {
+            // eight groups x two channels = lanes 0..15: two 16-byte LDS reads and a fixed chain of eight additions in the order of
+            // the loop below (the seventh row's missing eighth term is skipped, not added as zero: pw[..][63] is never written)
+            wave_lds_fence();
+            const int h = lane & 1, gi = lane >> 1;
+            if (gi < 8) {
+                const float4 p0 = *(const float4 *)&pw[w][h][8 * gi], p1 = *(const float4 *)&pw[w][h][8 * gi + 4];
+                float acc = 0.f;
+                acc += 0.125f * p0.x; acc += 0.125f * p0.y; acc += 0.125f * p0.z; acc += 0.125f * p0.w;
+                acc += 0.125f * p1.x; acc += 0.125f * p1.y; acc += 0.125f * p1.z;
+                const float acc8 = acc + 0.125f * p1.w;
+                acc = gi < 7 ? acc8 : acc;
+                st_off(o, 4u * (unsigned)(((c0 + h) * Tn + t) * 200 + 192 + gi), spec(acc, c0 + h, 192 + gi));
+            }
+        } else if (!LITE && kp.compress) {
             wave_lds_fence();
             const int ng = kp.F - kp.ident;
             const int h = lane & 1, gi = lane >> 1;
@@ -2310,7 +2386,15 @@ static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, 
     // a scaler is attached: the instantiation with the tables in LDS -- which hold [2][4 * 256] floats, so only while F <= 256 (the
     // contrib plan with SALSA_FLAG_NO_CLIP_FREQS and a lite band from bin 0 have F = 257: they take the plain kernel, whose
     // store path reads the tables from global memory at any F)
-    if (pl->p.n_fft == 512 && kp.sc_mean && !single && kp.F <= 256) {
+    // the dataset scripts' layout as a compile-time fact (stft_kernel's STD instantiations; K1_STD 0: the general kernel, for A/B)
+    const bool std_layout = K1_STD && pl->p.n_fft == 512 && !lite && !single && kp.feature == SALSA_FEATURE_SALSA && kp.compress &&
+                            kp.spec_lo == 1 && kp.spec_hi == 193 && kp.ident == 192 && kp.F == 200 && kp.nch == 4 &&
+                            kp.layout == SALSA_LAYOUT_PLANAR && kp.pair_sel < 0;
+    if (std_layout) {
+        constexpr size_t SCT_BYTES = 2 * 4 * 256 * sizeof(float);
+        if (kp.sc_mean) hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, true, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+        else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, false, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    } else if (pl->p.n_fft == 512 && kp.sc_mean && !single && kp.F <= 256) {
         constexpr size_t SCT_BYTES = 2 * 4 * 256 * sizeof(float);
         if (lite) hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
