@@ -339,6 +339,31 @@ def train_bench(rank, world, dev, batch=32, steps=20, warmup=5, on_the_fly=False
 
 
 
+STOCK_ENV = {'SALSA_HIP_POOL': '0', 'SALSA_HIP_BN': '0', 'SALSA_HIP_CONV': '0', 'SALSA_HIP_CONV_WIDE': '0', 'SALSA_HIP_CONV_WIDE_WRW': '0',
+             'SALSA_HIP_CONV_1X1': '0', 'SALSA_HIP_STEM_WRW': '0', 'SALSA_HIP_BN_POOL': '0', 'SALSA_HIP_BN_RES_POOL': '0', 'SALSA_HIP_FREQ_MEAN': '0',
+             'SALSA_FUSED_GRU': '0', 'SALSA_FUSED_LOSS': '0', 'SALSA_HIP_ADAM': '0', 'SALSA_CONV_STATS': '0', 'SALSA_WIDE_CONV_STATS': '0',
+             'SALSA_STEM_FUSED_BWD': '0', 'SALSA_FILTER_BANK': '0', 'SALSA_FUSED_SKIP': '0', 'SALSA_GEMM_1X1': '0'}
+
+
+def torch_baseline(steps=8, warmup=3, batch=32, timeout=420):
+    """The SAME training step on this box with every hand-written CRNN kernel switched off: torch / MIOpen convolutions, torch
+    BatchNorm, pooling, GRU (MIOpen), loss and (fused) Adam, bf16 autocast, channels-last -- what `pip install torch` gives the
+    reference's model on an MI355X.  A stated baseline (like cpu_baseline), measured in a child process (the switches are read at
+    import) after this process's own legs; None on any failure, never an exception."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(STOCK_ENV)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(steps), '--warmup', str(warmup), '--batch', str(batch)],
+                           capture_output=True, text=True, timeout=timeout, env=env)
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+        return {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': steps, 'warmup': warmup,
+                'kind': 'stock PyTorch-ROCm (MIOpen / hipBLASLt / torch kernels), same model, batch, dtype and box',
+                'convolutions': line['roofline']['note'].split('convolutions: ')[-1], 'switches': 'SALSA_HIP_* = 0 (bench_crnn.STOCK_ENV)'}
+    except Exception as e:  # noqa: BLE001 - a baseline, not the product
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+
+
 def _flush_c_stdio():
     """push out whatever native libraries (RCCL's version banner) left in libc's stdout buffer -- every rank, as soon as its
     process group is gone, so that nothing of it can land after rank 0's result line"""
