@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const 
             const unsigned q = (unsigned)(base + lane) * step;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if (STD) { // planar, 4-byte stride: the eight strided points of a channel are one address + immediates r * 256
+                if (STD) { // planar, 4-byte stride: the eight strided points of a channel are one address + immediates r * 256 (tried for every
+                           // planar plan behind a wave-uniform branch: the general instantiations went from 168 to 174 VGPRs = 2 waves per SIMD)
                     y0[r] = ld_off_c(clip, ch0 + q, r * (N / R) * 4);
                     y1[r] = ld_off_c(clip, ch1 + q, r * (N / R) * 4);
                 } else {

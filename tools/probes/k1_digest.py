@@ -22,3 +22,6 @@ print('ragged foa    ', dig(SalsaExtractor(device=dev).extract(r)))
 it = torch.from_numpy(np.ascontiguousarray(np.stack([synth_clip(27 + i, 72000) for i in range(2)]).transpose(0, 2, 1))).to(dev)
 print('interleaved   ', dig(SalsaExtractor(audio_layout='interleaved', device=dev).extract(it)))
 print('nocompress    ', dig(SalsaExtractor(is_compress_high_freq=False, device=dev).extract(r)))
+print('lite mic      ', dig(SalsaExtractor(audio_format='mic', feature_type='salsa_lite', fmax_doa=2000, device=dev).extract(m)))
+print('ipd mic       ', dig(SalsaExtractor(audio_format='mic', feature_type='salsa_ipd', fmax_doa=2000, device=dev).extract(r)))
+print('nfft256       ', dig(SalsaExtractor(n_fft=256, hop_len=150, win_len=256, device=dev).extract(r)))
