@@ -19,7 +19,9 @@ import sys
 src = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 name = {'stft_kernel': 'stft_logspec', 'tracker_kernel': 'noise_floor_tracker', 'cov_eig_kernel': 'cov_eig'}
-acc, origin = {}, {}
+# (gate_doubt_kernel, launched behind cov_eig_kernel since round 6, reads the 3.7-MB doubt mask and exits: its bytes are added to cov_eig's)
+extra = {'gate_doubt_kernel': 'cov_eig'}
+acc, origin, addl = {}, {}, {}
 for path in [src] + sys.argv[3:4]:
     rows = []
     for ln in open(path).read().splitlines()[1:]:            # kernel names may carry commas (template arguments): split from the right
@@ -27,6 +29,10 @@ for path in [src] + sys.argv[3:4]:
         if len(parts) == 4:
             rows.append({'kernel': parts[0], 'counter': parts[1], 'mean_per_dispatch': parts[2]})
     for row in rows:
+        ke = next((v for kk, v in extra.items() if row['kernel'].startswith(kk)), None)
+        if ke and path == src and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            addl.setdefault(ke, {}).setdefault(row['counter'], 0.0)
+            addl[ke][row['counter']] += float(row['mean_per_dispatch'])
         k = next((v for kk, v in name.items() if row['kernel'].startswith(kk)), None)   # (summaries may keep the template arguments)
         if k and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU') and row['counter'] not in acc.get(k, {}):
             acc.setdefault(k, {})[row['counter']] = float(row['mean_per_dispatch'])
@@ -43,7 +49,8 @@ out = {'source': ', '.join('%s from %s' % (c, f) for c, f in sorted(origin.items
        'commit': commit, 'kernel_sources_sha16': ksha, 'correction': 'FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1; valu_util = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
        'kernels': {}}
 for k, v in acc.items():
-    rd, wr = v.get('FETCH_SIZE', 0) * 1024 * 2, v.get('WRITE_SIZE', 0) * 1024
+    rd = (v.get('FETCH_SIZE', 0) + addl.get(k, {}).get('FETCH_SIZE', 0.0)) * 1024 * 2
+    wr = (v.get('WRITE_SIZE', 0) + addl.get(k, {}).get('WRITE_SIZE', 0.0)) * 1024
     out['kernels'][k] = {'hbm_read_bytes': int(rd), 'hbm_write_bytes': int(wr), 'hbm_bytes': int(rd + wr)}
     if v.get('SQ_ACTIVE_INST_VALU') and v.get('GRBM_GUI_ACTIVE'):
         out['kernels'][k]['valu_util'] = round(v['SQ_ACTIVE_INST_VALU'] * 4 / (v['GRBM_GUI_ACTIVE'] / 8 * 1024), 4)
