@@ -80,6 +80,8 @@ struct KParams {
     int force_f64;             // SALSA_FLAG_FORCE_F64: the float64 instantiation of the covariance / eigen kernel
     unsigned *doubt32;         // [B][32-bin group][T] bit mask of the TF bins whose coherence test the quartic could not decide
                                // (salsa_math.h SALSA_GATE_DOUBT; decided by gate_doubt_kernel after the launch), or NULL (ungated plans)
+    unsigned *doubt_flag;      // one word per launch group: non-zero once ANY bin was flagged (zeroed by the tracker launch before the
+                               // covariance / eigen launch, or by a memset on the tracker-less gated path): gate_doubt_kernel reads it and exits
 };
 
 constexpr int FEATURE_LOGSPEC_ONLY = 3;
@@ -611,6 +613,7 @@ static unsigned tracker_grid(const KParams &kp) { return (unsigned)(kp.B * ((kp.
 __global__ __launch_bounds__(64 * TR_WAVES) void tracker_kernel(const KParams kp, const float4 *__restrict__ Xs,
                                                                 unsigned *__restrict__ valid32)
 {
+    if (kp.doubt_flag && blockIdx.x == 0 && threadIdx.x == 0) *kp.doubt_flag = 0u; // (consumed two launches later, same stream)
     constexpr int BINS = TR_WG_BINS, FS = 64 / BINS;                                      // FS frames per producer instruction
     constexpr bool IDLE4 = TR_WAVES > 4 && TR_IDLE4;                                     // wave 4 shares the consumer's SIMD: keep it idle
     constexpr int NPROD = IDLE4 ? TR_WAVES - 2 : TR_WAVES - 1;
@@ -1008,8 +1011,10 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
             slow[atomicAdd(&nslow, 1)] = (unsigned short)(((t - t0) << 8) | (bin - bin0));
             return;
         }
-        if (er.doubt && kp.doubt32 && !ungated) // the threshold sits ON a root of the quartic: what is emitted below is provisional,
+        if (er.doubt && kp.doubt32 && !ungated) { // the threshold sits ON a root of the quartic: what is emitted below is provisional,
             atomicOr(&kp.doubt32[((long)b * ((kp.nd + TR_BINS - 1) / TR_BINS) + (bin >> 5)) * Tn + t], 1u << (bin & 31)); // gate_doubt_kernel decides
+            atomicOr(kp.doubt_flag, 1u);
+        }
         double e[3] = {0.0, 0.0, 0.0};
         unsigned char g = er.rank1 ? 2 : 1;
         if (er.rank1 || ungated) {
@@ -1215,12 +1220,13 @@ __global__ __launch_bounds__(K3_NT, PK ? K3_PK_WAVES : 1) void cov_eig_kernel(co
 // The TF bins cov_eig_kernel flagged in kp.doubt32 -- the threshold mu1 / cond numerically ON a root of the characteristic quartic, which
 // then cannot decide "s0 > s1 * cond" (:106): multiple eigenvalues at the threshold lose float64 to sqrt / cube-root precision -- decided
 // on the matrix: float64 covariance from the spill, eigenvalues by Jacobi rotations (salsa_math.h herm4_rank1_by_jacobi, the oracle's
-// method), eigenvector by the general adjugate path, and the bin's three values rewritten.  On natural signals the mask is empty:
-// the launch reads B * ceil(nd / 32) * T words (3.7 MB for 32 x 60-s clips) and exits.  Round 6.
+// method), eigenvector by the general adjugate path, and the bin's three values rewritten.  On natural signals nothing is flagged:
+// the launch (64 workgroups) reads the group's flag word and exits; only a flagged launch scans the mask.  Round 6.
 template <bool FEAT>
 __global__ __launch_bounds__(256) void gate_doubt_kernel(const KParams kp, const float4 *__restrict__ Xs, float *__restrict__ out_feat,
                                                          double *__restrict__ out_eig, unsigned char *__restrict__ gate)
 {
+    if (*(const volatile unsigned *)kp.doubt_flag == 0u) return; // nothing flagged (every natural signal): one load per wave
     const int Tn = kp.T, n32 = (kp.nd + TR_BINS - 1) / TR_BINS, stride = 2 * kp.nd;
     const long nwords = (long)kp.B * n32 * Tn;
     const bool foa = kp.format == SALSA_FORMAT_FOA;
@@ -1271,7 +1277,7 @@ static void launch_gate_doubt(const KParams &kp, hipStream_t s, const float4 *Xs
 {
     if (!kp.doubt32) return;
     const long nwords = (long)kp.B * ((kp.nd + TR_BINS - 1) / TR_BINS) * kp.T;
-    const unsigned blocks = (unsigned)(nwords < 256L * 1024 ? (nwords + 255) / 256 : 1024);
+    const unsigned blocks = (unsigned)(nwords < 256L * 64 ? (nwords + 255) / 256 : 64);
     hipLaunchKernelGGL(gate_doubt_kernel<FEAT>, dim3(blocks ? blocks : 1u), dim3(256), 0, s, kp, Xs, out_feat, out_eig, gate);
 }
 
@@ -1280,6 +1286,7 @@ static void launch_cov_eig(const KParams &kp, dim3 grid, hipStream_t s, const fl
                            float *out_feat, double *out_eig, unsigned char *gate)
 {
     const bool gated = kp.tracking || kp.flex; // (!ungated: the coherence test decides, so passing bins have a spectral gap)
+    if (kp.doubt32 && !kp.tracking) (void)hipMemsetAsync(kp.doubt_flag, 0, sizeof(unsigned), s); // (no tracker launch zeroed it: contrib's gate without tracking)
     // (the packed pair solve: feature output only -- salsa_eigvec_batch keeps float64 results -- and never for contrib's variant)
     if (FEAT && SALSA_PK && K3_GROUP == 2 && kp.n_hop == 3 && gated && SALSA_COL0 && !kp.flex && kp.cond >= SALSA_PK_COND_MIN && kp.cond < 1e6 && !kp.force_f64)
         hipLaunchKernelGGL((cov_eig_kernel<FEAT, 3, true, FEAT && K3_GROUP == 2>), grid, dim3(K3_NT), 0, s, kp, Xs, valid, out_feat, out_eig, gate);
@@ -2314,13 +2321,13 @@ size_t salsa_workspace_bytes(const salsa_plan *pl, int batch, int64_t n_samples)
 {
     if (!pl || batch <= 0 || n_samples <= 0 || pl->p.feature_type != SALSA_FEATURE_SALSA) return 0;
     const size_t T = 1 + n_samples / pl->p.hop_len;
-    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + 2 * mask_bytes(batch, T, pl->nd) + 256; // spill, gate masks, doubt mask
+    return align256((size_t)batch * T * 4 * pl->nd * sizeof(float2)) + 2 * mask_bytes(batch, T, pl->nd) + align256(sizeof(unsigned) * (size_t)batch) + 256; // spill, gate masks, doubt mask, doubt flags
 }
 
 size_t salsa_eigvec_workspace_bytes(const salsa_plan *pl, int batch, int n_bins, int64_t n_frames)
 {
     if (!pl || batch <= 0 || n_bins <= 0 || n_frames <= 0) return 0;
-    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + 2 * mask_bytes(batch, (size_t)n_frames, n_bins) + 256;
+    return align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)) + 2 * mask_bytes(batch, (size_t)n_frames, n_bins) + align256(sizeof(unsigned) * (size_t)batch) + 256;
 }
 
 static KParams make_kparams(const salsa_plan *pl, int batch, int64_t n_samples)
@@ -2440,8 +2447,10 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         if (!d_workspace || workspace_bytes < need) return fail(SALSA_EWORKSPACE, "workspace too small%s (need %ld bytes)", "", (long)need);
         Xs = (float4 *)d_workspace;
         valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * kp.T * 4 * kp.nd * sizeof(float2)));
-        if ((kp.tracking || kp.flex) && kp.cond > 1.0 && kp.nd > 0)
+        if ((kp.tracking || kp.flex) && kp.cond > 1.0 && kp.nd > 0) {
             kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)kp.T, kp.nd));
+            kp.doubt_flag = (unsigned *)((unsigned char *)kp.doubt32 + mask_bytes(batch, (size_t)kp.T, kp.nd)); // [batch]: one per launch group
+        }
     }
     pl->n_kernels = 0;
     const long T = kp.T;
@@ -2456,7 +2465,7 @@ int salsa_extract_batch(salsa_plan *pl, const float *d_audio, int batch, int64_t
         float *o = d_out + (size_t)g0 * 7 * T * kp.F;
         float4 *xs = Xs ? Xs + (size_t)g0 * T * 2 * kp.nd : nullptr;
         unsigned *vm = valid ? valid + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T : nullptr; // [b][32-bin group][t]
-        if (kp.doubt32) gp.doubt32 = kp.doubt32 + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T;
+        if (kp.doubt32) gp.doubt32 = kp.doubt32 + (size_t)g0 * ((kp.nd + TR_BINS - 1) / TR_BINS) * T, gp.doubt_flag = kp.doubt_flag + g0;
         const bool two = split && full && gp.nd > 0;
         gp.pair_sel = two ? 0 : -1;
         // timing mode with a repeat count (salsa_plan_set_timing(plan, K > 1)): every kernel is launched K times back to
@@ -2678,7 +2687,10 @@ int salsa_eigvec_batch(salsa_plan *pl, const float *d_X, int batch, int n_bins, 
     kp.feature = SALSA_FEATURE_SALSA;
     float4 *Xs = (float4 *)d_workspace;
     unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
-    if ((kp.tracking || kp.flex) && kp.cond > 1.0) kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
+    if ((kp.tracking || kp.flex) && kp.cond > 1.0) {
+        kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
+        kp.doubt_flag = (unsigned *)((unsigned char *)kp.doubt32 + mask_bytes(batch, (size_t)n_frames, n_bins));
+    }
     const long total = (long)batch * n_bins * n_frames * 2;
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
@@ -2714,7 +2726,10 @@ int salsa_eigvec_feature_batch(salsa_plan *pl, const float *d_X, int batch, int 
     kp.feature = SALSA_FEATURE_SALSA;
     float4 *Xs = (float4 *)d_workspace;
     unsigned *valid = (unsigned *)((unsigned char *)d_workspace + align256((size_t)batch * n_frames * 4 * n_bins * sizeof(float2)));
-    if ((kp.tracking || kp.flex) && kp.cond > 1.0) kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
+    if ((kp.tracking || kp.flex) && kp.cond > 1.0) {
+        kp.doubt32 = (unsigned *)((unsigned char *)valid + mask_bytes(batch, (size_t)n_frames, n_bins));
+        kp.doubt_flag = (unsigned *)((unsigned char *)kp.doubt32 + mask_bytes(batch, (size_t)n_frames, n_bins));
+    }
     const long total = (long)batch * n_bins * n_frames * 2;
     hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float4 *)d_X, Xs, batch, n_bins, (int)n_frames);
     HIP_TRY(hipGetLastError());
