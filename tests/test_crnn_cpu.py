@@ -567,3 +567,81 @@ def test_packed_parameters_stack_as_views_with_the_same_values_and_gradients():
     m64 = m.double()                                                                       # un-packs: stack_groups copies again
     assert not nn_ops._lie_stacked([m64.decoder.gru.weight_hh_l1, m64.decoder.gru.weight_hh_l1_reverse])
     torch.testing.assert_close(m64(x.double())['event_frame_logit'].float(), y1, rtol=1e-4, atol=1e-4)
+
+
+def test_dcase_rows_vectorised_equals_the_reference_loop():
+    """to_dcase_rows (round 6: one np.nonzero instead of the reference's 600-frame Python loop, models/interfaces.py:232-258) against a
+    literal restatement of that loop: same rows in the same order, 2021 and 2020 formats, the azimuth 180 -> -180 fold included."""
+    from salsa_amd.crnn.postprocess import to_dcase_rows
+
+    def loop(event_prob, doa_xyz, sed_threshold=0.3, n_classes=12, max_nframes_per_file=600, eval_version='2021'):
+        active = event_prob >= sed_threshold
+        x, y, z = doa_xyz[:, :n_classes], doa_xyz[:, n_classes:2 * n_classes], doa_xyz[:, 2 * n_classes:]
+        azi = np.around(np.arctan2(y, x) * 180.0 / np.pi)
+        ele = np.around(np.arctan2(z, np.sqrt(x ** 2 + y ** 2)) * 180.0 / np.pi)
+        rows = []
+        for t in range(max_nframes_per_file):
+            for c in np.where(active[t])[0]:
+                a = int(azi[t, c])
+                if a == 180:
+                    a = -180
+                rows.append([t, int(c), 0, a, int(ele[t, c])] if eval_version == '2021' else [t, int(c), a, int(ele[t, c])])
+        return rows
+    rng = np.random.RandomState(0)
+    n180 = 0
+    for k in range(12):
+        p = rng.rand(600, 12).astype(np.float32)
+        d = rng.randn(600, 36).astype(np.float32)
+        d[:, 12:24][rng.rand(600, 12) < 0.1] = 0.0                      # y = 0 ...
+        d[:, :12][rng.rand(600, 12) < 0.1] = -1.0                       # ... with x < 0: azimuth exactly 180
+        for ev in ('2021', '2020'):
+            got, want = to_dcase_rows(p, d, 0.5, eval_version=ev), loop(p, d, 0.5, eval_version=ev)
+            assert got == want
+        arr = to_dcase_rows(p, d, 0.5, as_array=True)
+        assert arr.dtype == np.int64 and arr.tolist() == want if ev == '2021' else True
+        n180 += sum(r[3] == -180 for r in loop(p, d, 0.5))
+    assert n180 > 50
+    assert to_dcase_rows(p * 0, d) == [] and to_dcase_rows(p * 0, d, as_array=True).shape == (0, 5)
+
+
+def test_pipelined_inference_engine_order_slots_and_stamps():
+    """crnn.infer.infer_pipelined on CPU tensors: every item answered once and in item order whatever the sub-batch size and
+    depth (ragged last sub-batch, depth 1 = serial, depth 3), slots reused without being overwritten before they are consumed,
+    one latency stamp per sub-batch with issue <= done."""
+    import torch
+    from salsa_amd.crnn.infer import infer_pipelined
+    n = 11
+    feats = torch.arange(n, dtype=torch.float32)
+    calls = []
+
+    def featurize(lo, hi):
+        calls.append((lo, hi))
+        return feats[lo:hi]
+
+    def forward(x):                                                     # item i: class i % 12 active in frame i, pointing along +x
+        b = x.shape[0]
+        prob = torch.zeros(b, 16, 12)
+        xyz = torch.zeros(b, 16, 36)
+        for j in range(b):
+            i = int(x[j])
+            prob[j, i % 16, i % 12] = 0.9
+            xyz[j, i % 16, i % 12] = 1.0
+        return prob, xyz
+    for sub, depth in ((4, 2), (3, 1), (2, 3), (16, 2)):
+        calls.clear()
+        stamps = []
+        rows = infer_pipelined(n, featurize, forward, sub_batch=sub, depth=depth, sed_threshold=0.5, n_label_frames=16, stamps=stamps)
+        assert [r for r in rows] == [[[i % 16, i % 12, 0, 0, 0]] for i in range(n)], (sub, depth)
+        assert calls == [(lo, min(n, lo + sub)) for lo in range(0, n, sub)]
+        assert sorted((a, b) for a, b, _, _ in stamps) == calls and all(t1 >= t0 for _, _, t0, t1 in stamps)
+
+
+def test_device_clip_synthesiser_is_seeded_and_distinct():
+    import torch
+    from salsa_amd.synth import synth_clips_device
+    a = synth_clips_device(2021, 3, 48000, device='cpu')
+    b = synth_clips_device(2021, 3, 48000, device='cpu')
+    c = synth_clips_device(2022, 2, 48000, device='cpu')
+    assert a.shape == (3, 4, 48000) and a.dtype == torch.float32 and torch.equal(a, b)
+    assert torch.equal(a[1], c[0]) and torch.equal(a[2], c[1])          # clip i of (seed0) = clip 0 of (seed0 + i): global indices shard freely
+    assert not torch.equal(a[0], a[1]) and float(a.abs().max()) > 1.0 and 0.005 < float(a[:, :, :100].std()) < 5.0
