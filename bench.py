@@ -10,7 +10,11 @@ shard across ranks with no collective on the data path (weak scaling: 32 clips p
 (box-to-box and run-to-run spread of a 24-ms region is several percent); every block's time is in `blocks_ms`.
 
 CRNN step (after the feature path, its own timed region) = forward + loss + backward + Adam on 32 chunks (7,640,200) per
-GPU, bf16 autocast, bucketed gradient all-reduce over RCCL for N > 1 (bench_crnn.train_bench, salsa_amd/crnn/grad_sync.py).
+GPU, bf16 autocast, bucketed gradient all-reduce over RCCL for N > 1 (bench_crnn.train_bench, salsa_amd/crnn/grad_sync.py);
+at N = 1 the same step on stock PyTorch-ROCm kernels is timed beside it (`crnn.torch_baseline`, a stated baseline).
+Further legs of the same line (reported, never `value`): `config4` = on-the-fly SALSA-MIC + augmentation + training step;
+`inference` = BASELINE config 5 at its real size, --infer-clips (1024) distinct 60-s clips sharded over the ranks through
+SALSA-FOA + CRNN forward + DCASE rows on the host, with per-clip latency percentiles (bench_crnn.infer_bench).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python bench.py --gpus 8            # no launcher needed: re-executes itself under torch.distributed.run, one rank per GPU

@@ -158,6 +158,8 @@ class _FilePipeline:
         self.slots = [dict(idx=i, ex=self.exs[i], n=None, s_in=torch.cuda.Stream(device=dev), s_run=torch.cuda.Stream(device=dev),
                            s_out=torch.cuda.Stream(device=dev)) for i in range(depth)]
         self.error = None
+        import threading
+        self.lock = threading.Lock()                 # (the pipeline of a parameter set is shared by every call in the process: one run at a time)
 
     def _buffers(self, sl, batch, n_samples):
         """Views of the slot's staging for (batch, n_samples); the flat pinned / device arrays behind them only ever GROW (a tree of
@@ -401,7 +403,7 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
         todo = todo[lo:hi]
     if USE_FILE_PIPELINE and todo:
         pipe = _pipeline_for(ex)
-        with torch.cuda.device(ex.device):
+        with pipe.lock, torch.cuda.device(ex.device):
             pipe.run(todo, audio_dir, feature_dir, fs, batch_size, stats)
         return
     pending = {}                                            # n_samples -> [(count, fn, audio)]
