@@ -114,6 +114,18 @@ def compute_scaler(feature_dir: str, audio_format: str) -> None:
     _log.info('scaler: %.3f s', timer() - start_time)
 
 
+def write_scaler_from_sums(feature_dir: str, audio_format: str, sums, n_frames: int) -> str:
+    """compute_scaler's result from statistics accumulated on the device while the dev split was extracted: mean = sum / n,
+    std = sqrt(sum of squares / n - mean^2) (population, like StandardScaler.var_), both (4,1,F) float32 -> the scaler file."""
+    h = sums.detach().cpu().numpy()
+    mean = h[0] / n_frames
+    std = np.sqrt(np.maximum(h[1] / n_frames - mean * mean, 0.0))
+    scaler_path = os.path.join(feature_dir, audio_format + '_feature_scaler.h5')
+    written = sio.save_arrays(scaler_path, mean=mean[:, None, :].astype(np.float32), std=std[:, None, :].astype(np.float32))
+    _log.info('scaler: from the device statistics of %d frames -> %s', n_frames, written)
+    return written
+
+
 def _parse(data_config):
     with open(data_config, 'r') as stream:
         cfg = yaml.safe_load(stream)
@@ -198,8 +210,12 @@ class _FilePipeline:
                 if self.stop.is_set():
                     return _STOP
 
-    def run(self, todo, audio_dir, feature_dir, fs, batch_size, stats=None):
-        """todo: [(count, file name)] in order.  Writes <feature_dir>/<feature_name(fn)> for every clip."""
+    def run(self, todo, audio_dir, feature_dir, fs, batch_size, stats=None, scaler=None):
+        """todo: [(count, file name)] in order.  Writes <feature_dir>/<feature_name(fn)> for every clip.
+        scaler: a dict that receives 'sums' (float64 [2][4][F] device tensor: sum / sum of squares of the spectrogram channels over
+        every frame extracted) and 'n' (frames) -- compute_scaler's statistics (:204-262) taken from the features while they are still
+        on the device (salsa_scaler_accumulate on the slot's own stream into the slot's own sums, added at the end), instead of reading
+        every feature file back."""
         import queue
         import threading
         import time
@@ -314,6 +330,13 @@ class _FilePipeline:
                 sl['s_run'].wait_stream(sl['s_in'])
                 with torch.cuda.stream(sl['s_run']):
                     sl['ex'].extract(sl['d_in'][:b], out=sl['d_out'][:b])
+                    if scaler is not None:
+                        from .extractor import scaler_accumulate
+                        F_ = sl['d_out'].shape[3]
+                        if sl.get('sums') is None or sl['sums'].shape[2] != F_:
+                            sl['sums'] = torch.zeros((2, 4, F_), dtype=torch.float64, device=sl['ex'].device)
+                        scaler_accumulate(sl['d_out'][:b], sl['sums'])
+                        scaler['n'] = scaler.get('n', 0) + b * sl['d_out'].shape[2]
                 sl['s_out'].wait_stream(sl['s_run'])
                 with torch.cuda.stream(sl['s_out']):
                     sl['h_out'][:b].copy_(sl['d_out'][:b], non_blocking=True)
@@ -332,6 +355,12 @@ class _FilePipeline:
         if self.error:
             e, self.error = self.error, None
             raise e
+        if scaler is not None:
+            torch.cuda.synchronize(self.exs[0].device)
+            for sl in self.slots:
+                if sl.get('sums') is not None:
+                    scaler['sums'] = sl['sums'].clone() if scaler.get('sums') is None else scaler['sums'] + sl['sums']
+                    sl['sums'].zero_()
         if stats is not None:
             t_wait['wall'] = time.perf_counter() - t_wait['wall']
             stats.update(batches=n_batches, read_s=t_read[0], write_s=t_write[0], **t_wait)
@@ -364,6 +393,7 @@ def release_file_pipelines():
 SLOT_CLIPS = 8     # clips per pipeline slot: small slots overlap read / copy / extract / copy / write sooner and pin 4x less host memory
                    # than 32-clip ones; the device does 8 x 60-s clips in ~0.45 ms, far below a slot's 8 ms of PCIe time
 USE_FILE_PIPELINE = os.environ.get('SALSA_FILE_PIPELINE', '1') != '0'
+FUSED_SCALER = os.environ.get('SALSA_FUSED_SCALER', '1') != '0'   # task='feature_scaler': the scaler from device statistics (0: re-read the files)
 
 
 def _rmtree_parallel(path, threads: int = 8):
@@ -387,7 +417,7 @@ def _rmtree_parallel(path, threads: int = 8):
     shutil.rmtree(path, ignore_errors=True)
 
 
-def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear=True, stats=None):
+def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear=True, stats=None, scaler=None):
     """Extract the clips of one split directory, batching clips of equal length (one device round trip per batch, overlapped
     with its neighbours' and with the file reads / writes: _FilePipeline).
     shard = (rank, world): this process takes a contiguous range of the sorted file list (salsa_amd.distributed)."""
@@ -404,8 +434,10 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
     if USE_FILE_PIPELINE and todo:
         pipe = _pipeline_for(ex)
         with pipe.lock, torch.cuda.device(ex.device):
-            pipe.run(todo, audio_dir, feature_dir, fs, batch_size, stats)
+            pipe.run(todo, audio_dir, feature_dir, fs, batch_size, stats, scaler)
         return
+    if scaler is not None:
+        scaler['unavailable'] = True                       # (serial loop / empty split: compute_scaler reads the files, as the reference does)
     pending = {}                                            # n_samples -> [(count, fn, audio)]
 
     def flush(items):
@@ -459,13 +491,19 @@ def extract_features(data_config: str = 'configs/tnsse2021_salsa_feature_config.
         ex = SalsaExtractor(fs=fs, n_fft=n_fft, hop_len=hop_length, win_len=win_length, fmin_doa=fmin_doa,
                             fmax_doa=fmax_doa, cond_num=cond_num, n_hopframes=n_hopframes, is_tracking=is_tracking,
                             is_compress_high_freq=is_compress_high_freq, audio_format=audio_format)
+        scaler = {} if (task == 'feature_scaler' and FUSED_SCALER) else None
         for split in splits:
             _log.info('split %s: extracting on %s', split, ex.device)
             start_time = timer()
             audio_dir = os.path.join(cfg['data_dir'], split)
             feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description, split)
-            _extract_split(ex, audio_dir, feature_dir, fs, batch_size)
+            # the scaler is over the files of <format>_dev (:214-215): its statistics are taken while that split is extracted
+            _extract_split(ex, audio_dir, feature_dir, fs, batch_size, scaler=scaler if split.endswith('_dev') else None)
             _log.info('split %s: done in %.3f s', split, timer() - start_time)
+        if scaler is not None and scaler.get('sums') is not None and not scaler.get('unavailable'):
+            feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
+            write_scaler_from_sums(feature_dir, audio_format, scaler['sums'], scaler['n'])
+            return
     if task in ['feature_scaler', 'scaler']:
         feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
         compute_scaler(feature_dir=feature_dir, audio_format=audio_format)

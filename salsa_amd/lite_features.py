@@ -28,13 +28,19 @@ def extract_features(data_config: str = 'configs/tnsse2021_salsa_lite_feature_co
         from .extractor import SalsaExtractor
         ex = SalsaExtractor(fs=fs, n_fft=n_fft, hop_len=hop_length, win_len=win_length, fmin_doa=fmin_doa,
                             fmax_doa=fmax_doa, audio_format='mic', feature_type=feature_type)
+        from . import features as _f
+        scaler = {} if (task == 'feature_scaler' and _f.FUSED_SCALER) else None    # (as features.extract_features: statistics taken on the device)
         for split in splits:
             _log.info('split %s: extracting on %s', split, ex.device)
             start_time = timer()
             audio_dir = os.path.join(cfg['data_dir'], split)
             feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description, split)
-            _extract_split(ex, audio_dir, feature_dir, fs, batch_size)
+            _extract_split(ex, audio_dir, feature_dir, fs, batch_size, scaler=scaler if split.endswith('_dev') else None)
             _log.info('split %s: done in %.3f s', split, timer() - start_time)
+        if scaler is not None and scaler.get('sums') is not None and not scaler.get('unavailable'):
+            feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
+            _f.write_scaler_from_sums(feature_dir, audio_format, scaler['sums'], scaler['n'])
+            return
     if task in ['feature_scaler', 'scaler']:
         feature_dir = os.path.join(cfg['feature_dir'], feature_type, audio_format, feature_description)
         compute_scaler(feature_dir=feature_dir, audio_format=audio_format)

@@ -416,6 +416,17 @@ def test_extract_features_harness_reproduces_reference_tree(dev, oracle, tmp_pat
             np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
         n_checked += 1
     assert n_checked == len(a)
+    # round 6: task='feature_scaler' takes the scaler's statistics from the features while they are on the device; the file-based
+    # compute_scaler (what task='scaler' alone runs, and what the reference does) must give the same file
+    from salsa_amd.features import compute_scaler
+    desc = [d for d in os.listdir(os.path.join(feat_dir, 'salsa', fmt))][0]
+    root = os.path.join(feat_dir, 'salsa', fmt, desc)
+    fused = sio.load_arrays(os.path.join(root, fmt + '_feature_scaler.h5'))
+    compute_scaler(feature_dir=root, audio_format=fmt)
+    files = sio.load_arrays(os.path.join(root, fmt + '_feature_scaler.h5'))
+    for k in ('mean', 'std'):
+        assert fused[k].shape == files[k].shape == (4, 1, 200) and fused[k].dtype == np.float32
+        np.testing.assert_allclose(fused[k], files[k], rtol=2e-6, atol=2e-6)
 
 
 @pytest.mark.timeout(120)
