@@ -102,6 +102,15 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
             dt = time.perf_counter() - t0
             res[name] = {'s': round(dt, 3), 'audio_s_per_s': round(secs / dt, 1)}
         features.USE_FILE_PIPELINE = True
+        # the reference's default task: features AND the scaler (round 6: its statistics are taken on the device while the dev split
+        # is extracted; SALSA_FUSED_SCALER=0 / the second figure: compute_scaler reads every feature file back, as the reference does)
+        for name, flag in (('feature_scaler', True), ('feature_scaler_rereading_files', False)):
+            features.FUSED_SCALER = flag
+            t0 = time.perf_counter()
+            features.extract_features(data_config=cfg_path, task='feature_scaler', batch_size=batch)
+            dt = time.perf_counter() - t0
+            res[name] = {'s': round(dt, 3), 'audio_s_per_s': round(secs / dt, 1)}
+        features.FUSED_SCALER = True
         # the file system's share: read every clip, write every feature file, nothing else (one thread)
         feat_dir = os.path.join(tmp, 'feat')
         files = [os.path.join(r, f) for r, _, fs_ in os.walk(feat_dir) for f in fs_]
