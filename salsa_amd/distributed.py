@@ -90,18 +90,36 @@ def extract_features_sharded(data_config: str, cond_num: float = 5, n_hopframes:
                             fmax_doa=fmax_doa, cond_num=cond_num, n_hopframes=n_hopframes, is_tracking=is_tracking,
                             is_compress_high_freq=is_compress_high_freq, audio_format=audio_format,
                             feature_type=feature_type)
+        from . import features as _f
+        fused = {} if (task == 'feature_scaler' and _f.FUSED_SCALER) else None   # this rank's scaler statistics, taken on its device
         for split in (audio_format + '_dev', audio_format + '_eval'):
             feature_dir = os.path.join(root, split)
             if rank == 0:
-                import shutil
-                shutil.rmtree(feature_dir, ignore_errors=True)
+                _f._rmtree_parallel(feature_dir)
                 os.makedirs(feature_dir, exist_ok=True)
             if world > 1:
                 dist.barrier()
             _extract_split(ex, os.path.join(cfg['data_dir'], split), feature_dir, fs, batch_size,
-                           shard=(rank, world), clear=False)
+                           shard=(rank, world), clear=False, scaler=fused if split.endswith('_dev') else None)
         if world > 1:
             dist.barrier()
+        if fused is not None:
+            # every rank must take the same branch: a rank with an empty shard (or on the serial loop) has no sums of its own
+            ok = torch.tensor([0 if fused.get('unavailable') else 1], dtype=torch.int32)
+            if world > 1:
+                okd = ok.to(ex.device) if dist.get_backend() == 'nccl' else ok
+                dist.all_reduce(okd, op=dist.ReduceOp.MIN)
+                ok = okd.cpu()
+            if int(ok.item()) == 1:
+                F = ex.output_shape(ex.params.n_fft)[2]
+                h = fused['sums'].detach().cpu().numpy() if fused.get('sums') is not None else np.zeros((2, 4, F))
+                device = ex.device if (dist.is_initialized() and dist.get_backend() == 'nccl') else None
+                mean, std = scaler_allreduce(fused.get('n', 0), h[0], h[1], F, device=device)
+                if rank == 0:
+                    sio.save_arrays(os.path.join(root, audio_format + '_feature_scaler.h5'), mean=mean, std=std)
+                if world > 1:
+                    dist.barrier()
+                return
     if task in ['feature_scaler', 'scaler']:
         dev_dir = os.path.join(root, audio_format + '_dev')
         files = shard_list(sio.feature_files(dev_dir), rank, world)
