@@ -113,7 +113,7 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
         features.FUSED_SCALER = True
         # the file system's share: read every clip, write every feature file, nothing else (one thread)
         feat_dir = os.path.join(tmp, 'feat')
-        files = [os.path.join(r, f) for r, _, fs_ in os.walk(feat_dir) for f in fs_]
+        files = [os.path.join(r, f) for r, _, fs_ in os.walk(feat_dir) for f in fs_ if 'feature_scaler' not in f]   # (clips' files, not the scaler)
         one = sio.load_arrays(files[0])['feature']
         t0 = time.perf_counter()
         for i in range(n_clips):
