@@ -93,7 +93,7 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
         cfg_path = os.path.join(tmp, 'cfg.yml')
         yaml.safe_dump(cfg, open(cfg_path, 'w'))
         secs = n_clips * n_samples / 24000.0
-        res = {'clips': n_clips, 'tree': 'float32 .npy clips on %s, feature files %s' % ('tmpfs' if base else 'the temp dir', 'HDF5' if sio.HAVE_H5PY else 'raw .npy (no h5py here)')}
+        res = {'clips': n_clips, 'tree': 'float32 .npy clips on %s, feature files %s' % ('tmpfs' if base else 'the temp dir', ('HDF5 (h5py)' if sio.HAVE_H5PY else 'HDF5 (libhdf5 %s through ctypes)' % sio._hdf5.version()) if sio.HAVE_HDF5 else 'raw .npy (no HDF5 library here)')}
         for name, flag in (('pipelined', True), ('serial', False)):
             features.USE_FILE_PIPELINE = flag
             features.extract_features(data_config=cfg_path, task='feature', batch_size=batch)        # warm-up: plans, pinned slots

@@ -1,9 +1,10 @@
 """File I/O either side of the hot path: WAV in (the reference uses librosa.load, salsa_feature_extraction.py:353),
 feature / scaler files out (h5py 'feature', 'mean', 'std' datasets, :380-382, :253-256).
 
-h5py is not installed in the build image or on the GPU box.  When it is importable the files are real HDF5 with the
-reference's dataset names, so the reference's Database (dataset/database.py:87-96, :193-195) reads them unchanged;
-otherwise a clip's ``'feature'`` array goes to ``<name>.npy`` next to where the ``.h5`` would be (round 6: one header + one raw
+The files are real HDF5 with the reference's dataset names -- so the reference's Database (dataset/database.py:87-96, :193-195)
+reads them unchanged -- whenever an HDF5 library can be reached: ``h5py`` if it is importable in this interpreter, else ``libhdf5``
+itself through ctypes (salsa_amd/_hdf5.py; the ROCm image carries HDF5 1.10.6 under /opt/conda/lib, and tests/test_host_logic_cpu.py
+reads the files back with that conda's h5py 3.3.0 -- the reader the reference uses).  With neither, a clip's ``'feature'`` array goes to ``<name>.npy`` next to where the ``.h5`` would be (round 6: one header + one raw
 write of the pinned buffer -- the ``.npz`` twin of rounds 1 - 5 spent 27 of its 39 ms per clip in the zip layer's CRC-32) and
 multi-array files (the scaler's ``'mean'`` / ``'std'``) to ``<name>.npz``; load_* reads all three.
 """
@@ -16,6 +17,9 @@ try:
     HAVE_H5PY = True
 except Exception:  # pragma: no cover - depends on the image
     HAVE_H5PY = False
+from . import _hdf5   # noqa: E402  (round 6: the HDF5 C library itself through ctypes, when h5py is not importable here but libhdf5 exists)
+
+HAVE_HDF5 = HAVE_H5PY or _hdf5.available()    # real .h5 files are written / read; False: the numpy twins
 
 
 def load_audio(path: str, sr: int) -> np.ndarray:
@@ -109,6 +113,9 @@ def save_arrays(path_h5: str, **arrays) -> str:
             for k, v in arrays.items():
                 hf.create_dataset(k, data=v, dtype=np.float32)
         return path_h5
+    if _hdf5.available():
+        _hdf5.write(path_h5, **arrays)
+        return path_h5
     if set(arrays) == {'feature'}:
         out = _alt_npy(path_h5)
         _write_npy(out, np.asarray(arrays['feature'], np.float32))
@@ -131,10 +138,16 @@ def load_arrays(path: str) -> dict:
         import h5py
         with h5py.File(path, 'r') as hf:
             return {k: hf[k][:] for k in hf.keys()}
+    if os.path.exists(path) and _hdf5.available():
+        try:
+            return _hdf5.read(path)
+        except IOError:
+            if not (os.path.exists(_alt_npy(path)) or os.path.exists(_alt(path))):
+                raise
     if os.path.exists(_alt_npy(path)):
         return {'feature': np.load(_alt_npy(path))}
     if os.path.exists(path) and not os.path.exists(_alt(path)):
-        raise RuntimeError('{} is HDF5 and h5py is not installed here (no .npy / .npz twin next to it)'.format(path))
+        raise RuntimeError('{} is HDF5 and neither h5py nor libhdf5 can be loaded here (no .npy / .npz twin next to it)'.format(path))
     z = np.load(_alt(path))
     return {k: z[k] for k in z.files}
 
@@ -142,7 +155,7 @@ def load_arrays(path: str) -> dict:
 def feature_files(feature_dir: str):
     """Sorted feature files of a split directory, ONE name per clip: when several containers of a clip are present the
     ``.h5`` is listed if h5py can read it, else the ``.npy``, else the ``.npz``."""
-    rank = {'.h5': 0 if HAVE_H5PY else 3, '.npy': 1, '.npz': 2}
+    rank = {'.h5': 0 if HAVE_HDF5 else 3, '.npy': 1, '.npz': 2}
     by_stem = {}
     for f in os.listdir(feature_dir):
         stem, ext = os.path.splitext(f)

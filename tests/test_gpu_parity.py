@@ -427,6 +427,31 @@ def test_extract_features_harness_reproduces_reference_tree(dev, oracle, tmp_pat
     for k in ('mean', 'std'):
         assert fused[k].shape == files[k].shape == (4, 1, 200) and fused[k].dtype == np.float32
         np.testing.assert_allclose(fused[k], files[k], rtol=2e-6, atol=2e-6)
+    # the tree as the REFERENCE reads it: h5py (the image's conda interpreter has 3.3.0), hf['feature'][:] / hf['mean'][:] (database.py:
+    # 87-96, :193-195) on the files the harness wrote through libhdf5
+    from test_host_logic_cpu import CONDA_PY, _conda_h5py
+    if sio.HAVE_HDF5 and not sio.HAVE_H5PY and _conda_h5py():
+        import hashlib
+        import json
+        import subprocess
+        dev_dir = os.path.join(root, fmt + '_dev')
+        names = sio.feature_files(dev_dir)
+        assert names and all(n.endswith('.h5') for n in names)
+        code = ("import h5py, sys, json, hashlib\n"
+                "out = {}\n"
+                "for fn in sys.argv[1:]:\n"
+                "    with h5py.File(fn, 'r') as hf:\n"
+                "        out[fn] = {k: [list(hf[k].shape), str(hf[k].dtype), hashlib.sha256(hf[k][:].tobytes()).hexdigest()] for k in hf.keys()}\n"
+                "print(json.dumps(out))\n")
+        paths = [os.path.join(dev_dir, names[0]), os.path.join(root, fmt + '_feature_scaler.h5')]
+        r = subprocess.run([CONDA_PY, '-c', code] + paths, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1000:]
+        seen = json.loads(r.stdout.strip().splitlines()[-1])
+        for pth in paths:
+            mine = sio.load_arrays(pth)
+            assert set(seen[pth]) == set(mine)
+            for k, v in mine.items():
+                assert seen[pth][k] == [list(v.shape), 'float32', hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()], (pth, k)
 
 
 @pytest.mark.timeout(120)
