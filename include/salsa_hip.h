@@ -18,6 +18,7 @@
  *   Database.load_chunk_data normalisation, dataset/database.py:197-202           salsa_normalize_batch
  *   SeldDataset train transforms, utilities/transforms.py (datamodule.py:45-82)   salsa_augment_batch
  *   SalsaFeatures / SalsaLiteFeatures.__call__, contrib/salsa_flexible.py:237-265 (+ :286-400)   salsa_extract_batch with SALSA_FLAG_FLEX, salsa_to_freq_major
+ *   librosa.load(sr=fs)'s resampling of a file of another rate, dataset/salsa_feature_extraction.py:353   salsa_resample_batch
  *
  * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
  * message of the calling thread's last failure.  Device pointers are caller-owned; work is enqueued asynchronously
@@ -226,6 +227,20 @@ int salsa_extract_multichannel(salsa_plan *plan, const float *d_audio, int n_cha
  * kernel inlines (hardware v_log_f32 times a constant); exported so a test can bound its error over the whole float32
  * exponent range instead of over whatever dynamic range a test clip happens to have. */
 int salsa_selftest_decibel(const float *d_power, float *d_db, int64_t n, void *hip_stream);
+
+/* The resampling step of the reference's loader: librosa.load(path, sr=fs, mono=False, dtype=float32)
+ * (dataset/salsa_feature_extraction.py:353, salsa_lite_feature_extraction.py:93) on a file whose native rate is not fs ->
+ * librosa 0.8.0 core/audio.py::resample(res_type='kaiser_best', fix=True) -> resampy 0.2.2 (requirements.yml:181)
+ * resample / interpn.py::resample_f.  d_x: float32 [n_rows][n_in] (one row per channel of a clip); d_y: float32
+ * [n_rows][n_out_fixed]: n_out = int(n_in * sample_ratio) samples computed (each tap float32(float64(y) + weight * x), left
+ * wing then right wing: the sequential reference loop bit for bit), then zeros up to n_out_fixed = ceil(n_in * sample_ratio)
+ * (librosa's fix_length).  d_interp_win / d_interp_delta: float64 [n_win], the filter half-window (scaled by sample_ratio when
+ * < 1) and its first differences; num_table: table entries per zero crossing (512 for kaiser_best); d_time_register: float64
+ * [n_out], the reference's sequentially accumulated read positions (0, 1/ratio, 1/ratio + 1/ratio, ...).  salsa_amd/resample.py
+ * builds all three. */
+int salsa_resample_batch(const float *d_x, int n_rows, int64_t n_in, float *d_y, int64_t n_out, int64_t n_out_fixed, double sample_ratio,
+                         const double *d_interp_win, const double *d_interp_delta, int n_win, int num_table,
+                         const double *d_time_register, void *hip_stream);
 
 #ifdef __cplusplus
 }

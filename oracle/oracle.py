@@ -42,6 +42,7 @@ def lib():
         L.salsa_oracle_flex_bins.argtypes = [C.c_int] * 5 + [ip, ip, ip]
         L.salsa_oracle_flex.argtypes = [fp, C.c_int, C.c_long] + [C.c_int] * 9 + [C.c_double, C.c_int, C.c_int,
                                                                                    C.c_double, fp, dp]
+        L.salsa_oracle_resample.argtypes = [fp, C.c_int, C.c_long, fp, C.c_long, C.c_long, C.c_double, dp, dp, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -209,3 +210,40 @@ def flexible(audio, kind='salsa', fs=24000, stft_winsize=512, hop_length=300, fm
     if rc != F:
         raise ValueError('salsa_oracle_flex failed: %d' % rc)
     return np.concatenate([spec.astype(np.float64), spat])
+
+
+def kaiser_best_filter():
+    """resampy 0.2.2 filters.py: the 'kaiser_best' table = sinc_window(num_zeros=64, precision=9, window=kaiser(beta=14.769656459379492),
+    rolloff=0.9475937167399596) -> (half window float64 [64 * 512 + 1], 512).  (resampy ships it precomputed; regenerated here.)"""
+    import scipy.signal
+    num_zeros, precision, beta, rolloff = 64, 9, 14.769656459379492, 0.9475937167399596
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    taper = scipy.signal.windows.kaiser(2 * n + 1, beta)[n:]
+    return taper * sinc_win, num_bits
+
+
+def librosa_resample(y, orig_sr, target_sr):
+    """librosa 0.8.0 core/audio.py::resample(y, orig_sr, target_sr, res_type='kaiser_best', fix=True, scale=False) of a float32
+    (..., n) array -- what librosa.load(sr=target_sr) applies to a file of another rate (salsa_feature_extraction.py:353).
+    PARITY UNPINNED (librosa / resampy absent): see salsa_oracle.c."""
+    y = np.ascontiguousarray(y, np.float32)
+    if orig_sr == target_sr:
+        return y
+    ratio = float(target_sr) / orig_sr
+    n_in = y.shape[-1]
+    n_samples = int(np.ceil(n_in * ratio))                 # librosa: fix_length target
+    n_out = int(n_in * ratio)                              # resampy core.py: shape[axis] = int(shape[axis] * sample_ratio)
+    interp_win, num_table = kaiser_best_filter()
+    interp_win = interp_win.copy()
+    if ratio < 1:
+        interp_win *= ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    x2 = y.reshape(-1, n_in)
+    out = np.zeros((x2.shape[0], n_samples), np.float32)
+    rc = lib().salsa_oracle_resample(_fp(x2), x2.shape[0], n_in, _fp(out), n_out, n_samples, ratio, _dp(interp_win), _dp(interp_delta),
+                                     interp_win.shape[0], num_table)
+    assert rc == 0
+    return out.reshape(y.shape[:-1] + (n_samples,))

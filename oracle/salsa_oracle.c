@@ -637,3 +637,57 @@ int salsa_oracle_flex(const float *audio, int C, long N, int fs, int n_fft, int 
     free(st);
     return F;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Resampling on load: librosa.load(path, sr=fs, mono=False, dtype=np.float32) (dataset/salsa_feature_extraction.py:353,
+ * salsa_lite_feature_extraction.py:93) of a file whose native rate is not fs -> librosa 0.8.0 core/audio.py::resample
+ * (res_type='kaiser_best', fix=True) -> resampy 0.2.2 (requirements.yml:181).  THIRD-PARTY ARITHMETIC, absent from
+ * /root/reference and from the image: PARITY UNPINNED for this function -- restated from resampy's published
+ * interpn.py::resample_f (a numba loop), whose order is kept: for each output sample, the left wing of the filter from
+ * sample n = int(time_register) downwards, then the right wing from n + 1 upwards; the filter value is linearly
+ * interpolated between table entries; y (float32, the dtype of x) is updated in place, i.e. rounded to float32 after
+ * every tap; time_register accumulates 1 / sample_ratio in float64.  x: [n_rows][n_in]; y: [n_rows][n_fix] with
+ * n_out = int(n_in * sample_ratio) computed samples followed by zeros (librosa util.fix_length to
+ * ceil(n_in * sample_ratio)).  interp_win / interp_delta / num_table: resampy core.py::resample's locals (the caller
+ * scales the window by sample_ratio when < 1 and takes np.diff, as core.py does). */
+int salsa_oracle_resample(const float *x, int n_rows, long n_in, float *y, long n_out, long n_fix, double sample_ratio,
+                          const double *interp_win, const double *interp_delta, int nwin, int num_table)
+{
+    if (!x || !y || n_rows <= 0 || n_in <= 0 || n_out < 0 || n_fix < n_out || !(sample_ratio > 0.0)) return -1;
+    const double scale = sample_ratio < 1.0 ? sample_ratio : 1.0;
+    const double time_increment = 1.0 / sample_ratio;
+    const int index_step = (int)(scale * num_table);
+    if (index_step < 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int r = 0; r < n_rows; r++) {
+        const float *xr = x + (long)r * n_in;
+        float *yr = y + (long)r * n_fix;
+        double time_register = 0.0;
+        for (long t = 0; t < n_fix; t++) yr[t] = 0.f;
+        for (long t = 0; t < n_out; t++) {
+            const long n = (long)time_register;                       /* top bits: index into the input */
+            double frac = scale * (time_register - (double)n);
+            double index_frac = frac * num_table;
+            int offset = (int)index_frac;
+            double eta = index_frac - offset;
+            long m = (nwin - offset) / index_step;
+            long i_max = n + 1 < m ? n + 1 : m;
+            for (long i = 0; i < i_max; i++) {                        /* left wing */
+                const double weight = interp_win[offset + i * index_step] + eta * interp_delta[offset + i * index_step];
+                yr[t] = (float)((double)yr[t] + weight * (double)xr[n - i]);
+            }
+            frac = scale - frac;                                      /* invert P */
+            index_frac = frac * num_table;
+            offset = (int)index_frac;
+            eta = index_frac - offset;
+            m = (nwin - offset) / index_step;
+            long k_max = n_in - n - 1 < m ? n_in - n - 1 : m;
+            for (long k = 0; k < k_max; k++) {                        /* right wing */
+                const double weight = interp_win[offset + k * index_step] + eta * interp_delta[offset + k * index_step];
+                yr[t] = (float)((double)yr[t] + weight * (double)xr[n + k + 1]);
+            }
+            time_register += time_increment;
+        }
+    }
+    return 0;
+}

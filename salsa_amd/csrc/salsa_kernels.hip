@@ -1958,6 +1958,57 @@ __global__ __launch_bounds__(256) void to_freq_major_kernel(const float *__restr
         if (f0 + i < F && t0 + lx < T) dst[(long)(f0 + i) * T + t0 + lx] = (double)tile[lx][i];
 }
 
+// ------------------------------------------------------------------------------------------------------------- resampling
+// The resampling step of the reference's loader: librosa.load(path, sr=fs) (salsa_feature_extraction.py:353, lite :93) on a
+// file of another native rate calls librosa 0.8.0 core/audio.py::resample -> resampy 0.2.2 (requirements.yml:181)
+// resample(x, sr_orig, sr_new, filter='kaiser_best'): a windowed-sinc interpolator whose inner loop (resampy/interpn.py
+// ::resample_f, numba) walks the filter's left wing from sample n = int(time_register) downwards and its right wing from
+// n + 1 upwards, with the filter linearly interpolated between table entries and the float32 output element updated in
+// place -- i.e. every tap is `y = float32(float64(y) + weight * float64(x))`, left wing first.  One thread per output
+// sample does exactly that sequence (no FMA contraction), so the result is the sequential loop's bit for bit.  The
+// filter table, its first differences and the time registers (a sequential float64 accumulation in the reference) are
+// the caller's: salsa_amd/resample.py builds them once per (rate pair, length).  Bandwidth is irrelevant here (n_out x
+// ~2 * 64 / scale taps from L2-resident tables): it is a loader step, not the hot path.
+__global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ x, float *__restrict__ y, long n_in, long n_out,
+                                                       long n_fix, const double *__restrict__ win, const double *__restrict__ delta,
+                                                       int nwin, int num_table, double scale, int index_step,
+                                                       const double *__restrict__ treg)
+{
+#pragma clang fp contract(off)
+    const long t = blockIdx.x * 256L + threadIdx.x;
+    if (t >= n_fix) return;
+    const long row = blockIdx.y;
+    const float *xr = x + row * n_in;
+    float acc = 0.f;                                     // (t >= n_out: librosa's fix_length pads with zeros)
+    if (t < n_out) {
+        const double tr = treg[t];
+        const long n = (long)tr;
+        double frac = scale * (tr - (double)n);
+        double index_frac = frac * (double)num_table;
+        int offset = (int)index_frac;
+        double eta = index_frac - (double)offset;
+        long m = (nwin - offset) / index_step;
+        const long i_max = n + 1 < m ? n + 1 : m;
+        for (long i = 0; i < i_max; i++) {
+            const long idx = offset + i * index_step;
+            const double w = win[idx] + eta * delta[idx];
+            acc = (float)((double)acc + w * (double)xr[n - i]);
+        }
+        frac = scale - frac;
+        index_frac = frac * (double)num_table;
+        offset = (int)index_frac;
+        eta = index_frac - (double)offset;
+        m = (nwin - offset) / index_step;
+        const long k_max = n_in - n - 1 < m ? n_in - n - 1 : m;
+        for (long k = 0; k < k_max; k++) {
+            const long idx = offset + k * index_step;
+            const double w = win[idx] + eta * delta[idx];
+            acc = (float)((double)acc + w * (double)xr[n + k + 1]);
+        }
+    }
+    y[row * n_fix + t] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------------------ augmentation
 // The reference's SALSA training augmentation (utilities/transforms.py; recipe in dataset/datamodule.py:45-52, :73-82) as
 // ONE gather pass over a feature batch [B][7][T][F]: channel swap (FOA :394-437 / MIC :469-523, applied in the reference's
@@ -2885,6 +2936,24 @@ int salsa_to_freq_major(const float *d_feat, int64_t n_rows, int64_t n_frames, i
         return fail(SALSA_EINVAL, "salsa_to_freq_major: bad argument%s");
     dim3 grid((unsigned)((n_freq + 63) / 64), (unsigned)((n_frames + 63) / 64), (unsigned)n_rows);
     hipLaunchKernelGGL(to_freq_major_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, d_feat, d_out, (int)n_frames, n_freq);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_resample_batch(const float *d_x, int n_rows, int64_t n_in, float *d_y, int64_t n_out, int64_t n_out_fixed, double sample_ratio,
+                         const double *d_interp_win, const double *d_interp_delta, int n_win, int num_table,
+                         const double *d_time_register, void *hip_stream)
+{
+    if (!d_x || !d_y || !d_interp_win || !d_interp_delta || !d_time_register || n_rows <= 0 || n_rows > 65535 || n_in <= 0 ||
+        n_out < 0 || n_out_fixed < n_out || n_out_fixed <= 0 || !(sample_ratio > 0.0) || n_win <= 0 || num_table <= 0 ||
+        (n_out_fixed + 255) / 256 >= INT32_MAX)
+        return fail(SALSA_EINVAL, "salsa_resample_batch: bad argument%s");
+    const double scale = sample_ratio < 1.0 ? sample_ratio : 1.0;          // resampy/interpn.py: scale = min(1.0, sample_ratio)
+    const int index_step = (int)(scale * (double)num_table);              //                     index_step = int(scale * num_table)
+    if (index_step < 1) return fail(SALSA_EINVAL, "salsa_resample_batch: sample_ratio * num_table < 1%s");
+    dim3 grid((unsigned)((n_out_fixed + 255) / 256), (unsigned)n_rows);
+    hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, d_x, d_y, (long)n_in, (long)n_out, (long)n_out_fixed,
+                       d_interp_win, d_interp_delta, n_win, num_table, scale, index_step, d_time_register);
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }

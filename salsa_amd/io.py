@@ -23,16 +23,15 @@ HAVE_HDF5 = HAVE_H5PY or _hdf5.available()    # real .h5 files are written / rea
 
 
 def load_audio(path: str, sr: int) -> np.ndarray:
-    """-> (n_channels, n_samples) float32 in [-1, 1), like librosa.load(path, sr=sr, mono=False, dtype=float32) on a
-    file whose native rate is ``sr`` (the TNSSE2021 clips are 24 kHz).  librosa.load would RESAMPLE a file of another
-    rate (salsa_feature_extraction.py:353); this loader raises instead -- resample such files beforehand."""
+    """-> (n_channels, n_samples) float32 in [-1, 1), like librosa.load(path, sr=sr, mono=False, dtype=float32)
+    (salsa_feature_extraction.py:353).  A WAV file whose native rate is not ``sr`` is RESAMPLED as librosa does ('kaiser_best',
+    result fixed to ceil(n * sr / native) samples) -- on the device (salsa_amd/resample.py -> salsa_resample_batch; round 6); the
+    TNSSE2021 clips are native 24 kHz and never take that branch.  ``.npy`` clips carry no rate and are taken as ``sr``."""
     if path.endswith('.npy'):
         a = np.load(path)
         return np.ascontiguousarray(a, dtype=np.float32)
     from scipy.io import wavfile
     rate, data = wavfile.read(path)
-    if rate != sr:
-        raise ValueError('{}: sample rate {} != configured fs {} (resampling is not supported)'.format(path, rate, sr))
     if data.ndim == 1:
         data = data[:, None]
     if data.dtype == np.int16:
@@ -43,12 +42,16 @@ def load_audio(path: str, sr: int) -> np.ndarray:
         x = (data.astype(np.float32) - 128.0) / 128.0
     else:
         x = data.astype(np.float32)
-    return np.ascontiguousarray(x.T)
+    x = np.ascontiguousarray(x.T)
+    if rate != sr:
+        from . import resample
+        x = resample.resample_host_array(x, int(rate), int(sr))
+    return x
 
 
 def audio_shape(path: str, sr: int):
-    """(n_channels, n_samples) of a clip from its HEADER alone (the file pipeline groups clips by length before any sample is
-    read); the rate check of load_audio applies."""
+    """(n_channels, n_samples) of a clip AS load_audio(path, sr) WILL RETURN IT, from its header alone (the file pipeline groups
+    clips by length before any sample is read): a file of another rate counts with its resampled length."""
     if path.endswith('.npy'):
         with open(path, 'rb') as f:
             shape, _, _ = _npy_header(f)
@@ -56,9 +59,10 @@ def audio_shape(path: str, sr: int):
         return int(shape[0]), int(shape[1])
     from scipy.io import wavfile
     rate, data = wavfile.read(path, mmap=True)
+    n = int(data.shape[0])
     if rate != sr:
-        raise ValueError('{}: sample rate {} != configured fs {} (resampling is not supported)'.format(path, rate, sr))
-    return (1, int(data.shape[0])) if data.ndim == 1 else (int(data.shape[1]), int(data.shape[0]))
+        n = int(np.ceil(n * (float(sr) / rate)))                      # librosa.resample: n_samples = ceil(n * ratio)
+    return (1, n) if data.ndim == 1 else (int(data.shape[1]), n)
 
 
 def _npy_header(f):
