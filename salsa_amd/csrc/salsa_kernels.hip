@@ -185,6 +185,9 @@ __device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const
 #ifndef K1_STD
 #define K1_STD 1 // the STD instantiations of stft_kernel for the dataset scripts' layout (0: always the general kernel; bit-identical)
 #endif
+#ifndef K1_LITE_WAVES
+#define K1_LITE_WAVES 1 // workgroups per CU the SALSA-Lite / IPD instantiations are compiled for (1: no register cap -> 184 VGPRs, 2 waves per SIMD)
+#endif
 template <bool LITE> struct k1_cfg {
     static constexpr int NF = LITE ? 8 : K1_NF_FULL;
 };
@@ -201,7 +204,7 @@ template <bool LITE> struct k1_cfg {
 // arithmetic in the same order: outputs are bit-identical (tests: goldens, fused-vs-three-kernel identity).  The DOA band stays a
 // run-time range (FOA 1..192, MIC 1..85, any fmin / fmax).
 template <int N, typename T, bool LITE, int NF, int NPAIRS = 2, bool SC = false, bool STD = false>
-__global__ __launch_bounds__(256, (SC && !LITE) ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+__global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
