@@ -185,11 +185,50 @@ __device__ __forceinline__ void st_off_nt(float4 *base, unsigned byte_off, const
 #ifndef K1_STD
 #define K1_STD 1 // the STD instantiations of stft_kernel for the dataset scripts' layout (0: always the general kernel; bit-identical)
 #endif
+// angle(X_c conj(X_0)) of SALSA-Lite / IPD (salsa_lite_feature_extraction.py:111) in float32, with the roundings spelled out: one
+// product rounded, the other fused into the sum.  Left to the compiler, `a * b + c * d` was contracted one way in the general
+// instantiation and the other way in the Lite STD one (1 % of the phases differed in the last bit); every instantiation calls this.
+__device__ __forceinline__ float lite_phase(const float2 xc, const float2 x0)
+{
+#pragma clang fp contract(off)
+    float wr = fmaf(xc.x, x0.x, xc.y * x0.y);
+    float wi = fmaf(xc.y, x0.x, -(xc.x * x0.y));
+    const float m = fmaxf(fabsf(wr), fabsf(wi));
+    if (m < 1e-30f && m > 0.f) { // products of tiny spectra: redo the product scaled up (exact)
+        const float sx = 0x1p60f;
+        wr = fmaf(xc.x * sx, x0.x * sx, (xc.y * sx) * (x0.y * sx));
+        wi = fmaf(xc.y * sx, x0.x * sx, -((xc.x * sx) * (x0.y * sx)));
+    }
+    return atan2f(wi, wr);
+}
+
+// SALSA-Lite STD instantiation: channel 0's spectrum of the wave's frame, kept from the pair-0 item for the pair-1 item, lives in LDS
+// (8 KB per workgroup) instead of ten registers per lane.  A function-local __shared__ array of a template that only the Lite STD
+// instantiation calls, so that no other instantiation's LDS layout moves (an 8-byte dummy array cost the full-SALSA kernel 2.5 %).
+template <bool ON> struct k1_x0_store {
+    static __device__ __forceinline__ float2 *get()
+    {
+        __shared__ float2 a[4 * 4 * 64];
+        return a;
+    }
+};
+template <> struct k1_x0_store<false> {
+    static __device__ __forceinline__ float2 *get() { return nullptr; }
+};
+#ifndef K1_LITE_STD
+#define K1_LITE_STD 1 // the STD instantiation of the SALSA-Lite / IPD kernel (planar 4-channel audio, n_fft 512, no scaler); 0: the general kernel (bit-identical)
+#endif
+#ifndef K1_LITE_STD_WAVES
+#define K1_LITE_STD_WAVES 3 // workgroups per CU the Lite STD instantiation is compiled for
+#endif
 #ifndef K1_LITE_WAVES
 #define K1_LITE_WAVES 1 // workgroups per CU the SALSA-Lite / IPD instantiations are compiled for (1: no register cap -> 184 VGPRs, 2 waves per SIMD)
 #endif
+#ifndef K1_NF_LITE
+#define K1_NF_LITE 8 // frames per wave of the SALSA-Lite / IPD instantiations
+#endif
 template <bool LITE> struct k1_cfg {
-    static constexpr int NF = LITE ? 8 : K1_NF_FULL;
+    static constexpr int NF = LITE ? K1_NF_LITE : K1_NF_FULL;
 };
 
 // SC (round 4): the instantiation launched when a scaler is attached keeps the [4][F] mean / std tables in LDS.  It is a separate
@@ -204,7 +243,7 @@ template <bool LITE> struct k1_cfg {
 // arithmetic in the same order: outputs are bit-identical (tests: goldens, fused-vs-three-kernel identity).  The DOA band stays a
 // run-time range (FOA 1..192, MIC 1..85, any fmin / fmax).
 template <int N, typename T, bool LITE, int NF, int NPAIRS = 2, bool SC = false, bool STD = false>
-__global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
+__global__ __launch_bounds__(256, LITE ? (STD ? K1_LITE_STD_WAVES : K1_LITE_WAVES) : SC ? 3 : 1) void stft_kernel(const KParams kp, const float *__restrict__ audio,
                                                    const double *__restrict__ window,
                                                    const cplx<double> *__restrict__ tw, float *__restrict__ out,
                                                    float4 *__restrict__ Xs)
@@ -257,7 +296,7 @@ __global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_k
     // samples of one item: 2 channels x R strided points per lane.  Straight-line code on the (wave-uniform) interior
     // path -- no per-load branching; frames that overlap a clip end take the reflect path (np.pad(mode='reflect'); one
     // fold suffices because Ns > N/2, checked on the host).
-    static_assert(!STD || (N == 512 && !LITE && NPAIRS == 2), "STD is the dataset scripts' full-SALSA configuration");
+    static_assert(!STD || (N == 512 && NPAIRS == 2 && !(LITE && SC)), "STD is the dataset scripts' configuration: n_fft 512, planar 4-channel audio");
     const bool planar = STD ? true : kp.layout == SALSA_LAYOUT_PLANAR;
     const int sstride = planar ? 1 : nch;
     // Item order.  Full SALSA: PAIR-major (all the wave's frames of channels 0/1, then of channels 2/3), so consecutive
@@ -328,7 +367,8 @@ __global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_k
         return kp.sc_mean ? (v - ld_off(kp.sc_mean, off)) / ld_off(kp.sc_std, off) : v;
     };
     const unsigned plane = 4u * (unsigned)(Tn * kp.F); // bytes of one output channel of a clip
-    float2 x0keep[R / 2 + 1];                     // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1
+    float2 x0keep[(LITE && STD) ? 1 : R / 2 + 1]; // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1 (Lite STD: in LDS)
+    float2 *const x0s = k1_x0_store<LITE && STD>::get() + (LITE && STD ? w * 4 * 64 + lane : 0);
 
     for (int item = 0; item < nitems; item++) {
         const int t = t_begin + K1_TSTEP * item_frame(item);
@@ -415,15 +455,7 @@ __global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_k
                     // channel c goes to output plane NCH + c - 1, i.e. NCH - 1 and NCH planes above this pair's spectrogram
                     auto phase = [&](const float2 xc) -> float {
                         if (!(f < kp.upper)) return 0.f; // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
-                        float wr = xc.x * x0.x + xc.y * x0.y;
-                        float wi = xc.y * x0.x - xc.x * x0.y;
-                        const float m = fmaxf(fabsf(wr), fabsf(wi));
-                        if (m < 1e-30f && m > 0.f) { // products of tiny spectra: redo the product scaled up (exact)
-                            const float sx = 0x1p60f;
-                            wr = (xc.x * sx) * (x0.x * sx) + (xc.y * sx) * (x0.y * sx);
-                            wi = (xc.y * sx) * (x0.x * sx) - (xc.x * sx) * (x0.y * sx);
-                        }
-                        return atan2f(wi, wr) * inv_scale;
+                        return lite_phase(xc, x0) * inv_scale;
                     };
                     if (pr >= 1) st_off(o, off + (unsigned)(nch - 1) * plane, phase(xa));
                     st_off(o, off + (unsigned)nch * plane, phase(xb));
@@ -455,25 +487,68 @@ __global__ __launch_bounds__(256, LITE ? K1_LITE_WAVES : SC ? 3 : 1) void stft_k
                 pw[w][1][lane - 1] = pb;
             }
         };
+        // Lite STD: same arithmetic as emit_bin's SALSA-Lite branch.  What is fixed per register here: register r holds bins 64 r .. 64 r + 63,
+        // so whether it has any bin below the cutoff, and any bin whose phase is not zeroed by :120, are wave-uniform tests (scalar
+        // branches around whole blocks instead of exec-masked code); channel 0's spectrum goes through LDS; no Nyquist item.
+        auto emit_lite_std = [&](auto rc, const cplx<T> a, const cplx<T> bm) {
+            constexpr int r = decltype(rc)::value;
+            if (64 * r >= kp.cutoff) return;                       // wave-uniform: no bin of this register is written
+            const bool any_phase = 64 * r - kp.lower < kp.upper;   // wave-uniform: some bin of this register keeps its phase (:120)
+            const int k = lane + 64 * r;
+            cplx<T> Xa, Xb;
+            salsa::unpack_pair_prescaled(a, bm, Xa, Xb);
+            const float2 xa = make_float2((float)Xa.re, (float)Xa.im); // the reference stores its STFT as complex64
+            const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
+            const float pa = power32(xa), pb = power32(xb);
+            float2 x0 = xa;
+            if (any_phase) {
+                if (pr == 0) x0s[r * 64] = xa;
+                else x0 = x0s[r * 64];
+            }
+            if (k >= kp.lower && k < kp.cutoff) {
+                const int f = k - kp.lower;
+                const unsigned off = 4u * (unsigned)((c0 * Tn + t) * kp.F + f);
+                st_off(o, off, db10(pa));
+                st_off(o, off + plane, db10(pb));
+                float pha = 0.f, phb = 0.f;
+                if (any_phase) {
+                    const float inv_scale = kp.feature == SALSA_FEATURE_IPD ? 0.318309886183790672f
+                                                                           : (float)(1.0 / (kp.delta * (double)(k == 0 ? 1 : k)));
+                    auto phase = [&](const float2 xc) -> float {
+                        if (!(f < kp.upper)) return 0.f; // ":120 phase_vector[:, :, upper_bin:] = 0" indexes the CROPPED axis
+                        return lite_phase(xc, x0) * inv_scale;
+                    };
+                    if (pr >= 1) pha = phase(xa);
+                    phb = phase(xb);
+                }
+                if (pr >= 1) st_off(o, off + 3u * plane, pha);
+                st_off(o, off + 4u * plane, phb);
+            }
+        };
 #pragma unroll
         for (int r = 0; r < R / 2; r++) {
             // mirror of k = lane + 64 r is N-k = (64-lane) + 64 (R-1-r): register R-1-r of lane 64-lane;
             // lane 0: N - 64 r = 64 (R-r), its own register (R-r) mod R
             cplx<T> bm = {__shfl(v[R - 1 - r].re, mlane), __shfl(v[R - 1 - r].im, mlane)};
             if (lane == 0) bm = v[(R - r) & (R - 1)];
-            if constexpr (STD) {
+            if constexpr (STD && LITE) {
+                if (r == 0) emit_lite_std(std::integral_constant<int, 0>{}, v[r], bm);
+                else if (r == 1) emit_lite_std(std::integral_constant<int, 1>{}, v[r], bm);
+                else if (r == 2) emit_lite_std(std::integral_constant<int, 2>{}, v[r], bm);
+                else emit_lite_std(std::integral_constant<int, 3>{}, v[r], bm);
+            } else if constexpr (STD) {
                 if (r == 0) emit_std(std::integral_constant<int, 0>{}, v[r], bm);
                 else if (r == 1) emit_std(std::integral_constant<int, 1>{}, v[r], bm);
                 else if (r == 2) emit_std(std::integral_constant<int, 2>{}, v[r], bm);
                 else emit_std(std::integral_constant<int, 3>{}, v[r], bm);
             } else {
-                emit_bin(lane + 64 * r, v[r], bm, x0keep[r]);
+                emit_bin(lane + 64 * r, v[r], bm, x0keep[(LITE && STD) ? 0 : r]);
             }
             __builtin_amdgcn_sched_barrier(0); // one bin at a time: keeps the live set (and the VGPR count) small
         }
-        if (!STD && lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2], x0keep[R / 2]); // (STD: bin 256 is in no DOA band, row or compressed row)
+        if (!STD && lane == 0) emit_bin(N / 2, v[R / 2], v[R / 2], x0keep[(LITE && STD) ? 0 : R / 2]); // (STD: bin 256 is in no DOA band, row or compressed row)
         // ---- compressed high-frequency rows of W: sum of 8 (last row 7) bins times 1/8
-        if constexpr (STD) {
+        if constexpr (STD && !LITE) {
             // eight groups x two channels = lanes 0..15: two 16-byte LDS reads and a fixed chain of eight additions in the order of
             // the loop below (the seventh row's missing eighth term is skipped, not added as zero: pw[..][63] is never written)
             wave_lds_fence();
@@ -2452,7 +2527,11 @@ static int launch_stft(salsa_plan *pl, const KParams &kp, const float *d_audio, 
     const bool std_layout = K1_STD && pl->p.n_fft == 512 && !lite && !single && kp.feature == SALSA_FEATURE_SALSA && kp.compress &&
                             kp.spec_lo == 1 && kp.spec_hi == 193 && kp.ident == 192 && kp.F == 200 && kp.nch == 4 &&
                             kp.layout == SALSA_LAYOUT_PLANAR && kp.pair_sel < 0;
-    if (std_layout) {
+    const bool lite_std = K1_LITE_STD && pl->p.n_fft == 512 && lite && kp.nch == 4 && kp.layout == SALSA_LAYOUT_PLANAR && !kp.sc_mean &&
+                          kp.cutoff <= 256 && kp.pair_sel < 0;
+    if (lite_std) {
+        hipLaunchKernelGGL((stft_kernel<512, double, true, NF_LITE, 2, false, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
+    } else if (std_layout) {
         constexpr size_t SCT_BYTES = 2 * 4 * 256 * sizeof(float);
         if (kp.sc_mean) hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, true, true>), grid, dim3(256), SCT_BYTES, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);
         else hipLaunchKernelGGL((stft_kernel<512, double, false, NF_FULL, 2, false, true>), grid, dim3(256), 0, s, kp, d_audio, pl->d_window, pl->d_tw, d_out, Xs);

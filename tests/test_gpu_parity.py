@@ -283,6 +283,27 @@ def test_batched_clips_against_oracle(dev, oracle, fmt, fmax, layout):
     assert np.array_equal(solo[0], out[1])
 
 
+@pytest.mark.parametrize('ftype,fmax', [('salsa_lite', 2000), ('salsa_ipd', 2000), ('salsa_lite', 4000), ('salsa_lite', 9000)])
+def test_lite_std_instantiation_equals_the_general_kernel(dev, oracle, ftype, fmax):
+    """Round 6: planar 4-channel audio takes the Lite STD instantiation of the STFT kernel (channel 0's spectrum through LDS, per-register
+    band tests, 3 waves per SIMD); the same clips INTERLEAVED take the general kernel.  Bit-equal outputs -- incl. ragged lengths (reflect
+    path), a silent stretch, spectra tiny enough for the scaled phase product -- and one clip against the oracle."""
+    ys = np.stack([synth_clip(900 + i, 24000 * 5 + 137) for i in range(6)])
+    ys[5, :, :3000] = 0.0
+    ys[4] *= 1e-18
+    a = torch.from_numpy(ys).to(dev)
+    std = _extractor(audio_format='mic', feature_type=ftype, fmax_doa=fmax).extract(a)
+    gen = _extractor(audio_format='mic', feature_type=ftype, fmax_doa=fmax, audio_layout='interleaved').extract(a.permute(0, 2, 1).contiguous())
+    assert std.shape == gen.shape == (6, 7, 401, 191)
+    assert torch.equal(std, gen), 'differing elements: %d' % int((std != gen).sum())
+    _check_lite(std[1].cpu().numpy(), oracle.extract_lite(ys[1], fmax_doa=fmax, feature_type=ftype), ftype=ftype)
+    for n in (300, 813, 3001):                                    # tiny clips: every frame on the reflect path
+        y = torch.from_numpy(synth_clip(40 + n, n)[None]).to(dev)
+        s1 = _extractor(audio_format='mic', feature_type=ftype, fmax_doa=fmax).extract(y)
+        g1 = _extractor(audio_format='mic', feature_type=ftype, fmax_doa=fmax, audio_layout='interleaved').extract(y.permute(0, 2, 1).contiguous())
+        assert torch.equal(s1, g1), n
+
+
 def test_ragged_and_tiny_clips_against_oracle(dev, oracle):
     for n in (300, 511, 512, 813, 2999, 3000, 3001):       # around hop / n_fft boundaries; heavy reflect padding
         y = synth_clip(900 + n, n)
