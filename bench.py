@@ -497,6 +497,33 @@ def main():
             if args.feature == 'salsa':
                 pcie['harness'] = harness_bench(fmt, fmax, args.batch, n_samples, host)
 
+    lite_leg = None
+    if world == 1 and args.feature == 'salsa':
+        # ---- SURVEY 8(a8) / BASELINE config 1's feature on the GPU (reported, never `value`): SALSA-Lite MIC on the same 32 x 60-s batch --
+        # one launch of the STFT kernel's Lite STD instantiation per step; algorithmic bytes 48 715 748 per clip
+        try:
+            lex = SalsaExtractor(audio_format='mic', feature_type='salsa_lite', fmax_doa=2000, device=dev)
+            lout = torch.empty((args.batch,) + tuple(lex.output_shape(n_samples)), dtype=torch.float32, device=dev)
+            for _ in range(args.warmup):
+                lex.extract(audio, out=lout)
+            lt = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    lex.extract(audio, out=lout)
+                torch.cuda.synchronize()
+                lt.append((time.perf_counter() - t0) / args.steps)
+            lms = 1e3 * float(np.median(lt))
+            lbytes = args.batch * (4 * n_samples * 4 + 7 * int(lout.shape[2]) * int(lout.shape[3]) * 4)
+            lite_leg = {'workload': 'SALSA-Lite MIC (fmax_doa 2000): batch %dx%.0f-s 4-ch clips, 1 GPU' % (args.batch, args.seconds),
+                        'ms_per_step': round(lms, 4), 'value': round(args.batch * args.seconds / (lms * 1e-3), 1), 'unit': 'audio-seconds/s',
+                        'algorithmic_bytes': lbytes, 'achieved_gbs': round(lbytes / (lms * 1e-3) / 1e9, 1),
+                        'frac_of_8tbs': round(lbytes / (lms * 1e-3) / 8e12, 4), 'timing': 'median of 3 blocks of %d steps, wall clock' % args.steps}
+            del lex, lout
+            torch.cuda.empty_cache()
+        except Exception as e:                      # (a reported extra: never takes the line down)
+            lite_leg = {'error': '%s: %s' % (type(e).__name__, e)}
     # ---- second half of the metric: CRNN training (its own timed region; every rank takes part in the data-parallel run)
     del ex, out, audio
     torch.cuda.empty_cache()
@@ -538,6 +565,7 @@ def main():
             'crnn': done.get('crnn'),
             'config4': done.get('config4'),
             'inference': done.get('inference'),
+            'salsa_lite': lite_leg,
         }
         if status or failures:
             ln['status'] = status or 'partial: %s failed' % ', '.join(failures)
