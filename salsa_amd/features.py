@@ -240,7 +240,7 @@ class _FilePipeline:
 
             def read_one(path, dst, planar):
                 t0 = time.perf_counter()
-                sio.load_audio_into(path, fs, dst, planar)
+                sio.load_audio_into(path, fs, dst, planar, device=self.exs[0].device)
                 return time.perf_counter() - t0
 
             def publish(keep):
@@ -448,7 +448,7 @@ def _extract_split(ex, audio_dir, feature_dir, fs, batch_size, shard=None, clear
             _log.debug('clip %d %s -> %s', count, fn, f.shape)
 
     for count, audio_fn in todo:
-        audio_input = sio.load_audio(os.path.join(audio_dir, audio_fn), sr=fs)
+        audio_input = sio.load_audio(os.path.join(audio_dir, audio_fn), sr=fs, device=ex.device)
         assert audio_input.shape[0] == 4, '{}: expected a 4-channel clip'.format(audio_fn)
         lst = pending.setdefault(audio_input.shape[1], [])
         lst.append((count, audio_fn, audio_input))

@@ -22,7 +22,7 @@ from . import _hdf5   # noqa: E402  (round 6: the HDF5 C library itself through 
 HAVE_HDF5 = HAVE_H5PY or _hdf5.available()    # real .h5 files are written / read; False: the numpy twins
 
 
-def load_audio(path: str, sr: int) -> np.ndarray:
+def load_audio(path: str, sr: int, device=None) -> np.ndarray:
     """-> (n_channels, n_samples) float32 in [-1, 1), like librosa.load(path, sr=sr, mono=False, dtype=float32)
     (salsa_feature_extraction.py:353).  A WAV file whose native rate is not ``sr`` is RESAMPLED as librosa does ('kaiser_best',
     result fixed to ceil(n * sr / native) samples) -- on the device (salsa_amd/resample.py -> salsa_resample_batch; round 6); the
@@ -45,7 +45,7 @@ def load_audio(path: str, sr: int) -> np.ndarray:
     x = np.ascontiguousarray(x.T)
     if rate != sr:
         from . import resample
-        x = resample.resample_host_array(x, int(rate), int(sr))
+        x = resample.resample_host_array(x, int(rate), int(sr), device=device)
     return x
 
 
@@ -71,7 +71,7 @@ def _npy_header(f):
     return np.lib.format.read_array_header_1_0(f) if major == 1 else np.lib.format.read_array_header_2_0(f)
 
 
-def load_audio_into(path: str, sr: int, dst: np.ndarray, planar: bool = True) -> None:
+def load_audio_into(path: str, sr: int, dst: np.ndarray, planar: bool = True, device=None) -> None:
     """load_audio(path, sr) written INTO ``dst`` -- (n_channels, n_samples) float32 when ``planar``, (n_samples, n_channels) otherwise
     -- without an intermediate array where the file already holds that layout: a float32 C-order .npy is read straight into the
     (pinned) destination with one readinto()."""
@@ -87,7 +87,7 @@ def load_audio_into(path: str, sr: int, dst: np.ndarray, planar: bool = True) ->
                         raise IOError('{}: truncated .npy payload'.format(path))
                     got += k
                 return
-    a = load_audio(path, sr)
+    a = load_audio(path, sr, device=device)
     dst[...] = a if planar else a.T
 
 

@@ -87,11 +87,12 @@ def resample(x: torch.Tensor, sr_orig: int, sr_new: int) -> torch.Tensor:
     return y
 
 
-def resample_host_array(a: np.ndarray, sr_orig: int, sr_new: int) -> np.ndarray:
+def resample_host_array(a: np.ndarray, sr_orig: int, sr_new: int, device=None) -> np.ndarray:
     """(n_channels, n) float32 host array -> resampled host array, through the device (the loader's use: io.load_audio)."""
     if not torch.cuda.is_available():
         raise RuntimeError('resampling a {} Hz file to {} Hz runs on the GPU (salsa_resample_batch); no GPU is visible'.format(sr_orig, sr_new))
-    with torch.cuda.stream(torch.cuda.Stream()):                           # loader threads: a stream of their own
-        y = resample(torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda(non_blocking=False), sr_orig, sr_new)
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(dev)):    # loader threads: the caller's GPU, a stream of their own
+        y = resample(torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev), sr_orig, sr_new)
         out = y.cpu().numpy()
     return out
