@@ -205,6 +205,7 @@ def main():
     ap.add_argument('--no-crnn', action='store_true', help='skip the CRNN-training half of the metric')
     ap.add_argument('--no-infer', action='store_true', help='skip the batched-inference leg (BASELINE config 5)')
     ap.add_argument('--no-torch-baseline', action='store_true', help='skip the stock-PyTorch training step timed beside the CRNN leg (N = 1 only)')
+    ap.add_argument('--infer-torch-baseline', action='store_true', help='also time config 5 with the CRNN forward on stock PyTorch-ROCm kernels (inference.torch_baseline; ~70 s more)')
     ap.add_argument('--no-config4', action='store_true', help='skip the on-the-fly SALSA-MIC + augmentation training leg (BASELINE config 4)')
     ap.add_argument('--tolerate-crnn-failure', action='store_true', help='exit 0 even if a CRNN-side leg (crnn / config4 / inference) failed')
     ap.add_argument('--infer-steps', type=int, default=5, help='timed steps of the inference leg; a step is the WHOLE --infer-clips job once through')
@@ -645,6 +646,14 @@ def main():
         tb = done['crnn']['torch_baseline']
         if tb and tb.get('value'):
             done['crnn']['speedup_vs_torch_baseline'] = round(done['crnn']['value'] / tb['value'], 3)
+    # (opt-in: the child process costs ~70 s -- MIOpen's solver search on 60-s maps -- and the default run is kept near two minutes)
+    if world == 1 and isinstance(done.get('inference'), dict) and 'value' in done['inference'] and args.infer_torch_baseline:
+        from bench_crnn import torch_infer_baseline
+        torch.cuda.empty_cache()
+        done['inference']['torch_baseline'] = torch_infer_baseline()
+        tb = done['inference']['torch_baseline']
+        if tb and tb.get('value'):
+            done['inference']['speedup_vs_torch_baseline'] = round(done['inference']['value'] / tb['value'], 3)
     # CPU baseline: rank 0 only, for every N (after the process group is gone, so the other ranks are not kept waiting on a
     # collective); the same bounded sample at every N
     if not args.no_cpu_baseline:

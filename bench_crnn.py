@@ -364,6 +364,25 @@ def torch_baseline(steps=8, warmup=3, batch=32, timeout=420):
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
 
 
+def torch_infer_baseline(clips=64, steps=2, warmup=1, timeout=300):
+    """Config 5's leg with every hand-written CRNN kernel switched off (the feature extraction stays ours: stock PyTorch has none): torch /
+    MIOpen convolutions with folded BatchNorm, MIOpen GRU, bf16 autocast -- a stated baseline for `inference`, measured in a child process on
+    a smaller job (the rate does not depend on the job size: sub-batches of 32); an error object on any failure, never an exception."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(STOCK_ENV)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--infer', '--clips', str(clips), '--steps', str(steps),
+                            '--warmup', str(warmup)], capture_output=True, text=True, timeout=timeout, env=env)
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+        return {'value': line['value'], 'unit': line['unit'], 'clips': clips, 'steps': steps, 'warmup': warmup,
+                'p50_latency_ms_per_clip': line.get('p50_latency_ms_per_clip'),
+                'kind': 'stock PyTorch-ROCm CRNN forward (MIOpen / hipBLASLt / torch kernels) behind the same HIP feature extraction, same model, '
+                        'sub-batch, dtype and box', 'switches': 'SALSA_HIP_* = 0 (bench_crnn.STOCK_ENV)'}
+    except Exception as e:  # noqa: BLE001 - a baseline, not the product
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
+
+
 def _flush_c_stdio():
     """push out whatever native libraries (RCCL's version banner) left in libc's stdout buffer -- every rank, as soon as its
     process group is gone, so that nothing of it can land after rank 0's result line"""
