@@ -102,6 +102,32 @@ def harness_bench(fmt, fmax, batch, n_samples, host):
             dt = time.perf_counter() - t0
             res[name] = {'s': round(dt, 3), 'audio_s_per_s': round(secs / dt, 1)}
         features.USE_FILE_PIPELINE = True
+        # the dataset's own format: 16-bit PCM WAV clips (TNSSE2021).  Round 6: the file's data chunk is uploaded as it is and converted on
+        # the device (salsa_pcm_to_planar); `host_decode` = the same tree with the numpy decoder (SALSA_RAW_PCM=0)
+        try:
+            from scipy.io import wavfile
+            dw = os.path.join(tmp, 'data_wav', fmt + '_dev')
+            os.makedirs(dw)
+            os.makedirs(os.path.join(tmp, 'data_wav', fmt + '_eval'))
+            for i in range(n_clips):
+                y = host[i % batch]
+                wavfile.write(os.path.join(dw, 'fold1_room1_mix%03d.wav' % i), 24000, np.clip(y.T * (30000.0 / np.abs(y).max()), -32768, 32767).astype(np.int16))
+            cfg_w = dict(cfg, data_dir=os.path.join(tmp, 'data_wav'), feature_dir=os.path.join(tmp, 'feat_wav'))
+            cfg_w_path = os.path.join(tmp, 'cfg_wav.yml')
+            yaml.safe_dump(cfg_w, open(cfg_w_path, 'w'))
+            for name, flag in (('wav16_pipelined', True), ('wav16_pipelined_host_decode', False)):
+                features.RAW_PCM = flag
+                features.extract_features(data_config=cfg_w_path, task='feature', batch_size=batch)
+                t0 = time.perf_counter()
+                features.extract_features(data_config=cfg_w_path, task='feature', batch_size=batch)
+                dt = time.perf_counter() - t0
+                res[name] = {'s': round(dt, 3), 'audio_s_per_s': round(secs / dt, 1)}
+            shutil.rmtree(os.path.join(tmp, 'feat_wav'), ignore_errors=True)
+            shutil.rmtree(os.path.join(tmp, 'data_wav'), ignore_errors=True)
+        except Exception as e:      # (a reported extra)
+            res['wav16_pipelined'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        finally:
+            features.RAW_PCM = True
         # the reference's default task: features AND the scaler (round 6: its statistics are taken on the device while the dev split
         # is extracted; SALSA_FUSED_SCALER=0 / the second figure: compute_scaler reads every feature file back, as the reference does)
         for name, flag in (('feature_scaler', True), ('feature_scaler_rereading_files', False)):

@@ -19,6 +19,7 @@
  *   SeldDataset train transforms, utilities/transforms.py (datamodule.py:45-82)   salsa_augment_batch
  *   SalsaFeatures / SalsaLiteFeatures.__call__, contrib/salsa_flexible.py:237-265 (+ :286-400)   salsa_extract_batch with SALSA_FLAG_FLEX, salsa_to_freq_major
  *   librosa.load(sr=fs)'s resampling of a file of another rate, dataset/salsa_feature_extraction.py:353   salsa_resample_batch
+ *   librosa.load's PCM -> float32 (channels, samples) conversion, dataset/salsa_feature_extraction.py:353    salsa_pcm_to_planar
  *
  * Conventions: every function returns 0 on success or a negative SALSA_E* code; salsa_last_error() gives the
  * message of the calling thread's last failure.  Device pointers are caller-owned; work is enqueued asynchronously
@@ -241,6 +242,17 @@ int salsa_selftest_decibel(const float *d_power, float *d_db, int64_t n, void *h
 int salsa_resample_batch(const float *d_x, int n_rows, int64_t n_in, float *d_y, int64_t n_out, int64_t n_out_fixed, double sample_ratio,
                          const double *d_interp_win, const double *d_interp_delta, int n_win, int num_table,
                          const double *d_time_register, void *hip_stream);
+
+/* The sample conversion inside librosa.load(path, sr=fs, mono=False, dtype=float32) (dataset/salsa_feature_extraction.py:353, lite :93:
+ * soundfile reads the WAV's interleaved PCM frames as float32, librosa transposes to (channels, samples)).  d_pcm: the file's data chunk as
+ * it is on disk, [n_frames][n_channels] samples of `sample_format`, aligned to one frame; d_out: float32 [n_channels][n_frames] (what
+ * salsa_extract_batch takes as one planar clip).  int16 / 2^15, int32 / 2^31, (uint8 - 128) / 2^7, float32 as is: libsndfile's normalisation,
+ * exact in float32.  Lets a loader upload raw file bytes (half the PCIe traffic for 16-bit clips) and do no arithmetic on the host. */
+#define SALSA_PCM_S16 1
+#define SALSA_PCM_S32 2
+#define SALSA_PCM_U8 3
+#define SALSA_PCM_F32 4
+int salsa_pcm_to_planar(const void *d_pcm, int sample_format, int n_channels, int64_t n_frames, float *d_out, void *hip_stream);
 
 #ifdef __cplusplus
 }

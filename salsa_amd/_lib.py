@@ -142,6 +142,7 @@ def load():
     L.salsa_augment_batch.argtypes = [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.salsa_to_freq_major.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, vp]
     L.salsa_selftest_decibel.argtypes = [vp, vp, C.c_int64, vp]
+    L.salsa_pcm_to_planar.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp, vp]
     L.salsa_resample_batch.argtypes = [vp, C.c_int, C.c_int64, vp, C.c_int64, C.c_int64, C.c_double, vp, vp, C.c_int, C.c_int, vp, vp]
     L.salsa_multichannel_workspace_bytes.restype = C.c_size_t
     L.salsa_multichannel_workspace_bytes.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
@@ -169,7 +170,7 @@ EXPORTS = ['salsa_abi_version', 'salsa_build_flags', 'salsa_last_error', 'salsa_
            'salsa_logspec_batch', 'salsa_eigvec_workspace_bytes', 'salsa_eigvec_batch', 'salsa_eigvec_feature_batch', 'salsa_plan_set_stats', 'salsa_plan_set_fused', 'salsa_plan_set_timing',
            'salsa_plan_read_timing', 'salsa_plan_set_groups', 'salsa_plan_set_pipeline', 'salsa_scaler_accumulate', 'salsa_normalize_batch', 'salsa_plan_set_scaler',
            'salsa_to_freq_major', 'salsa_augment_batch', 'salsa_selftest_decibel', 'salsa_multichannel_workspace_bytes', 'salsa_extract_multichannel',
-           'salsa_resample_batch']
+           'salsa_resample_batch', 'salsa_pcm_to_planar']
 GRU_EXPORTS = ['salsa_gru_scan_fwd', 'salsa_gru_scan_fwd_regw', 'salsa_gru_scan_bwd', 'salsa_gru_scan_bwd_regw']
 NN_EXPORTS = ['salsa_nn_avgpool2x2_fwd', 'salsa_nn_avgpool2x2_bwd', 'salsa_nn_conv3x3_c64', 'salsa_nn_conv3x3_c64_bias_act', 'salsa_nn_conv3x3_c64_wrw', 'salsa_nn_conv3x3_stem', 'salsa_nn_conv3x3_c64_bias_act_pool', 'salsa_nn_conv3x3_wide_supported', 'salsa_nn_conv3x3_wide', 'salsa_nn_conv3x3_wide_bias_act', 'salsa_nn_conv3x3_wide_wrw_supported', 'salsa_nn_conv3x3_wide_table_len', 'salsa_nn_conv3x3_wide_tile_count', 'salsa_nn_conv3x3_wide_tables', 'salsa_nn_conv3x3_wide_wrw', 'salsa_nn_bn_supported', 'salsa_nn_bn_workspace_bytes', 'salsa_nn_bn_train_fwd',
               'salsa_nn_bn_eval_fwd', 'salsa_nn_bn_bwd', 'salsa_nn_bn_train_fwd_pool', 'salsa_nn_bn_bwd_pool', 'salsa_nn_conv_filter_bank', 'salsa_nn_conv3x3_c64_stats_blocks', 'salsa_nn_conv3x3_c64_stats', 'salsa_nn_conv3x3_stem_wrw', 'salsa_nn_conv3x3_stem_stats_blocks', 'salsa_nn_conv3x3_stem_stats', 'salsa_nn_conv3x3_stem_wrw_bn', 'salsa_nn_conv1x1_supported', 'salsa_nn_conv1x1', 'salsa_nn_conv1x1_wrw_supported', 'salsa_nn_conv1x1_wrw', 'salsa_nn_seld_loss', 'salsa_nn_seld_loss_bwd', 'salsa_nn_freq_mean_fwd',

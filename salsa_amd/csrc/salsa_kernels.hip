@@ -2087,6 +2087,43 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     y[row * n_fix + t] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------- PCM -> planar float32
+// What librosa.load(path, sr=fs, mono=False, dtype=np.float32) (salsa_feature_extraction.py:353) does to a WAV file's samples before
+// anything else: soundfile reads the interleaved PCM frames as float32 (libsndfile's normalisation: int16 / 2^15, int32 / 2^31,
+// uint8 (x - 128) / 2^7, float32 as is -- all exact in float32 up to the one rounding of a 32-bit integer) and librosa transposes to
+// (channels, samples).  The file pipeline uploads the file's data chunk as it is (half the PCIe bytes for 16-bit clips, no host
+// arithmetic) and this kernel converts + de-interleaves: one thread per frame, one vector load of the frame's samples, one
+// coalesced 4-byte store per channel plane.
+template <typename S, int NCH> __device__ __forceinline__ void pcm_frame(const void *pcm, long n, float *v)
+{
+    struct alignas(sizeof(S) * NCH) vec { S x[NCH]; };
+    const vec f = ((const vec *)pcm)[n];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if constexpr (sizeof(S) == 2) v[c] = (float)f.x[c] * (1.0f / 32768.0f);
+        else if constexpr (sizeof(S) == 1) v[c] = ((float)f.x[c] - 128.0f) * (1.0f / 128.0f);
+        else if constexpr (std::is_same<S, int>::value) v[c] = (float)((double)f.x[c] * (1.0 / 2147483648.0));
+        else v[c] = f.x[c];
+    }
+}
+template <typename S> __global__ __launch_bounds__(256) void pcm_to_planar_kernel(const void *__restrict__ pcm, float *__restrict__ out, long n_frames, int nch)
+{
+    const long n = blockIdx.x * 256L + threadIdx.x;
+    if (n >= n_frames) return;
+    if (nch == 4) {
+        float v[4];
+        pcm_frame<S, 4>(pcm, n, v);
+#pragma unroll
+        for (int c = 0; c < 4; c++) out[c * n_frames + n] = v[c];
+    } else {
+        for (int c = 0; c < nch; c++) {
+            float v[1];
+            pcm_frame<S, 1>(pcm, n * nch + c, v);
+            out[c * n_frames + n] = v[0];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ augmentation
 // The reference's SALSA training augmentation (utilities/transforms.py; recipe in dataset/datamodule.py:45-52, :73-82) as
 // ONE gather pass over a feature batch [B][7][T][F]: channel swap (FOA :394-437 / MIC :469-523, applied in the reference's
@@ -3036,6 +3073,25 @@ int salsa_resample_batch(const float *d_x, int n_rows, int64_t n_in, float *d_y,
     dim3 grid((unsigned)((n_out_fixed + 255) / 256), (unsigned)n_rows);
     hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, d_x, d_y, (long)n_in, (long)n_out, (long)n_out_fixed,
                        d_interp_win, d_interp_delta, n_win, num_table, scale, index_step, d_time_register);
+    HIP_TRY(hipGetLastError());
+    return SALSA_OK;
+}
+
+int salsa_pcm_to_planar(const void *d_pcm, int sample_format, int n_channels, int64_t n_frames, float *d_out, void *hip_stream)
+{
+    if (!d_pcm || !d_out || n_channels <= 0 || n_channels > 64 || n_frames <= 0 || (n_frames + 255) / 256 >= INT32_MAX)
+        return fail(SALSA_EINVAL, "salsa_pcm_to_planar: bad argument%s");
+    const size_t fb = (size_t)n_channels * (sample_format == SALSA_PCM_S16 ? 2 : sample_format == SALSA_PCM_U8 ? 1 : 4);
+    if (n_channels == 4 && ((uintptr_t)d_pcm % fb)) return fail(SALSA_EINVAL, "salsa_pcm_to_planar: d_pcm must be aligned to one frame%s");
+    dim3 grid((unsigned)((n_frames + 255) / 256));
+    hipStream_t s = (hipStream_t)hip_stream;
+    switch (sample_format) {
+    case SALSA_PCM_S16: hipLaunchKernelGGL(pcm_to_planar_kernel<short>, grid, dim3(256), 0, s, d_pcm, d_out, (long)n_frames, n_channels); break;
+    case SALSA_PCM_S32: hipLaunchKernelGGL(pcm_to_planar_kernel<int>, grid, dim3(256), 0, s, d_pcm, d_out, (long)n_frames, n_channels); break;
+    case SALSA_PCM_U8: hipLaunchKernelGGL(pcm_to_planar_kernel<unsigned char>, grid, dim3(256), 0, s, d_pcm, d_out, (long)n_frames, n_channels); break;
+    case SALSA_PCM_F32: hipLaunchKernelGGL(pcm_to_planar_kernel<float>, grid, dim3(256), 0, s, d_pcm, d_out, (long)n_frames, n_channels); break;
+    default: return fail(SALSA_EINVAL, "salsa_pcm_to_planar: unknown sample format%s");
+    }
     HIP_TRY(hipGetLastError());
     return SALSA_OK;
 }

@@ -243,6 +243,12 @@ class _FilePipeline:
                 sio.load_audio_into(path, fs, dst, planar, device=self.exs[0].device)
                 return time.perf_counter() - t0
 
+            def read_raw(path, offset, dst_bytes):
+                t0 = time.perf_counter()
+                sio.read_raw_into(path, offset, dst_bytes)
+                return time.perf_counter() - t0
+            planar_plan = self.exs[0].audio_layout == 'planar'
+
             def publish(keep):
                 """hand the oldest closed slots to the device stage once their reads have finished (never more than `keep` waiting)"""
                 while pending and (len(pending) > keep or all(f.done() for f in pending[0][1])):
@@ -263,7 +269,10 @@ class _FilePipeline:
                     if self.stop.is_set():
                         return
                     path = os.path.join(audio_dir, fn)
-                    n_ch, n = sio.audio_shape(path, fs)     # header only
+                    # a plain PCM / float WAV at the configured rate goes to the device AS IT IS ON DISK (round 6: decoding 16-bit clips
+                    # on the host -- astype, scale, transpose -- was the harness' bound on the dataset's own format: 14 k audio-s/s)
+                    lay = sio.wav_pcm_layout(path, fs) if (RAW_PCM and planar_plan) else None
+                    n_ch, n = (lay[1], lay[2]) if lay else sio.audio_shape(path, fs)     # header only
                     assert n_ch == 4, '{}: expected a 4-channel clip'.format(fn)
                     if n not in open_:
                         if len(open_) >= self.depth - 2:    # never hold every slot half-filled: flush the fullest bucket
@@ -274,9 +283,16 @@ class _FilePipeline:
                         if sl is _STOP:
                             return
                         self._buffers(sl, cap, n)
+                        sl['raw'] = [0] * cap               # per clip: 0 = float32 samples in the slot, else its SALSA_PCM_* code
                         open_[n] = (sl, [], [])
                     sl, items, futs = open_[n]
-                    futs.append(pool.submit(read_one, path, sl['h_in'].numpy()[len(items)], sl['ex'].audio_layout == 'planar'))
+                    place = sl['h_in'].numpy()[len(items)]
+                    if lay:
+                        sl['raw'][len(items)] = lay[0]
+                        nbytes = n * 4 * {1: 2, 2: 4, 3: 1, 4: 4}[lay[0]]
+                        futs.append(pool.submit(read_raw, path, lay[3], place.reshape(-1).view(np.uint8)[:nbytes]))
+                    else:
+                        futs.append(pool.submit(read_one, path, place, planar_plan))
                     items.append((count, fn))
                     if len(items) == cap:
                         close(n)
@@ -329,7 +345,17 @@ class _FilePipeline:
                     sl['d_in'][:b].copy_(sl['h_in'][:b], non_blocking=True)
                 sl['s_run'].wait_stream(sl['s_in'])
                 with torch.cuda.stream(sl['s_run']):
-                    sl['ex'].extract(sl['d_in'][:b], out=sl['d_out'][:b])
+                    d_audio = sl['d_in']
+                    if any(sl['raw'][:b]):                  # raw file bytes in the slot: convert + de-interleave on the device
+                        if sl.get('f_d_conv') is None or sl['f_d_conv'].numel() < sl['cap_in']:
+                            sl['f_d_conv'] = torch.empty(sl['cap_in'], dtype=torch.float32, device=sl['ex'].device)
+                        d_audio = sl['f_d_conv'][:sl['d_in'].numel()].view(sl['d_in'].shape)
+                        for k in range(b):
+                            if sl['raw'][k]:
+                                pcm_to_planar(sl['d_in'][k], sl['raw'][k], d_audio[k])
+                            else:
+                                d_audio[k].copy_(sl['d_in'][k], non_blocking=True)
+                    sl['ex'].extract(d_audio[:b], out=sl['d_out'][:b])
                     if scaler is not None:
                         from .extractor import scaler_accumulate
                         F_ = sl['d_out'].shape[3]
@@ -366,6 +392,18 @@ class _FilePipeline:
             stats.update(batches=n_batches, read_s=t_read[0], write_s=t_write[0], **t_wait)
 
 
+def pcm_to_planar(d_raw, code, d_out):
+    """d_raw: a clip's place in a device slot holding the WAV file's data chunk ([N][4] samples of SALSA_PCM_* ``code``) -> d_out float32
+    [4][N], on the current stream (salsa_pcm_to_planar)."""
+    import ctypes as C
+    from . import _lib
+    torch = _torch()
+    rc = _lib.load().salsa_pcm_to_planar(C.c_void_p(d_raw.data_ptr()), int(code), int(d_out.shape[0]), int(d_out.shape[1]),
+                                         C.c_void_p(d_out.data_ptr()), C.c_void_p(torch.cuda.current_stream(d_out.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError('salsa_pcm_to_planar failed (%d): %s' % (rc, _lib.last_error()))
+
+
 _STOP = object()
 _PIPELINES = {}
 
@@ -393,6 +431,7 @@ def release_file_pipelines():
 SLOT_CLIPS = 8     # clips per pipeline slot: small slots overlap read / copy / extract / copy / write sooner and pin 4x less host memory
                    # than 32-clip ones; the device does 8 x 60-s clips in ~0.45 ms, far below a slot's 8 ms of PCIe time
 USE_FILE_PIPELINE = os.environ.get('SALSA_FILE_PIPELINE', '1') != '0'
+RAW_PCM = os.environ.get('SALSA_RAW_PCM', '1') != '0'     # plain PCM WAV clips: upload the file's bytes, convert on the device (0: decode on the host)
 FUSED_SCALER = os.environ.get('SALSA_FUSED_SCALER', '1') != '0'   # task='feature_scaler': the scaler from device statistics (0: re-read the files)
 
 

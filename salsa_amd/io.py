@@ -65,6 +65,39 @@ def audio_shape(path: str, sr: int):
     return (1, n) if data.ndim == 1 else (int(data.shape[1]), n)
 
 
+PCM_CODES = {'int16': 1, 'int32': 2, 'uint8': 3, 'float32': 4}      # SALSA_PCM_* of include/salsa_hip.h
+
+
+def wav_pcm_layout(path: str, sr: int):
+    """-> (sample_format, n_channels, n_frames, byte offset of the samples) of a WAV file whose data chunk the DEVICE can turn into what
+    load_audio(path, sr) returns (salsa_pcm_to_planar: plain little-endian 8 / 16 / 32-bit PCM or float32 at the configured rate), else None
+    (another rate: resampling; 24-bit containers, big-endian, anything scipy cannot memory-map: the host decoder of load_audio)."""
+    if not path.endswith('.wav'):
+        return None
+    try:
+        from scipy.io import wavfile
+        rate, data = wavfile.read(path, mmap=True)
+    except Exception:
+        return None
+    if rate != sr or not isinstance(data, np.memmap) or data.dtype.name not in PCM_CODES or data.dtype.byteorder == '>' \
+            or not data.flags.c_contiguous or data.shape[0] == 0:
+        return None
+    return PCM_CODES[data.dtype.name], (1 if data.ndim == 1 else int(data.shape[1])), int(data.shape[0]), int(data.offset)
+
+
+def read_raw_into(path: str, offset: int, dst_bytes: np.ndarray) -> None:
+    """len(dst_bytes) bytes of the file from ``offset`` straight into a (pinned) uint8 buffer"""
+    mv = memoryview(dst_bytes).cast('B')
+    with open(path, 'rb') as f:
+        f.seek(offset)
+        got = 0
+        while got < len(mv):
+            k = f.readinto(mv[got:])
+            if not k:
+                raise IOError('{}: truncated data chunk'.format(path))
+            got += k
+
+
 def _npy_header(f):
     """-> (shape, fortran_order, dtype) of an open .npy file, positioned at the data"""
     major, _ = np.lib.format.read_magic(f)

@@ -153,3 +153,95 @@ def test_harness_on_a_48_khz_tree_equals_the_tree_of_the_resampled_clips(oracle,
         assert got.shape == ref.shape == (7, 1 + y.shape[1] // 300, 200)
         from test_gpu_parity import _check
         _check(got, ref, aux['margin'])
+
+
+# ------------------------------------------------------------------------------------------- raw PCM upload (round 6)
+def _pcm_variants(n=5003, seed=5):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (n, 4))
+    return {'int16': (x * 32767).astype(np.int16), 'int32': (x * 2147483647).astype(np.int32), 'uint8': ((x + 1) * 127.5).astype(np.uint8),
+            'float32': x.astype(np.float32)}
+
+
+def test_wav_pcm_layout_names_what_the_device_can_take(tmp_path):
+    """the loader's header probe: plain PCM / float WAV at the configured rate -> (format code, channels, frames, offset of the samples);
+    the bytes at that offset are the interleaved samples; anything else -> None (host decoder / resampler)"""
+    from scipy.io import wavfile
+    from salsa_amd import io as sio
+    for name, data in _pcm_variants().items():
+        p = str(tmp_path / (name + '.wav'))
+        wavfile.write(p, 24000, data)
+        code, n_ch, n, off = sio.wav_pcm_layout(p, 24000)
+        assert (code, n_ch, n) == (sio.PCM_CODES[name], 4, data.shape[0])
+        raw = np.zeros(data.nbytes, np.uint8)
+        sio.read_raw_into(p, off, raw)
+        assert np.array_equal(raw.view(data.dtype).reshape(data.shape), data)
+        assert sio.wav_pcm_layout(p, 48000) is None                       # another rate: the resampling loader
+    np.save(tmp_path / 'a.npy', np.zeros((4, 10), np.float32))
+    assert sio.wav_pcm_layout(str(tmp_path / 'a.npy'), 24000) is None
+    (tmp_path / 'junk.wav').write_bytes(b'not a wav file at all')
+    assert sio.wav_pcm_layout(str(tmp_path / 'junk.wav'), 24000) is None
+
+
+@pytest.mark.gpu
+def test_pcm_to_planar_equals_the_host_decoder(tmp_path):
+    """salsa_pcm_to_planar on the file's data chunk = load_audio's numpy decode (libsndfile's normalisation), bit for bit, for the four
+    sample formats; + a mono file through the generic channel count"""
+    import torch
+    from scipy.io import wavfile
+    from salsa_amd import io as sio
+    from salsa_amd.features import pcm_to_planar
+    for name, data in _pcm_variants().items():
+        p = str(tmp_path / (name + '.wav'))
+        wavfile.write(p, 24000, data)
+        ref = sio.load_audio(p, 24000)
+        code, n_ch, n, off = sio.wav_pcm_layout(p, 24000)
+        raw = np.zeros(data.nbytes, np.uint8)
+        sio.read_raw_into(p, off, raw)
+        d_raw = torch.zeros(4 * n, dtype=torch.float32, device='cuda')      # a slot place: room for float32 [4][n]
+        d_raw.view(torch.uint8)[:raw.size].copy_(torch.from_numpy(raw))
+        out = torch.empty((4, n), dtype=torch.float32, device='cuda')
+        pcm_to_planar(d_raw, code, out)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    mono = _pcm_variants()['int16'][:, 0].copy()
+    wavfile.write(str(tmp_path / 'mono.wav'), 24000, mono)
+    ref = sio.load_audio(str(tmp_path / 'mono.wav'), 24000)
+    out = torch.empty((1, mono.shape[0]), dtype=torch.float32, device='cuda')
+    pcm_to_planar(torch.from_numpy(mono).cuda(), 1, out)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_harness_uploads_raw_pcm_and_gives_the_same_files(tmp_path):
+    """a tree of 16-bit WAV clips (TNSSE2021's format) + one float32 WAV + one .npy clip of ragged lengths: the pipeline with the raw-PCM
+    upload writes byte-identical feature files to the pipeline decoding on the host"""
+    import yaml
+    from scipy.io import wavfile
+    from salsa_amd import features, io as sio
+    from salsa_amd.synth import synth_clip
+    data_dir = str(tmp_path / 'data')
+    os.makedirs(os.path.join(data_dir, 'foa_dev'))
+    os.makedirs(os.path.join(data_dir, 'foa_eval'))
+    for i, n in enumerate([72000] * 10 + [48001, 72000 - 300]):
+        y = synth_clip(300 + i, n)
+        y16 = np.clip(y.T / np.abs(y).max() * 30000, -32768, 32767).astype(np.int16)
+        wavfile.write(os.path.join(data_dir, 'foa_dev', 'c%02d.wav' % i), 24000, y16)
+    wavfile.write(os.path.join(data_dir, 'foa_dev', 'f32.wav'), 24000, synth_clip(400, 72000).T)
+    np.save(os.path.join(data_dir, 'foa_dev', 'n.npy'), synth_clip(401, 72000))
+    trees = {}
+    for raw in (True, False):
+        feat_dir = str(tmp_path / ('feat_%d' % raw))
+        cfg = {'data_dir': data_dir, 'feature_dir': feat_dir,
+               'data': {'format': 'foa', 'fs': 24000, 'n_fft': 512, 'win_len': 512, 'hop_len': 300, 'fmin_doa': 50, 'fmax_doa': 9000}}
+        with open(tmp_path / 'cfg.yml', 'w') as f:
+            yaml.safe_dump(cfg, f)
+        features.RAW_PCM = raw
+        try:
+            features.extract_features(data_config=str(tmp_path / 'cfg.yml'), task='feature', batch_size=4)
+        finally:
+            features.RAW_PCM = True
+        root = os.path.join(feat_dir, 'salsa', 'foa', '24000fs_512nfft_300nhop_5cond_9000fmaxdoa', 'foa_dev')
+        trees[raw] = {fn: sio.load_arrays(os.path.join(root, fn))['feature'] for fn in sio.feature_files(root)}
+    assert sorted(trees[True]) == sorted(trees[False]) and len(trees[True]) == 14
+    for fn in trees[True]:
+        assert np.array_equal(trees[True][fn], trees[False][fn]), fn
