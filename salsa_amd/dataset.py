@@ -1,11 +1,14 @@
 """On-device counterpart of the reference's data layer (dataset/database.py + dataset/dataloader.py) for training
-straight from raw audio (BASELINE.json config 4): clips are extracted on the GPU, kept there in the reference's
+straight from raw audio (BASELINE.json config 4) or from a tree of precomputed feature files (config 3; add_feature_files +
+load_feature_scaler = Database.load_chunk_data / load_feature_scaler): clips are extracted on the GPU, kept there in the reference's
 concatenated ``(C, sum T, F)`` layout (database.py:230-231), normalised on load with the scaler (first 4 channels only,
 :197-202) and sliced into chunks with the reference's segment index arithmetic (:98-119).  ``__getitem__`` returns the
 same 4-tuple contract as SeldDataset (dataloader.py:37-62) minus augmentation: (X (7,chunk,F), sed, doa, name).
 
 Nothing here runs in DataLoader worker processes: HIP contexts do not survive fork, so extraction happens on the
 training process' stream (SURVEY.md section 7 'hard parts')."""
+import os
+
 import numpy as np
 import torch
 
@@ -78,9 +81,10 @@ def load_classwise_gt(gt_meta_fn, n_frames: int, n_classes: int = 12, label_upsa
 
 
 class GpuFeatureBank(torch.utils.data.Dataset):
-    def __init__(self, extractor: SalsaExtractor, fs=24000, hop_len=300, label_rate=10, chunk_len_s=8.0,
-                 chunk_hop_len_s=0.5, n_classes=12, max_clip_s=60):
-        self.ex = extractor
+    def __init__(self, extractor: SalsaExtractor = None, fs=24000, hop_len=300, label_rate=10, chunk_len_s=8.0,
+                 chunk_hop_len_s=0.5, n_classes=12, max_clip_s=60, device=None):
+        self.ex = extractor                                                    # None: a bank of precomputed feature files (add_feature_files)
+        self.device = extractor.device if extractor is not None else torch.device(device if device is not None else 'cuda')
         self.fs, self.hop_len, self.label_rate, self.n_classes = fs, hop_len, label_rate, n_classes
         self.chunk_len = second2frame(chunk_len_s, fs, hop_len)
         self.chunk_hop_len = second2frame(chunk_hop_len_s, fs, hop_len)
@@ -98,9 +102,38 @@ class GpuFeatureBank(torch.utils.data.Dataset):
         """audio: float32 [B,4,N] (numpy or CUDA tensor).  Labels, one of: ``gt_meta`` = per-clip paths of DCASE metadata CSVs
         (read by load_classwise_gt, as Database.load_chunk_data does, database.py:209-211); ``sed`` / ``doa`` = per-clip label
         arrays at label rate, (T_lab, n_classes) and (T_lab, 3*n_classes); none of them -> zeros (inference)."""
-        assert gt_meta is None or (sed is None and doa is None), 'give either metadata CSVs or label arrays'
+        assert self.ex is not None, 'this bank was built without an extractor: it takes feature files only'
         a = audio if torch.is_tensor(audio) else torch.from_numpy(np.ascontiguousarray(audio, np.float32))
-        feats = self.ex.extract(a.to(self.ex.device).contiguous())
+        self._ingest(self.ex.extract(a.to(self.ex.device).contiguous()), names, sed, doa, gt_meta)
+
+    def add_feature_files(self, feature_files, names=None, sed=None, doa=None, gt_meta=None):
+        """PRECOMPUTED features (BASELINE config 3; what extract_features() wrote: a 'feature' dataset (7, T, F) per clip) instead of
+        audio -- Database.load_chunk_data's file loop (database.py:190-207: read, trim to max_nframes_per_file * label_upsample_ratio
+        frames; the normalisation of :197-202 happens in finalize(), on the device).  Clips of one shape go to the device in one copy."""
+        from . import io as sio
+        names = [os.path.splitext(os.path.basename(f))[0] for f in feature_files] if names is None else list(names)
+        assert len(names) == len(feature_files)
+        arrays = [np.ascontiguousarray(sio.load_arrays(f)['feature'], np.float32) for f in feature_files]
+        i = 0
+        while i < len(arrays):                                                 # runs of equal shape, file order kept (the pointers are sequential)
+            j = i + 1
+            while j < len(arrays) and arrays[j].shape == arrays[i].shape:
+                j += 1
+            feats = torch.from_numpy(np.stack(arrays[i:j])).to(self.device)
+            sl = slice(i, j)
+            self._ingest(feats, names[sl], None if sed is None else sed[sl], None if doa is None else doa[sl],
+                         None if gt_meta is None else gt_meta[sl])
+            i = j
+
+    def load_feature_scaler(self, scaler_file):
+        """<fmt>_feature_scaler.h5 -> the bank's scaler: Database.load_feature_scaler (database.py:87-96: 'mean', 'std' of shape (4, 1, F))"""
+        from . import io as sio
+        z = sio.load_arrays(scaler_file)
+        self.set_scaler(z['mean'], z['std'])
+        return self.mean, self.std
+
+    def _ingest(self, feats, names, sed=None, doa=None, gt_meta=None):
+        assert gt_meta is None or (sed is None and doa is None), 'give either metadata CSVs or label arrays'
         n_frames = min(feats.shape[2], self.max_frames)
         n_frames -= n_frames % self.upsample
         feats = feats[:, :, :n_frames].contiguous()
@@ -134,7 +167,7 @@ class GpuFeatureBank(torch.utils.data.Dataset):
         return self.mean, self.std
 
     def set_scaler(self, mean, std):
-        self.mean, self.std = torch.as_tensor(mean), torch.as_tensor(std)
+        self.mean, self.std = torch.as_tensor(np.asarray(mean, np.float32)), torch.as_tensor(np.asarray(std, np.float32))
 
     def finalize(self):
         """concatenate along time (database.py:230) and normalise the spectrogram channels in place."""

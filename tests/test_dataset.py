@@ -1,5 +1,7 @@
 """Data-layer mirror: segment index arithmetic against an independent statement of database.py:98-119 (CPU) and the
 on-device feature bank against the oracle + numpy normalisation (GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,3 +112,77 @@ def test_feature_bank_matches_oracle_and_numpy_normalisation(oracle):
     np.testing.assert_allclose(x[4:].cpu().numpy(), cat[4:, s:s + 640], rtol=1e-5, atol=1e-6)
     xb, _, _, names = bank.batch([0, 5, len(bank) - 1])
     assert xb.shape == (3, 7, 640, 200) and names[0] == 'a'
+
+
+@pytest.mark.gpu
+def test_feature_bank_from_a_precomputed_feature_tree(tmp_path):
+    """BASELINE config 3's data path: extract_features() writes the tree (feature files + scaler file), a bank built from those FILES
+    (Database.load_chunk_data :190-219 + load_feature_scaler :87-96) yields the same chunks as the reference's numpy arithmetic on the
+    files -- (x - mean) / std on the first 4 channels, trim to a multiple of 8 frames, segment indices, labels from the CSVs -- and the
+    same as a bank fed the audio with that scaler."""
+    import torch
+    import yaml
+    from scipy.io import wavfile
+    from conftest import load_golden
+    from salsa_amd import io as sio
+    from salsa_amd.dataset import GpuFeatureBank, get_segment_idxes
+    from salsa_amd.extractor import SalsaExtractor
+    from salsa_amd.features import extract_features
+    from salsa_amd.synth import synth_clip
+    meta, a = load_golden('g17_labels')
+    data_dir, feat_dir = str(tmp_path / 'data'), str(tmp_path / 'feat')
+    os.makedirs(os.path.join(data_dir, 'foa_dev'))
+    os.makedirs(os.path.join(data_dir, 'foa_eval'))
+    names = ['repeat_in_track', 'short_clip', 'third']
+    lens = [640 * 300, 640 * 300, 700 * 300 + 17]
+    ys = [synth_clip(70 + i, n) for i, n in enumerate(lens)]
+    for n, y in zip(names, ys):
+        wavfile.write(os.path.join(data_dir, 'foa_dev', n + '.wav'), 24000, y.T)
+    csvs = []
+    for n in names:
+        fn = tmp_path / (n + '.csv')
+        fn.write_text(meta['cases'][n if n != 'third' else 'short_clip']['csv'])
+        csvs.append(str(fn))
+    cfg = {'data_dir': data_dir, 'feature_dir': feat_dir,
+           'data': {'format': 'foa', 'fs': 24000, 'n_fft': 512, 'win_len': 512, 'hop_len': 300, 'fmin_doa': 50, 'fmax_doa': 9000}}
+    with open(tmp_path / 'cfg.yml', 'w') as f:
+        yaml.safe_dump(cfg, f)
+    extract_features(data_config=str(tmp_path / 'cfg.yml'))                   # task='feature_scaler': files + scaler
+    root = os.path.join(feat_dir, 'salsa', 'foa', '24000fs_512nfft_300nhop_5cond_9000fmaxdoa')
+    files = [os.path.join(root, 'foa_dev', n + '.h5') for n in names]
+    bank = GpuFeatureBank(max_clip_s=60)                                      # no extractor: files only
+    bank.load_feature_scaler(os.path.join(root, 'foa_feature_scaler.h5'))
+    bank.add_feature_files(files, gt_meta=csvs)
+    bank.finalize()
+    with pytest.raises(AssertionError):
+        bank.add_clips(np.stack(ys[:2]), names[:2])
+    # the reference's arithmetic on the files (database.py:190-231)
+    sc = sio.load_arrays(os.path.join(root, 'foa_feature_scaler.h5'))
+    pointer, cat, idx, who = 0, [], [], []
+    for n, fpath in zip(names, files):
+        feat = sio.load_arrays(fpath)['feature'].copy()
+        feat[:4] = (feat[:4] - sc['mean']) / sc['std']
+        n_frames = min(feat.shape[1], 600 * 8)
+        n_frames -= n_frames % 8                                             # (whole label frames: what the 4800-frame trim gives 60-s clips)
+        cat.append(feat[:, :n_frames])
+        ii, pointer = get_segment_idxes(n_frames, 640, 40, 1, pointer)
+        idx += ii
+        who += [n] * len(ii)
+    cat = np.concatenate(cat, axis=1)
+    assert bank.chunk_idx == idx and bank.chunk_name == who and len(bank) == len(idx) >= 4
+    for i in (0, 1, len(bank) - 1):
+        x, sed, doa, name = bank[i]
+        assert name == who[i] and x.shape == (7, 640, 200)
+        np.testing.assert_array_equal(x[4:].cpu().numpy(), cat[4:, idx[i]:idx[i] + 640])
+        np.testing.assert_allclose(x[:4].cpu().numpy(), cat[:4, idx[i]:idx[i] + 640], rtol=1e-6, atol=1e-6)   # float32 (x - mean) / std on the device
+    x0, sed0, doa0, _ = bank[0]
+    assert torch.equal(sed0.cpu(), torch.from_numpy(a['repeat_in_track_sed'])) and torch.equal(doa0.cpu(), torch.from_numpy(a['repeat_in_track_doa']))
+    # ... and the same chunks as a bank fed the AUDIO with that scaler
+    bank2 = GpuFeatureBank(SalsaExtractor(), max_clip_s=60)
+    bank2.add_clips(np.stack(ys[:2]), names[:2], gt_meta=csvs[:2])
+    bank2.add_clips(ys[2][None], names[2:], gt_meta=csvs[2:])
+    bank2.load_feature_scaler(os.path.join(root, 'foa_feature_scaler.h5'))
+    bank2.finalize()
+    assert bank2.chunk_idx == bank.chunk_idx
+    for i in (0, len(bank) - 1):
+        assert torch.equal(bank2[i][0], bank[i][0]) and torch.equal(bank2[i][1], bank[i][1])
