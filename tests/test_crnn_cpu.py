@@ -322,7 +322,8 @@ def test_train_bench_ddp_branch_under_gloo(tmp_path):
     assert l0['n_gpus'] == 2 and l0['rccl_ranks'] == 2 and l0['backend'] == 'gloo' and l0['scaling'] == 'weak'
     assert l0['config']['parallelism'] == 'dp2' and l0['config']['grad_allreduce'] == 'fp32'
     assert l0['value'] > 0 and np.isfinite(l0['final_loss'])
-    assert abs(l0['value'] - 2 * 2 * 2 / (l0['ms_per_step'] * 2 / 1e3)) / l0['value'] < 1e-2   # whole-job chunks / max-rank time
+    # whole-job chunks / max-rank time (the line rounds `value` to 0.1: on a slow CPU that alone is > 1 % of a rate near 4 chunks/s)
+    assert abs(l0['value'] - 2 * 2 * 2 / (l0['ms_per_step'] * 2 / 1e3)) < 1e-2 * l0['value'] + 0.051
 
 
 def test_weight_gradient_buffer_pool_hands_out_fresh_zeros():
