@@ -186,3 +186,56 @@ def test_feature_bank_from_a_precomputed_feature_tree(tmp_path):
     assert bank2.chunk_idx == bank.chunk_idx
     for i in (0, len(bank) - 1):
         assert torch.equal(bank2[i][0], bank[i][0]) and torch.equal(bank2[i][1], bank[i][1])
+
+
+def _g18_feature(seed, T, F):
+    # tools/make_golden.py::g18_feature_tree_rng restated: the fixture's feature files are functions of their seeds
+    rng = np.random.RandomState(seed)
+    f = np.empty((7, T, F), np.float32)
+    f[:4] = (-40 + 12 * rng.standard_normal((4, T, F))).astype(np.float32)
+    f[4:] = (rng.uniform(-1, 1, (3, T, F)) * (rng.uniform(size=(3, T, F)) < 0.25)).astype(np.float32)
+    return f
+
+
+@pytest.mark.gpu
+def test_feature_bank_from_files_reproduces_the_references_get_split(tmp_path):
+    """golden g18 = the REFERENCE's Database.get_split('train', stage='fit') on a synthetic tree of precomputed feature files (database.py:
+    120-231).  The bank built from the same files (real HDF5 through salsa_amd.io) must hold the same split: chunk start indices of
+    features and labels, file name per chunk, targets bit for bit, normalised features to float32 round-off (and, restated in numpy, to
+    the reference's SHA-256), 60-s clips trimmed to 4800 frames."""
+    import hashlib
+    import torch
+    from conftest import load_golden
+    from salsa_amd import io as sio
+    from salsa_amd.dataset import GpuFeatureBank
+    meta, a = load_golden('g18_feature_tree')
+    F = meta['F']
+    files, csvs, cat = [], [], []
+    for name, seed, T in meta['clips']:
+        f = _g18_feature(seed, T, F)
+        files.append(sio.save_arrays(str(tmp_path / (name + '.h5')), feature=f))
+        (tmp_path / (name + '.csv')).write_text(meta['csv'][name])
+        csvs.append(str(tmp_path / (name + '.csv')))
+        g = f.copy()
+        g[:4] = (g[:4] - a['mean']) / a['std']                                 # database.py:197-202
+        cat.append(g[:, :min(T, 4800)])
+    cat = np.concatenate(cat, axis=1)
+    assert list(cat.shape) == meta['features_shape'] and hashlib.sha256(cat.tobytes()).hexdigest() == meta['features_sha256']
+    scaler_file = sio.save_arrays(str(tmp_path / 'foa_feature_scaler.h5'), mean=a['mean'], std=a['std'])
+    bank = GpuFeatureBank(max_clip_s=60)
+    bank.load_feature_scaler(scaler_file)
+    bank.add_feature_files(files, names=[c[0] for c in meta['clips']], gt_meta=csvs)
+    bank.finalize()
+    assert bank.chunk_idx == a['feature_chunk_idxes'].tolist() and bank.gt_idx == a['gt_chunk_idxes'].tolist()
+    assert bank.chunk_name == meta['filename_list'] and bank.chunk_len == meta['feature_chunk_len']
+    assert bank.chunk_name.count(meta['clips'][-1][0]) == meta['test_batch_size']
+    assert torch.equal(bank.sed_all.cpu(), torch.from_numpy(a['sed_targets'])) and torch.equal(bank.doa_all.cpu(), torch.from_numpy(a['doa_targets']))
+    feats = bank.features.cpu().numpy()
+    assert list(feats.shape) == meta['features_shape']
+    np.testing.assert_array_equal(feats[4:, ::16], a['features_every_16th_frame'][4:])
+    np.testing.assert_allclose(feats[:4, ::16], a['features_every_16th_frame'][:4], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(feats[:4], cat[:4], rtol=1e-6, atol=1e-6)
+    x, sed, doa, name = bank[len(bank) - 1]
+    s, g = int(a['feature_chunk_idxes'][-1]), int(a['gt_chunk_idxes'][-1])
+    assert name == meta['filename_list'][-1] and x.shape == (7, 640, F) and sed.shape == (meta['gt_chunk_len'], 12)
+    assert torch.equal(sed.cpu(), torch.from_numpy(a['sed_targets'][g:g + 80])) and np.array_equal(x[4:].cpu().numpy(), cat[4:, s:s + 640])

@@ -449,6 +449,63 @@ def g17_labels():
     shutil.rmtree(tmp)
 
 
+def g18_feature_tree_rng(seed, T, F):
+    """the synthetic feature file of fixture g18 (a function of its seed: the test regenerates it)"""
+    rng = np.random.RandomState(seed)
+    f = np.empty((7, T, F), np.float32)
+    f[:4] = (-40 + 12 * rng.standard_normal((4, T, F))).astype(np.float32)        # dB-like spectrogram channels
+    f[4:] = (rng.uniform(-1, 1, (3, T, F)) * (rng.uniform(size=(3, T, F)) < 0.25)).astype(np.float32)
+    return f
+
+
+def g18_feature_tree():
+    """Database.get_split('train', stage='fit') of the reference (dataset/database.py:120-231: load_feature_scaler :87-96, load_chunk_data
+    :175-240 -- read 'feature', normalise the first 4 channels, trim to 4800 frames, labels from the metadata CSV, segment indices -- and
+    the concatenation) on a synthetic tree of PRECOMPUTED feature files: BASELINE config 3's data path.  Three clips: two of 4801 frames
+    (a 60-s clip: trimmed to 4800) and one of 1280 frames; F = 6 keeps the fixture small.  The feature files are functions of their seeds
+    (g18_feature_tree_rng, restated by the test); stored: the split's chunk indices, targets, file names, and the normalised features (every 16th frame + the SHA-256 of all of them)."""
+    from dataset.database import Database  # the reference (h5py = the in-memory shim of ref_shims)
+    import h5py
+    tmp = tempfile.mkdtemp()
+    F, clips = 6, [('fold1_room1_mix001', 181, 4801), ('fold1_room1_mix002', 182, 1280), ('fold2_room1_mix003', 183, 4801)]
+    root = os.path.join(tmp, 'feat')
+    os.makedirs(os.path.join(root, 'foa_dev'))
+    os.makedirs(os.path.join(tmp, 'gt', 'metadata_dev'))
+    os.makedirs(os.path.join(tmp, 'meta', 'original'))
+    rng = np.random.RandomState(18)
+    mean = (-40 + rng.standard_normal((4, 1, F))).astype(np.float32)
+    std = (10 + rng.uniform(size=(4, 1, F))).astype(np.float32)
+    with h5py.File(os.path.join(root, 'foa_feature_scaler.h5'), 'w') as hf:
+        hf.create_dataset('mean', data=mean, dtype=np.float32)
+        hf.create_dataset('std', data=std, dtype=np.float32)
+    csv_text = {}
+    for name, seed, T in clips:
+        with h5py.File(os.path.join(root, 'foa_dev', name + '.h5'), 'w') as hf:
+            hf.create_dataset('feature', data=g18_feature_tree_rng(seed, T, F), dtype=np.float32)
+        r = np.random.RandomState(seed)
+        rows = []
+        for trk in range(3):
+            t0, cls = int(r.randint(0, T // 8 - 60)), int(r.randint(0, 12))
+            rows += [(f, cls, trk, int(r.randint(-180, 181)), int(r.randint(-90, 91))) for f in range(t0, t0 + int(r.randint(10, 60)))]
+        csv_text[name] = ''.join('%d,%d,%d,%d,%d\n' % x for x in rows)
+        open(os.path.join(tmp, 'gt', 'metadata_dev', name + '.csv'), 'w').write(csv_text[name])
+    open(os.path.join(tmp, 'meta', 'original', 'train.csv'), 'w').write('filename\n' + ''.join(n + '\n' for n, _, _ in clips))
+    db = Database(feature_root_dir=root, gt_meta_root_dir=os.path.join(tmp, 'gt'), audio_format='foa', n_classes=12, fs=24000, n_fft=512,
+                  hop_len=300, label_rate=10, train_chunk_len_s=8.0, train_chunk_hop_len_s=0.5)
+    d = db.get_split('train', split_meta_dir=os.path.join(tmp, 'meta', 'original'), stage='fit')
+    meta = {'what': "Database.get_split('train', stage='fit')", 'clips': [[n, s, t] for n, s, t in clips], 'F': F, 'csv': csv_text,
+            'filename_list': list(d['filename_list']), 'test_batch_size': int(d['test_batch_size']),
+            'feature_chunk_len': int(d['feature_chunk_len']), 'gt_chunk_len': int(d['gt_chunk_len'])}
+    feats = d['features'].astype(np.float32)
+    meta['features_shape'] = list(feats.shape)
+    meta['features_sha256'] = sha256_of(feats)
+    save('g18_feature_tree', meta, mean=mean, std=std, features_every_16th_frame=feats[:, ::16].copy(), sed_targets=d['sed_targets'].astype(np.float32),
+         doa_targets=d['doa_targets'].astype(np.float32), feature_chunk_idxes=np.asarray(d['feature_chunk_idxes'], np.int64),
+         gt_chunk_idxes=np.asarray(d['gt_chunk_idxes'], np.int64))
+    print('    %d chunks, features %s, last file has %d chunks' % (len(d['feature_chunk_idxes']), d['features'].shape, d['test_batch_size']))
+    shutil.rmtree(tmp)
+
+
 if __name__ == '__main__':
     g5_w_and_bins()
     g1_eigvec()
@@ -462,3 +519,4 @@ if __name__ == '__main__':
     g11_augment()
     g12_metrics()
     g17_labels()
+    g18_feature_tree()
