@@ -203,12 +203,13 @@ __device__ __forceinline__ float lite_phase(const float2 xc, const float2 x0)
 }
 
 // SALSA-Lite STD instantiation: channel 0's spectrum of the wave's frame, kept from the pair-0 item for the pair-1 item, lives in LDS
-// (8 KB per workgroup) instead of ten registers per lane.  A function-local __shared__ array of a template that only the Lite STD
+// (16 KB per workgroup) instead of ten registers per lane.  A function-local __shared__ array of a template that only the Lite STD
 // instantiation calls, so that no other instantiation's LDS layout moves (an 8-byte dummy array cost the full-SALSA kernel 2.5 %).
+constexpr int K1_LITE_X0_SLOTS = 8; // per wave: one slot per bin register (frame-major order) or per frame of the wave (pair-major order, phase band in register 0)
 template <bool ON> struct k1_x0_store {
     static __device__ __forceinline__ float2 *get()
     {
-        __shared__ float2 a[4 * 4 * 64];
+        __shared__ float2 a[4 * K1_LITE_X0_SLOTS * 64];
         return a;
     }
 };
@@ -217,6 +218,9 @@ template <> struct k1_x0_store<false> {
 };
 #ifndef K1_LITE_STD
 #define K1_LITE_STD 1 // the STD instantiation of the SALSA-Lite / IPD kernel (planar 4-channel audio, n_fft 512, no scaler); 0: the general kernel (bit-identical)
+#endif
+#ifndef K1_LITE_PAIR_MAJOR
+#define K1_LITE_PAIR_MAJOR 1 // Lite STD: pair-major item order when the phase band fits bin register 0 (0: always frame-major; bit-identical)
 #endif
 #ifndef K1_LITE_STD_WAVES
 #define K1_LITE_STD_WAVES 3 // workgroups per CU the Lite STD instantiation is compiled for
@@ -311,11 +315,17 @@ __global__ __launch_bounds__(256, LITE ? (STD ? K1_LITE_STD_WAVES : K1_LITE_WAVE
     const int nleft_ = (Tn - t_begin + K1_TSTEP - 1) / K1_TSTEP; // frames t_begin, t_begin + K1_TSTEP, ... below Tn
     const int nfr_ = STD ? __builtin_amdgcn_readfirstlane(nleft_ < K1_NF ? nleft_ : K1_NF) : (nleft_ < K1_NF ? nleft_ : K1_NF);
     const int psel = (LITE || STD) ? -1 : kp.pair_sel; // one channel pair per launch (the pipelined schedule): item = frame
+    // Lite STD: when every bin whose phase survives :120 sits in bin register 0 (lower + upper <= 64: the dataset script's fmax_doa 2000
+    // gives bins 1..42), channel 0 of a frame is 512 B per wave and the wave's whole run of frames fits in LDS: PAIR-major order like
+    // full SALSA (the frame-major order re-read the samples neighbouring frames share from HBM: 1.6x the audio, profiles/r6_ab_notes.txt)
+    const bool lite_pm = (LITE && STD && K1_LITE_PAIR_MAJOR) ? (64 - kp.lower >= kp.upper && K1_NF <= K1_LITE_X0_SLOTS) : false;
     auto item_frame = [&](int item) {
         if (NPAIRS != 2) return PAIR_MAJOR ? item % nfr_ : item / npairs;
+        if (LITE && STD) return lite_pm ? (item >= nfr_ ? item - nfr_ : item) : item >> 1;
         return psel >= 0 ? item : PAIR_MAJOR ? (item >= nfr_ ? item - nfr_ : item) : item >> 1;
     };
     auto item_pair = [&](int item) {
+        if (LITE && STD && NPAIRS == 2) return lite_pm ? (item >= nfr_ ? 1 : 0) : item & 1;
         if (NPAIRS != 2) return PAIR_MAJOR ? item / nfr_ : item % npairs;
         return psel >= 0 ? psel : PAIR_MAJOR ? (item >= nfr_ ? 1 : 0) : item & 1;
     };
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256, LITE ? (STD ? K1_LITE_STD_WAVES : K1_LITE_WAVE
     };
     const unsigned plane = 4u * (unsigned)(Tn * kp.F); // bytes of one output channel of a clip
     float2 x0keep[(LITE && STD) ? 1 : R / 2 + 1]; // SALSA-Lite: channel-0 spectrum of this lane's bins, kept from pair 0 for pair 1 (Lite STD: in LDS)
-    float2 *const x0s = k1_x0_store<LITE && STD>::get() + (LITE && STD ? w * 4 * 64 + lane : 0);
+    float2 *const x0s = k1_x0_store<LITE && STD>::get() + (LITE && STD ? w * K1_LITE_X0_SLOTS * 64 + lane : 0);
 
     for (int item = 0; item < nitems; item++) {
         const int t = t_begin + K1_TSTEP * item_frame(item);
@@ -501,9 +511,10 @@ __global__ __launch_bounds__(256, LITE ? (STD ? K1_LITE_STD_WAVES : K1_LITE_WAVE
             const float2 xb = make_float2((float)Xb.re, (float)Xb.im);
             const float pa = power32(xa), pb = power32(xb);
             float2 x0 = xa;
-            if (any_phase) {
-                if (pr == 0) x0s[r * 64] = xa;
-                else x0 = x0s[r * 64];
+            if (any_phase) { // (pair-major order: only register 0 comes here, the slot is the frame's place in the wave's run)
+                const int slot = lite_pm ? item_frame(item) : r;
+                if (pr == 0) x0s[slot * 64] = xa;
+                else x0 = x0s[slot * 64];
             }
             if (k >= kp.lower && k < kp.cutoff) {
                 const int f = k - kp.lower;
